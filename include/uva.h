@@ -1,0 +1,115 @@
+/*
+ * uva.h -- C ABI of libuva.so, the MI355X (gfx950) per-frame super-resolution engine that
+ * replaces the `ncnn_vulkan` surface used by davlee1972/upscale_video's worker functions.
+ *
+ * Every entry point cites the reference call site (file:line under /root/reference) whose
+ * ncnn call it replaces.  Plain pointers and sizes only; no torch / numpy types.
+ * All functions returning int return 0 on success and non-zero on error (ncnn's
+ * convention for load_param/load_model/extract); uva_last_error() gives the message of the
+ * last failure on the calling thread.
+ *
+ * Threading: a uva_net belongs to one thread at a time (the reference holds one
+ * process-global net per pool worker, upscale/upscale_processing.py:22,57,65).  HIP is
+ * initialised lazily inside the calling process, so the library is safe to load in a
+ * multiprocessing "spawn" worker (:321, :565).
+ *
+ * There is NO CPU path: with no usable HIP device every compute entry point fails.
+ */
+#ifndef UVA_H
+#define UVA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UVA_ABI_VERSION 1
+
+typedef struct uva_net uva_net;
+
+/* ---- device enumeration ------------------------------------------------------------ */
+
+/* ncnn.get_gpu_count()            test_gpus.py:47 */
+int uva_get_gpu_count(void);
+/* ncnn.get_default_gpu_index()    test_gpus.py:53 */
+int uva_get_default_gpu_index(void);
+/* ncnn.get_gpu_info(i).type() / .device_name()   test_gpus.py:59-66
+ * *type: 0 discrete, 1 integrated, 2 virtual, 3 cpu (ncnn's enumeration). */
+int uva_get_gpu_info(int index, int* type, char* name, size_t name_len);
+/* ncnn.destroy_gpu_instance()     upscale/upscale_processing.py:292, :458
+ * Frees every cached device allocation of every live net (nets stay loadable). */
+void uva_destroy_gpu_instance(void);
+
+/* ---- net life cycle ---------------------------------------------------------------- */
+
+/* ncnn.Net()                      upscale/upscale_processing.py:65 */
+uva_net* uva_net_create(void);
+/* net.opt.use_vulkan_compute = True; net.set_vulkan_device(gpus[gpu])   :67-68
+ * device = HIP ordinal.  A negative index is rejected (no CPU path). */
+int uva_net_set_device(uva_net* net, int device);
+/* net.load_param(path)            :70   parses the ncnn text graph; only the
+ * SRVGGNetCompact pattern (conv3x3+PReLU stack, conv3x3, PixelShuffle r, Interp nearest r,
+ * BinaryOp add) is accepted, anything else (e.g. 4x_Valar_v1) returns an error. */
+int uva_net_load_param(uva_net* net, const char* param_path);
+/* net.load_model(path)            :71   reads the .bin stream; every byte must be
+ * consumed.  Weights are repacked for the MFMA kernels and uploaded on first use. */
+int uva_net_load_model(uva_net* net, const char* bin_path);
+/* ncnn::Net::~Net */
+void uva_net_destroy(uva_net* net);
+
+/* graph facts after load_param */
+int uva_net_scale(const uva_net* net);        /* 1, 2 or 4 */
+int uva_net_num_features(const uva_net* net); /* 64 or 24 */
+int uva_net_num_convs(const uva_net* net);    /* 18 or 10 */
+
+/* ---- inference --------------------------------------------------------------------- */
+
+/* ex = net.create_extractor(); ex.input("input", mat_in); ret, mat_out = ex.extract("output");
+ * np.array(mat_out)               upscale/upscale_processing.py:278-281, :450-453
+ * in_chw : host f32 planar [3][h][w] (what Mat.from_pixels + substract_mean_normalize made)
+ * out_chw: host f32 planar [3][h*s][w*s] (what np.array(mat_out) returns) */
+int uva_net_extract_f32(uva_net* net, const float* in_chw, int h, int w, float* out_chw);
+
+/* Fused frame call: from_pixels(PIXEL_BGR) + substract_mean_normalize + extract +
+ * transpose*255 + cv2 convertTo(CV_8U), all on the device, i.e. the arithmetic of
+ *   apply_model   upscale/upscale_processing.py:263-288   (tile_size <= 0: whole frame)
+ *   upscale_image + process_tile   :395-519               (tile_size = 960, border = 10)
+ * in : u8 HWC BGR [h][w][3], rows in_stride bytes apart
+ * out: u8 HWC BGR [h*s][w*s][3], rows out_stride bytes apart
+ * Host pointers; H2D/D2H staged through pinned buffers on the net's stream. */
+int uva_net_process_u8(uva_net* net, const uint8_t* in, int h, int w, size_t in_stride,
+                       uint8_t* out, size_t out_stride, int tile_size, int border);
+
+/* Same, with in/out already resident in this device's HBM (dense rows: in_stride = 3*w,
+ * out_stride = 3*w*s unless stated).  Asynchronous on the net's stream; follow with
+ * uva_net_synchronize().  This is the call bench.py times. */
+int uva_net_process_u8_device(uva_net* net, const void* d_in, int h, int w, size_t in_stride,
+                              void* d_out, size_t out_stride, int tile_size, int border);
+
+int uva_net_synchronize(uva_net* net);
+
+/* ---- introspection used by the parity tests and bench.py ------------------------------ */
+
+/* Activation after convolution #conv_idx (+PReLU) of the last extract/process call with
+ * tile_size <= 0, converted to host f32 planar [cout][h][w].  conv_idx in [0, nconv-2]. */
+int uva_net_debug_read_activation(uva_net* net, int conv_idx, float* out_chw, int h, int w);
+
+/* Per-kernel-kind timing with HIP events recorded on the net's stream around each launch.
+ * kind: 0 head conv, 1 trunk conv (the dominant kernel), 2 tail conv.
+ * enable != 0 starts (and resets) collection; stats are valid after uva_net_synchronize. */
+int uva_net_set_profiling(uva_net* net, int enable);
+int uva_net_kernel_stats(uva_net* net, int kind, long long* launches, double* total_ms);
+
+/* Test hook (host only, no device needed): the fp16 MFMA A-operand image convolution #conv_idx is
+ * repacked into, [k-step][m-frag][lane][8].  *needed receives the element count. */
+int uva_net_debug_packed_weights(uva_net* net, int conv_idx, uint16_t* out, size_t out_halfs, size_t* needed);
+
+const char* uva_last_error(void);
+int uva_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UVA_H */

@@ -1,0 +1,57 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (test infrastructure; oracle/oracle.c built with gcc)."""
+    from oracle import uvoracle
+    uvoracle.build()
+    return uvoracle
+
+
+@pytest.fixture(scope="session")
+def oracle_models(oracle):
+    return {k: oracle.load_model(k) for k in ("2x", "4x", "1x")}
+
+
+@pytest.fixture(scope="session")
+def uva():
+    """The product library; built on demand (hipcc cross-compiles without a GPU)."""
+    from upscale_video_amd import build
+    build.build_lib()
+    from upscale_video_amd import ncnn
+    return ncnn
+
+
+def model_paths(key):
+    from oracle import uvoracle
+    base = os.path.join(ROOT, "models", uvoracle.MODEL_FILES[key])
+    return base + ".param", base + ".bin"
+
+
+def load_net(ncnn, key, device=0):
+    net = ncnn.Net()
+    net.opt.use_vulkan_compute = True
+    net.set_vulkan_device(device)
+    p, b = model_paths(key)
+    assert net.load_param(p) == 0, getattr(net, "last_error", "")
+    assert net.load_model(b) == 0, getattr(net, "last_error", "")
+    return net
+
+
+def psnr_u8(a, b):
+    d = a.astype(np.float64) - b.astype(np.float64)
+    mse = float((d * d).mean())
+    return 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)

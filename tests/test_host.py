@@ -1,0 +1,151 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every symbol that
+include/uva.h declares, the .param/.bin loader accepts exactly the SRVGGNetCompact graphs, the
+MFMA weight image is a faithful permutation of the OIHW weights, and -- with no GPU -- every
+compute entry point fails loudly (there is no CPU path in the product)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_net, model_paths
+
+
+def test_library_exports_every_declared_symbol(uva):
+    from upscale_video_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "uva.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)   # prototypes only, not the comments
+    declared = sorted(set(re.findall(r"\b(uva_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 20
+    assert sorted(_lib.SYMBOLS) == declared
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert _lib.load().uva_abi_version() == 1
+
+
+@pytest.mark.parametrize("key,facts", [("2x", (2, 64, 18)), ("4x", (4, 64, 18)), ("1x", (1, 24, 10))])
+def test_loader_accepts_compact_models(uva, key, facts):
+    net = load_net(uva, key)
+    assert (net.scale, net.num_features, net.num_convs) == facts
+
+
+def test_loader_rejects_valar_and_bad_files(uva, tmp_path):
+    net = uva.Net()
+    assert net.load_param(os.path.join(ROOT, "models", "4x_Valar_v1.param")) != 0
+    assert "unsupported layer type" in net.last_error
+    assert net.load_param(str(tmp_path / "missing.param")) != 0
+    p, b = model_paths("2x")
+    assert net.load_model(b) != 0            # load_model before load_param
+    assert net.load_param(p) == 0
+    raw = open(b, "rb").read()
+    (tmp_path / "short.bin").write_bytes(raw[:-7])
+    assert net.load_model(str(tmp_path / "short.bin")) != 0
+    (tmp_path / "long.bin").write_bytes(raw + b"\0\0\0\0")
+    assert net.load_model(str(tmp_path / "long.bin")) != 0 and "unread bytes" in net.last_error
+    # weights of another graph do not fit
+    assert net.load_model(model_paths("1x")[1]) != 0
+    assert net.load_model(b) == 0
+
+
+def test_negative_device_rejected(uva):
+    net = uva.Net()
+    with pytest.raises(Exception, match="no CPU path"):
+        net.set_vulkan_device(-1)
+
+
+def _unpack_conv(pk, nf, cout):
+    spp = nf // 8
+    ko_n = 9 * spp
+    ks_n, mf = (ko_n + 1) // 2, (cout + 31) // 32
+    img = pk.view(np.float16).astype(np.float32).reshape(ks_n, mf, 64, 8)
+    w = np.zeros((cout, nf, 9), np.float32)
+    seen = np.zeros((cout, nf, 9), bool)
+    for ks in range(ks_n):
+        for m in range(mf):
+            for lane in range(64):
+                i, half = lane & 31, lane >> 5
+                co, ko = 32 * m + i, 2 * ks + half
+                if co >= cout or ko >= ko_n:
+                    assert not img[ks, m, lane].any()
+                    continue
+                tap, octet = divmod(ko, spp)
+                w[co, octet * 8:octet * 8 + 8, tap] = img[ks, m, lane]
+                seen[co, octet * 8:octet * 8 + 8, tap] = True
+    assert seen.all()
+    return w.reshape(cout, nf, 3, 3)
+
+
+@pytest.mark.parametrize("key", ["2x", "4x", "1x"])
+def test_packed_weights_are_a_permutation_of_oihw(uva, oracle_models, key):
+    """The kernel's B operand supplies, for k-step ks and lane half h, K octet ko = 2ks+h = channels
+    8*(ko % (nf/8)).. of tap ko // (nf/8); the packed A image must put the matching weights there."""
+    net = load_net(uva, key)
+    om = oracle_models[key]
+    nf = net.num_features
+    for idx in (1, net.num_convs // 2, net.num_convs - 1):
+        w, _, _ = om.conv(idx)
+        got = _unpack_conv(net.debug_packed_weights(idx), nf, w.shape[0])
+        with np.errstate(over="ignore"):
+            want = w.astype(np.float16).astype(np.float32)
+        assert np.array_equal(got, want), (key, idx)
+    # head: K = [tap][4] (3 channels + zero), octet o = 2ks+h holds taps 2o, 2o+1
+    w0, _, _ = om.conv(0)
+    pk = net.debug_packed_weights(0).view(np.float16).astype(np.float32)
+    mf = (nf + 31) // 32
+    img = pk.reshape(3, mf, 64, 8)
+    rec = np.zeros((nf, 3, 9), np.float32)
+    for ks in range(3):
+        for m in range(mf):
+            for lane in range(64):
+                co, o = 32 * m + (lane & 31), 2 * ks + (lane >> 5)
+                for e in range(8):
+                    tap, ch = 2 * o + (e >> 2), e & 3
+                    v = img[ks, m, lane, e]
+                    if co < nf and tap < 9 and ch < 3:
+                        rec[co, ch, tap] = v
+                    else:
+                        assert v == 0
+    with np.errstate(over="ignore"):
+        assert np.array_equal(rec.reshape(nf, 3, 3, 3), w0.astype(np.float16).astype(np.float32))
+
+
+def test_mat_from_pixels_and_normalize_match_oracle(uva, oracle):
+    img = oracle.synthetic_frame(9, 13, kind="random")
+    m = uva.Mat.from_pixels(img, uva.Mat.PixelType.PIXEL_BGR, 13, 9)
+    m.substract_mean_normalize([], [1 / 255.0] * 3)
+    assert np.array_equal(np.array(m), oracle.from_pixels_normalize(img))
+    with pytest.raises(ValueError):
+        uva.Mat.from_pixels(img, uva.Mat.PixelType.PIXEL_BGR, 9, 13)
+
+
+def test_compute_fails_loudly_without_gpu(uva):
+    if uva.get_gpu_count() > 0:
+        pytest.skip("a GPU is present")
+    assert uva.get_default_gpu_index() == -1
+    net = load_net(uva, "1x")
+    from upscale_video_amd._lib import UvaError
+    with pytest.raises(UvaError, match="no HIP device|no CPU path"):
+        net.process_u8(np.zeros((8, 8, 3), np.uint8))
+    ex = net.create_extractor()
+    ex.input("input", uva.Mat(np.zeros((3, 8, 8), np.float32)))
+    with pytest.raises(UvaError):
+        ex.extract("output")
+
+
+def test_missing_library_is_an_error(monkeypatch, uva):
+    from upscale_video_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libuva.so")
+    with pytest.raises(_lib.UvaError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "upscale_video_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "uvoracle" not in text and "liboracle" not in text and "oracle/" not in text, f

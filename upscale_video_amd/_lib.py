@@ -1,0 +1,68 @@
+"""ctypes binding of libuva.so (C ABI: include/uva.h).  Fails loudly: there is no fallback path."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libuva.so")
+
+# every symbol include/uva.h declares
+SYMBOLS = [
+    "uva_get_gpu_count", "uva_get_default_gpu_index", "uva_get_gpu_info", "uva_destroy_gpu_instance",
+    "uva_net_create", "uva_net_set_device", "uva_net_load_param", "uva_net_load_model",
+    "uva_net_destroy", "uva_net_scale", "uva_net_num_features", "uva_net_num_convs",
+    "uva_net_extract_f32", "uva_net_process_u8", "uva_net_process_u8_device", "uva_net_synchronize",
+    "uva_net_debug_read_activation", "uva_net_set_profiling", "uva_net_kernel_stats",
+    "uva_net_debug_packed_weights", "uva_last_error", "uva_abi_version",
+]
+
+_lib = None
+
+
+class UvaError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads libuva.so; raises if it has not been built (python -m upscale_video_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UvaError(
+            "libuva.so is missing: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or python upscale_video_amd/build.py). "
+            "There is no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    c_p, c_i, c_sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+    L.uva_get_gpu_count.restype = c_i
+    L.uva_get_default_gpu_index.restype = c_i
+    L.uva_get_gpu_info.restype = c_i
+    L.uva_get_gpu_info.argtypes = [c_i, ctypes.POINTER(c_i), ctypes.c_char_p, c_sz]
+    L.uva_destroy_gpu_instance.restype = None
+    L.uva_net_create.restype = c_p
+    L.uva_net_destroy.argtypes = [c_p]
+    L.uva_net_destroy.restype = None
+    L.uva_net_set_device.argtypes = [c_p, c_i]
+    L.uva_net_load_param.argtypes = [c_p, ctypes.c_char_p]
+    L.uva_net_load_model.argtypes = [c_p, ctypes.c_char_p]
+    for n in ("uva_net_scale", "uva_net_num_features", "uva_net_num_convs", "uva_net_synchronize"):
+        getattr(L, n).argtypes = [c_p]
+    L.uva_net_extract_f32.argtypes = [c_p, c_p, c_i, c_i, c_p]
+    L.uva_net_process_u8.argtypes = [c_p, c_p, c_i, c_i, c_sz, c_p, c_sz, c_i, c_i]
+    L.uva_net_process_u8_device.argtypes = [c_p, c_p, c_i, c_i, c_sz, c_p, c_sz, c_i, c_i]
+    L.uva_net_debug_read_activation.argtypes = [c_p, c_i, c_p, c_i, c_i]
+    L.uva_net_set_profiling.argtypes = [c_p, c_i]
+    L.uva_net_kernel_stats.argtypes = [c_p, c_i, ctypes.POINTER(ctypes.c_longlong),
+                                       ctypes.POINTER(ctypes.c_double)]
+    L.uva_net_debug_packed_weights.argtypes = [c_p, c_i, c_p, c_sz, ctypes.POINTER(c_sz)]
+    L.uva_last_error.restype = ctypes.c_char_p
+    L.uva_abi_version.restype = c_i
+    for n in SYMBOLS:   # AttributeError here means the .so is stale: rebuild it
+        getattr(L, n)
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise UvaError(load().uva_last_error().decode(errors="replace"))

@@ -1,0 +1,644 @@
+// uva_api.hip -- C ABI (include/uva.h) and device runtime of libuva.so.
+//
+// Replaces the ncnn_vulkan surface used by the reference worker functions
+// (upscale/upscale_processing.py:54-73 init_worker, :258-299 apply_model, :395-477 process_tile,
+// :480-542 upscale_image; test_gpus.py:47-67 enumeration).  One uva_net = one ncnn.Net: it owns a
+// HIP stream, the packed weights, and a small cache of per-geometry workspaces (zero-bordered
+// fp16 NHWC ping-pong planes) sized for 288 GB of HBM: nothing is freed between frames.
+#include "../../include/uva.h"
+#include "uva_kernels.hip.h"
+#include "uva_model.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <list>
+#include <memory>
+#include <mutex>
+#include <set>
+#include <string>
+#include <vector>
+
+using namespace uva;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string& msg)
+{
+    g_err = msg;
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(std::string(#expr) + ": " + hipGetErrorString(e_));                    \
+    } while (0)
+
+struct Workspace {
+    int h = 0, w = 0, tile_size = 0, border = 0;
+    std::vector<PlaneDesc> planes;
+    PlaneDesc* d_planes = nullptr;
+    int ntiles = 0;
+    size_t act_pixels = 0;
+    _Float16* act[2] = {nullptr, nullptr};
+    void release()
+    {
+        if (d_planes) (void)hipFree(d_planes);
+        if (act[0]) (void)hipFree(act[0]);
+        if (act[1]) (void)hipFree(act[1]);
+        d_planes = nullptr;
+        act[0] = act[1] = nullptr;
+    }
+};
+
+struct DeviceLayer {
+    half8* wpk = nullptr;
+    float* bias = nullptr;
+    float* slope = nullptr;
+};
+
+struct LastCall {
+    bool valid = false;
+    Workspace* ws = nullptr;
+    bool f32 = false;
+    const void* src = nullptr;
+    size_t src_stride = 0;
+};
+
+std::mutex g_nets_mu;
+std::set<uva_net*> g_nets;
+
+}  // namespace
+
+struct uva_net {
+    int device = 0;
+    Graph g;
+    bool dev_ready = false;
+    int ncu = 256;
+    hipStream_t stream = nullptr;
+    std::vector<DeviceLayer> layers;
+    std::list<Workspace> wss;   // most recently used first
+    // staging for the host-pointer entry points
+    uint8_t *h_in = nullptr, *h_out = nullptr, *d_in = nullptr, *d_out = nullptr;
+    size_t h_in_cap = 0, h_out_cap = 0, d_in_cap = 0, d_out_cap = 0;
+    float *d_fin = nullptr, *d_fout = nullptr;
+    size_t d_fin_cap = 0, d_fout_cap = 0;
+    LastCall last;
+    // profiling
+    bool prof = false;
+    std::vector<hipEvent_t> ev_free;
+    struct EvSet { hipEvent_t e[4]; int ntrunk; };
+    std::vector<EvSet> ev_pending;
+    long long launches[3] = {0, 0, 0};
+    double total_ms[3] = {0, 0, 0};
+
+    void free_device()
+    {
+        if (!dev_ready) return;
+        (void)hipSetDevice(device);
+        if (stream) (void)hipStreamSynchronize(stream);
+        for (auto& l : layers) {
+            if (l.wpk) (void)hipFree(l.wpk);
+            if (l.bias) (void)hipFree(l.bias);
+            if (l.slope) (void)hipFree(l.slope);
+        }
+        layers.clear();
+        for (auto& w : wss) w.release();
+        wss.clear();
+        if (h_in) (void)hipHostFree(h_in);
+        if (h_out) (void)hipHostFree(h_out);
+        if (d_in) (void)hipFree(d_in);
+        if (d_out) (void)hipFree(d_out);
+        if (d_fin) (void)hipFree(d_fin);
+        if (d_fout) (void)hipFree(d_fout);
+        h_in = h_out = d_in = d_out = nullptr;
+        d_fin = d_fout = nullptr;
+        h_in_cap = h_out_cap = d_in_cap = d_out_cap = d_fin_cap = d_fout_cap = 0;
+        for (auto& s : ev_pending)
+            for (auto e : s.e) (void)hipEventDestroy(e);
+        ev_pending.clear();
+        for (auto e : ev_free) (void)hipEventDestroy(e);
+        ev_free.clear();
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr;
+        dev_ready = false;
+        last = LastCall();
+    }
+};
+
+namespace {
+
+template <typename T>
+int upload(T** dst, const void* src, size_t bytes, hipStream_t st)
+{
+    HIP_TRY(hipMalloc((void**)dst, bytes));
+    HIP_TRY(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, st));
+    return 0;
+}
+
+template <int NF>
+constexpr size_t conv_lds(int r) { return 2 * Geo<NF>::BUFB + PARAM_LDS + 4 * (2 * r * TW * r * 3); }
+
+template <int NF, int MODE, int R>
+int launch_conv_t(uva_net* n, const ConvArgs& a)
+{
+    static bool attr_done[16] = {false};   // per device ordinal
+    const size_t lds = conv_lds<NF>(MODE == 0 ? 1 : R);
+    auto kfn = conv3x3_kernel<NF, MODE, R>;
+    if (n->device < 16 && !attr_done[n->device]) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done[n->device] = true;
+    } else if (n->device >= 16) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    const int grid = std::max(8, (n->ncu / 8) * 8);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, n->stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int NF>
+int launch_conv_nf(uva_net* n, int mode, int r, const ConvArgs& a)
+{
+    if (mode == 0) return launch_conv_t<NF, 0, 1>(n, a);
+    if (mode == 1) {
+        if (r == 1) return launch_conv_t<NF, 1, 1>(n, a);
+        if (r == 2) return launch_conv_t<NF, 1, 2>(n, a);
+        if (r == 4) return launch_conv_t<NF, 1, 4>(n, a);
+    } else {
+        if (r == 1) return launch_conv_t<NF, 2, 1>(n, a);
+        if (r == 2) return launch_conv_t<NF, 2, 2>(n, a);
+        if (r == 4) return launch_conv_t<NF, 2, 4>(n, a);
+    }
+    return fail("no kernel for this scale");
+}
+
+int launch_conv(uva_net* n, int mode, const ConvArgs& a)
+{
+    if (n->g.nf == 64) return launch_conv_nf<64>(n, mode, n->g.scale, a);
+    if (n->g.nf == 24) return launch_conv_nf<24>(n, mode, n->g.scale, a);
+    return fail("no kernel for this trunk width");
+}
+
+int launch_head(uva_net* n, bool f32, const HeadArgs& a)
+{
+    const dim3 grid(a.ntiles), block(256);
+    if (n->g.nf == 64) {
+        if (f32) hipLaunchKernelGGL((head_kernel<64, 1>), grid, block, 0, n->stream, a);
+        else hipLaunchKernelGGL((head_kernel<64, 0>), grid, block, 0, n->stream, a);
+    } else {
+        if (f32) hipLaunchKernelGGL((head_kernel<24, 1>), grid, block, 0, n->stream, a);
+        else hipLaunchKernelGGL((head_kernel<24, 0>), grid, block, 0, n->stream, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ensure_device(uva_net* n)
+{
+    if (!n->g.param_loaded || !n->g.model_loaded) return fail("net has no model: call load_param and load_model first");
+    if (n->dev_ready) {
+        HIP_TRY(hipSetDevice(n->device));
+        return 0;
+    }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail("no HIP device available: libuva has no CPU path");
+    if (n->device < 0 || n->device >= count)
+        return fail("HIP device " + std::to_string(n->device) + " does not exist (" + std::to_string(count) + " visible)");
+    HIP_TRY(hipSetDevice(n->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, n->device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(std::string("libuva is built for gfx950 (MI355X) only; device is ") + prop.gcnArchName);
+    n->ncu = prop.multiProcessorCount;
+    HIP_TRY(hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking));
+    n->dev_ready = true;
+    // weights: head, trunk..., tail
+    const Graph& g = n->g;
+    n->layers.resize(g.convs.size());
+    for (size_t i = 0; i < g.convs.size(); ++i) {
+        std::vector<uint16_t> pk;
+        int mf = 0;
+        if (i == 0) pack_head(g.convs[i], pk, &mf);
+        else pack_conv3x3(g.convs[i], g.nf, pk, nullptr, &mf);
+        DeviceLayer& dl = n->layers[i];
+        if (upload(&dl.wpk, pk.data(), pk.size() * 2, n->stream)) return 1;
+        std::vector<float> b((size_t)mf * 32, 0.f), s((size_t)mf * 32, 0.f);
+        std::copy(g.convs[i].bias.begin(), g.convs[i].bias.end(), b.begin());
+        if (upload(&dl.bias, b.data(), b.size() * 4, n->stream)) return 1;
+        if (i + 1 < g.convs.size()) {
+            std::copy(g.slopes[i].begin(), g.slopes[i].end(), s.begin());
+            if (upload(&dl.slope, s.data(), s.size() * 4, n->stream)) return 1;
+        }
+        HIP_TRY(hipStreamSynchronize(n->stream));   // pk / b / s go out of scope
+    }
+    return 0;
+}
+
+// Plane list of one frame: the reference's tile grid (upscale_processing.py:398-434, :499-516)
+// or a single whole-frame plane (apply_model, :263-288).
+int build_planes(int h, int w, int tile_size, int border, std::vector<PlaneDesc>& out)
+{
+    out.clear();
+    auto add = [&](int sy0, int sx0, int ph, int pw, int cy0, int cy1, int cx0, int cx1) {
+        PlaneDesc p;
+        std::memset(&p, 0, sizeof p);
+        p.h = ph; p.w = pw;
+        p.src_y0 = sy0; p.src_x0 = sx0;
+        p.core_y0 = cy0; p.core_y1 = cy1; p.core_x0 = cx0; p.core_x1 = cx1;
+        out.push_back(p);
+    };
+    if (tile_size <= 0) {
+        add(0, 0, h, w, 0, h, 0, w);
+    } else {
+        const int tiles_x = (w + tile_size - 1) / tile_size, tiles_y = (h + tile_size - 1) / tile_size;
+        if ((long long)tiles_x * tiles_y > MAX_PLANES) return fail("frame needs more than 64 tiles");
+        for (int ty = 0; ty < tiles_y; ++ty)
+            for (int tx = 0; tx < tiles_x; ++tx) {
+                const int y0 = ty * tile_size, x0 = tx * tile_size;
+                const int y1 = std::min(y0 + tile_size, h), x1 = std::min(x0 + tile_size, w);
+                const int by0 = y0 >= border ? border : 0, by1 = y1 <= h - border ? border : 0;
+                const int bx0 = x0 >= border ? border : 0, bx1 = x1 <= w - border ? border : 0;
+                add(y0 - by0, x0 - bx0, (y1 + by1) - (y0 - by0), (x1 + bx1) - (x0 - bx0), by0, by0 + (y1 - y0),
+                    bx0, bx0 + (x1 - x0));
+            }
+    }
+    return 0;
+}
+
+int get_workspace(uva_net* n, int h, int w, int tile_size, int border, Workspace** out)
+{
+    if (tile_size <= 0) { tile_size = 0; border = 0; }
+    for (auto it = n->wss.begin(); it != n->wss.end(); ++it)
+        if (it->h == h && it->w == w && it->tile_size == tile_size && it->border == border) {
+            n->wss.splice(n->wss.begin(), n->wss, it);
+            *out = &n->wss.front();
+            return 0;
+        }
+    Workspace ws;
+    ws.h = h; ws.w = w; ws.tile_size = tile_size; ws.border = border;
+    if (build_planes(h, w, tile_size, border, ws.planes)) return 1;
+    size_t pix = 0;
+    int tiles = 0;
+    for (auto& p : ws.planes) {
+        p.nty = (p.h + TH - 1) / TH;
+        p.ntx = (p.w + TW - 1) / TW;
+        p.pitch = p.ntx * TW + 2;
+        p.tile_begin = tiles;
+        p.act_off = (long long)pix;
+        tiles += p.nty * p.ntx;
+        pix += (size_t)(p.nty * TH + 2) * p.pitch;
+    }
+    ws.ntiles = tiles;
+    ws.act_pixels = pix;
+    if (n->wss.size() >= 6) {   // LRU: keep a handful of geometries resident
+        HIP_TRY(hipStreamSynchronize(n->stream));
+        if (n->last.ws == &n->wss.back()) n->last = LastCall();
+        n->wss.back().release();
+        n->wss.pop_back();
+    }
+    const size_t bytes = pix * (size_t)n->g.nf * 2;
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipMalloc((void**)&ws.act[i], bytes));
+        HIP_TRY(hipMemsetAsync(ws.act[i], 0, bytes, n->stream));   // the zero border lives here forever
+    }
+    HIP_TRY(hipMalloc((void**)&ws.d_planes, ws.planes.size() * sizeof(PlaneDesc)));
+    HIP_TRY(hipMemcpyAsync(ws.d_planes, ws.planes.data(), ws.planes.size() * sizeof(PlaneDesc),
+                           hipMemcpyHostToDevice, n->stream));
+    HIP_TRY(hipStreamSynchronize(n->stream));
+    n->wss.push_front(ws);
+    *out = &n->wss.front();
+    return 0;
+}
+
+hipEvent_t take_event(uva_net* n)
+{
+    if (!n->ev_free.empty()) {
+        hipEvent_t e = n->ev_free.back();
+        n->ev_free.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void resolve_events(uva_net* n)
+{
+    for (auto& s : n->ev_pending) {
+        float ms[3] = {0, 0, 0};
+        bool ok = true;
+        for (int k = 0; k < 3; ++k) ok &= hipEventElapsedTime(&ms[k], s.e[k], s.e[k + 1]) == hipSuccess;
+        if (ok) {
+            n->launches[0] += 1; n->total_ms[0] += ms[0];
+            n->launches[1] += s.ntrunk; n->total_ms[1] += ms[1];
+            n->launches[2] += 1; n->total_ms[2] += ms[2];
+        }
+        for (auto e : s.e) n->ev_free.push_back(e);
+    }
+    n->ev_pending.clear();
+}
+
+// The whole graph for one frame.  stop_after >= 0: run only convolutions 0..stop_after (debug).
+int run_graph(uva_net* n, Workspace* ws, bool f32, const void* src, size_t src_stride, void* dst,
+              size_t dst_stride, int stop_after)
+{
+    const Graph& g = n->g;
+    const int nconv = (int)g.convs.size();
+    const bool prof = n->prof && stop_after < 0;
+    uva_net::EvSet ev;
+    ev.ntrunk = nconv - 2;
+    if (prof) {
+        for (auto& e : ev.e) e = take_event(n);
+        HIP_TRY(hipEventRecord(ev.e[0], n->stream));
+    }
+    HeadArgs ha;
+    std::memset(&ha, 0, sizeof ha);
+    ha.planes = ws->d_planes;
+    ha.nplanes = (int)ws->planes.size();
+    ha.ntiles = ws->ntiles;
+    ha.src_u8 = f32 ? nullptr : (const uint8_t*)src;
+    ha.src_stride = src_stride;
+    ha.src_f32 = f32 ? (const float*)src : nullptr;
+    ha.out_act = ws->act[0];
+    ha.wpk = n->layers[0].wpk;
+    ha.bias = n->layers[0].bias;
+    ha.slope = n->layers[0].slope;
+    ha.in_scale = f32 ? 1.0f : (float)(1 / 255.0);
+    if (launch_head(n, f32, ha)) return 1;
+    if (prof) HIP_TRY(hipEventRecord(ev.e[1], n->stream));
+
+    ConvArgs ca;
+    std::memset(&ca, 0, sizeof ca);
+    ca.planes = ws->d_planes;
+    ca.nplanes = (int)ws->planes.size();
+    ca.ntiles = ws->ntiles;
+    ca.tiles_per_xcd = (ws->ntiles + 7) / 8;
+    for (int i = 1; i < nconv - 1; ++i) {
+        if (stop_after >= 0 && i > stop_after) return 0;
+        ca.in_act = ws->act[(i - 1) & 1];
+        ca.out_act = ws->act[i & 1];
+        ca.wpk = n->layers[i].wpk;
+        ca.bias = n->layers[i].bias;
+        ca.slope = n->layers[i].slope;
+        if (launch_conv(n, 0, ca)) return 1;
+    }
+    if (stop_after >= 0) return 0;
+    if (prof) HIP_TRY(hipEventRecord(ev.e[2], n->stream));
+    ca.in_act = ws->act[(nconv - 2) & 1];
+    ca.out_act = nullptr;
+    ca.wpk = n->layers[nconv - 1].wpk;
+    ca.bias = n->layers[nconv - 1].bias;
+    ca.slope = nullptr;
+    if (f32) {
+        ca.src_f32 = (const float*)src;
+        ca.dst_f32 = (float*)dst;
+    } else {
+        ca.src_u8 = (const uint8_t*)src;
+        ca.src_stride = src_stride;
+        ca.dst_u8 = (uint8_t*)dst;
+        ca.dst_stride = dst_stride;
+    }
+    if (launch_conv(n, f32 ? 2 : 1, ca)) return 1;
+    if (prof) {
+        HIP_TRY(hipEventRecord(ev.e[3], n->stream));
+        n->ev_pending.push_back(ev);
+    }
+    return 0;
+}
+
+template <typename T>
+int grow_dev(T** p, size_t* cap, size_t bytes)
+{
+    if (*cap >= bytes) return 0;
+    if (*p) HIP_TRY(hipFree(*p));
+    *p = nullptr; *cap = 0;
+    HIP_TRY(hipMalloc((void**)p, bytes));
+    *cap = bytes;
+    return 0;
+}
+
+int grow_host(uint8_t** p, size_t* cap, size_t bytes)
+{
+    if (*cap >= bytes) return 0;
+    if (*p) HIP_TRY(hipHostFree(*p));
+    *p = nullptr; *cap = 0;
+    HIP_TRY(hipHostMalloc((void**)p, bytes, hipHostMallocDefault));
+    *cap = bytes;
+    return 0;
+}
+
+int check_dims(const uva_net* n, int h, int w)
+{
+    if (!n) return fail("null net");
+    if (h <= 0 || w <= 0 || (long long)h * w > (1ll << 28)) return fail("bad image size");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int uva_abi_version(void) { return UVA_ABI_VERSION; }
+const char* uva_last_error(void) { return g_err.c_str(); }
+
+int uva_get_gpu_count(void)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count;
+}
+
+int uva_get_default_gpu_index(void) { return uva_get_gpu_count() > 0 ? 0 : -1; }
+
+int uva_get_gpu_info(int index, int* type, char* name, size_t name_len)
+{
+    const int count = uva_get_gpu_count();
+    if (index < 0 || index >= count) return fail("no such HIP device");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, index));
+    if (type) *type = prop.integrated ? 1 : 0;
+    if (name && name_len) std::snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    return 0;
+}
+
+void uva_destroy_gpu_instance(void)
+{
+    std::lock_guard<std::mutex> lk(g_nets_mu);
+    for (uva_net* n : g_nets) n->free_device();
+}
+
+uva_net* uva_net_create(void)
+{
+    uva_net* n = new uva_net();
+    std::lock_guard<std::mutex> lk(g_nets_mu);
+    g_nets.insert(n);
+    return n;
+}
+
+void uva_net_destroy(uva_net* n)
+{
+    if (!n) return;
+    {
+        std::lock_guard<std::mutex> lk(g_nets_mu);
+        g_nets.erase(n);
+    }
+    n->free_device();
+    delete n;
+}
+
+int uva_net_set_device(uva_net* n, int device)
+{
+    if (!n) return fail("null net");
+    if (device < 0) return fail("negative device index: libuva has no CPU path");
+    if (n->dev_ready && device != n->device) n->free_device();
+    n->device = device;
+    return 0;
+}
+
+int uva_net_load_param(uva_net* n, const char* path)
+{
+    if (!n || !path) return fail("null argument");
+    n->free_device();
+    std::string err;
+    if (!parse_param(path, n->g, err)) return fail(err);
+    return 0;
+}
+
+int uva_net_load_model(uva_net* n, const char* path)
+{
+    if (!n || !path) return fail("null argument");
+    n->free_device();
+    std::string err;
+    if (!load_bin(path, n->g, err)) return fail(err);
+    return 0;
+}
+
+int uva_net_scale(const uva_net* n) { return n && n->g.param_loaded ? n->g.scale : 0; }
+int uva_net_num_features(const uva_net* n) { return n && n->g.param_loaded ? n->g.nf : 0; }
+int uva_net_num_convs(const uva_net* n) { return n && n->g.param_loaded ? (int)n->g.convs.size() : 0; }
+
+int uva_net_synchronize(uva_net* n)
+{
+    if (!n) return fail("null net");
+    if (!n->dev_ready) return 0;
+    HIP_TRY(hipSetDevice(n->device));
+    HIP_TRY(hipStreamSynchronize(n->stream));
+    resolve_events(n);
+    return 0;
+}
+
+int uva_net_process_u8_device(uva_net* n, const void* d_in, int h, int w, size_t in_stride, void* d_out,
+                              size_t out_stride, int tile_size, int border)
+{
+    if (check_dims(n, h, w)) return 1;
+    if (!d_in || !d_out) return fail("null frame pointer");
+    if (ensure_device(n)) return 1;
+    if (in_stride < (size_t)w * 3 || out_stride < (size_t)w * n->g.scale * 3) return fail("row stride too small");
+    Workspace* ws = nullptr;
+    if (get_workspace(n, h, w, tile_size, border, &ws)) return 1;
+    n->last.valid = true; n->last.ws = ws; n->last.f32 = false; n->last.src = d_in; n->last.src_stride = in_stride;
+    return run_graph(n, ws, false, d_in, in_stride, d_out, out_stride, -1);
+}
+
+int uva_net_process_u8(uva_net* n, const uint8_t* in, int h, int w, size_t in_stride, uint8_t* out,
+                       size_t out_stride, int tile_size, int border)
+{
+    if (check_dims(n, h, w)) return 1;
+    if (!in || !out) return fail("null frame pointer");
+    if (ensure_device(n)) return 1;
+    const int s = n->g.scale;
+    const size_t in_row = (size_t)w * 3, out_row = (size_t)w * s * 3;
+    if (in_stride < in_row || out_stride < out_row) return fail("row stride too small");
+    const size_t in_bytes = in_row * h, out_bytes = out_row * (size_t)h * s;
+    if (grow_host(&n->h_in, &n->h_in_cap, in_bytes) || grow_host(&n->h_out, &n->h_out_cap, out_bytes) ||
+        grow_dev(&n->d_in, &n->d_in_cap, in_bytes) || grow_dev(&n->d_out, &n->d_out_cap, out_bytes))
+        return 1;
+    for (int y = 0; y < h; ++y) std::memcpy(n->h_in + y * in_row, in + y * in_stride, in_row);
+    HIP_TRY(hipMemcpyAsync(n->d_in, n->h_in, in_bytes, hipMemcpyHostToDevice, n->stream));
+    if (uva_net_process_u8_device(n, n->d_in, h, w, in_row, n->d_out, out_row, tile_size, border)) return 1;
+    HIP_TRY(hipMemcpyAsync(n->h_out, n->d_out, out_bytes, hipMemcpyDeviceToHost, n->stream));
+    if (uva_net_synchronize(n)) return 1;
+    for (int y = 0; y < h * s; ++y) std::memcpy(out + y * out_stride, n->h_out + y * out_row, out_row);
+    return 0;
+}
+
+int uva_net_extract_f32(uva_net* n, const float* in_chw, int h, int w, float* out_chw)
+{
+    if (check_dims(n, h, w)) return 1;
+    if (!in_chw || !out_chw) return fail("null Mat pointer");
+    if (ensure_device(n)) return 1;
+    const int s = n->g.scale;
+    const size_t in_bytes = (size_t)3 * h * w * 4, out_bytes = (size_t)3 * h * s * w * s * 4;
+    if (grow_dev(&n->d_fin, &n->d_fin_cap, in_bytes) || grow_dev(&n->d_fout, &n->d_fout_cap, out_bytes)) return 1;
+    Workspace* ws = nullptr;
+    if (get_workspace(n, h, w, 0, 0, &ws)) return 1;
+    HIP_TRY(hipMemcpyAsync(n->d_fin, in_chw, in_bytes, hipMemcpyHostToDevice, n->stream));
+    n->last.valid = true; n->last.ws = ws; n->last.f32 = true; n->last.src = n->d_fin; n->last.src_stride = 0;
+    if (run_graph(n, ws, true, n->d_fin, 0, n->d_fout, 0, -1)) return 1;
+    HIP_TRY(hipMemcpyAsync(out_chw, n->d_fout, out_bytes, hipMemcpyDeviceToHost, n->stream));
+    return uva_net_synchronize(n);
+}
+
+int uva_net_debug_read_activation(uva_net* n, int conv_idx, float* out_chw, int h, int w)
+{
+    if (!n || !out_chw) return fail("null argument");
+    if (!n->dev_ready || !n->last.valid) return fail("no previous call to replay");
+    Workspace* ws = n->last.ws;
+    const int nconv = (int)n->g.convs.size();
+    if (ws->planes.size() != 1 || ws->h != h || ws->w != w) return fail("debug read needs an untiled call of the same size");
+    if (conv_idx < 0 || conv_idx > nconv - 2) return fail("conv_idx out of range");
+    HIP_TRY(hipSetDevice(n->device));
+    if (run_graph(n, ws, n->last.f32, n->last.src, n->last.src_stride, nullptr, 0, conv_idx)) return 1;
+    const PlaneDesc& p = ws->planes[0];
+    const int nf = n->g.nf;
+    const size_t rows = (size_t)p.nty * TH + 2;
+    std::vector<uint16_t> hbuf(rows * p.pitch * nf);
+    HIP_TRY(hipMemcpyAsync(hbuf.data(), ws->act[conv_idx & 1], hbuf.size() * 2, hipMemcpyDeviceToHost, n->stream));
+    HIP_TRY(hipStreamSynchronize(n->stream));
+    for (int c = 0; c < nf; ++c)
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x)
+                out_chw[((size_t)c * h + y) * w + x] =
+                    f16_bits_to_f32(hbuf[((size_t)(y + 1) * p.pitch + (x + 1)) * nf + c]);
+    return 0;
+}
+
+int uva_net_set_profiling(uva_net* n, int enable)
+{
+    if (!n) return fail("null net");
+    if (uva_net_synchronize(n)) return 1;
+    n->prof = enable != 0;
+    for (int k = 0; k < 3; ++k) { n->launches[k] = 0; n->total_ms[k] = 0; }
+    return 0;
+}
+
+int uva_net_kernel_stats(uva_net* n, int kind, long long* launches, double* total_ms)
+{
+    if (!n || kind < 0 || kind > 2) return fail("bad argument");
+    if (launches) *launches = n->launches[kind];
+    if (total_ms) *total_ms = n->total_ms[kind];
+    return 0;
+}
+
+// test hook: the packed MFMA weight image of convolution #conv_idx (host side, no device needed)
+int uva_net_debug_packed_weights(uva_net* n, int conv_idx, uint16_t* out, size_t out_halfs, size_t* needed)
+{
+    if (!n || !n->g.model_loaded) return fail("no model");
+    if (conv_idx < 0 || conv_idx >= (int)n->g.convs.size()) return fail("conv_idx out of range");
+    std::vector<uint16_t> pk;
+    if (conv_idx == 0) pack_head(n->g.convs[0], pk, nullptr);
+    else pack_conv3x3(n->g.convs[conv_idx], n->g.nf, pk, nullptr, nullptr);
+    if (needed) *needed = pk.size();
+    if (out && out_halfs >= pk.size()) std::memcpy(out, pk.data(), pk.size() * 2);
+    return 0;
+}
+
+}  // extern "C"

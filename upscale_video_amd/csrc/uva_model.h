@@ -1,0 +1,46 @@
+// uva_model.h -- host-side ncnn .param/.bin loader and MFMA weight packer (no HIP here).
+// Replaces ncnn::Net::load_param / load_model as the reference uses them
+// (upscale/upscale_processing.py:70-71).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace uva {
+
+struct ConvWeights {
+    std::string name;
+    int cin = 0, cout = 0;
+    int weight_data_size = 0;
+    uint32_t tag = 0;             // .bin flag word: 0x01306B47 fp16, 0 fp32
+    std::vector<float> w;         // OIHW (ncnn order), fp32 (fp16 expanded exactly)
+    std::vector<float> bias;      // [cout]
+};
+
+struct Graph {
+    bool param_loaded = false, model_loaded = false;
+    int scale = 0;                // PixelShuffle factor r (1, 2, 4)
+    int nf = 0;                   // trunk width (64 / 24)
+    std::vector<ConvWeights> convs;               // head, trunk..., tail
+    std::vector<std::string> prelu_names;
+    std::vector<std::vector<float>> slopes;       // one per PReLU (convs.size() - 1)
+    size_t bin_size = 0, bin_consumed = 0;
+};
+
+// Parses the ncnn text graph and accepts only the SRVGGNetCompact pattern.
+bool parse_param(const std::string& path, Graph& g, std::string& err);
+// Reads the weight stream in graph order; every byte of the file must be consumed.
+bool load_bin(const std::string& path, Graph& g, std::string& err);
+
+uint16_t f32_to_f16_bits(float x);   // round-to-nearest-even
+float f16_bits_to_f32(uint16_t h);
+
+// MFMA A-operand image of a 3x3 convolution with cin = nf: [KS][MF][64 lanes][8] fp16, where
+// lane = (half << 5) | i supplies output channel 32*m + i and K octet ko = 2*ks + half
+// (tap = ko / (nf/8), input channels 8*(ko % (nf/8)) .. +7).  Out-of-range -> 0.
+void pack_conv3x3(const ConvWeights& c, int nf, std::vector<uint16_t>& out, int* ks_out, int* mf_out);
+// Head (cin = 3): K = [tap][4] (3 channels + zero), octet o = 2*ks + half holds taps 2o, 2o+1;
+// image [3][MF][64][8].
+void pack_head(const ConvWeights& c, std::vector<uint16_t>& out, int* mf_out);
+
+}  // namespace uva

@@ -1,0 +1,222 @@
+"""Drop-in for the slice of `from ncnn_vulkan import ncnn` that davlee1972/upscale_video uses,
+backed by the MI355X HIP engine (libuva.so, include/uva.h).
+
+The reference touches exactly these names (upscale/upscale_processing.py:65-73, :265-281,
+:292, :437-453, :458; test_gpus.py:47-67):
+
+    ncnn.Net(); net.opt.use_vulkan_compute; net.set_vulkan_device(i)
+    net.load_param(path); net.load_model(path)
+    ncnn.Mat.from_pixels(arr, ncnn.Mat.PixelType.PIXEL_BGR, w, h)
+    mat.substract_mean_normalize(mean_vals, norm_vals)
+    ex = net.create_extractor(); ex.input(name, mat); ret, mat_out = ex.extract(name)
+    np.array(mat_out)
+    ncnn.destroy_gpu_instance(); ncnn.get_gpu_count(); ncnn.get_default_gpu_index()
+    ncnn.get_gpu_info(i).type() / .device_name()
+
+Same names, argument meaning and error behaviour (load_*/extract return 0 on success).  Mat is a
+host-side f32 planar container like ncnn::Mat; all network arithmetic runs in HIP kernels.  There
+is no CPU path: without an MI355X every extract raises.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+def get_gpu_count():
+    """test_gpus.py:47"""
+    return _lib.load().uva_get_gpu_count()
+
+
+def get_default_gpu_index():
+    """test_gpus.py:53"""
+    return _lib.load().uva_get_default_gpu_index()
+
+
+class GpuInfo:
+    def __init__(self, type_, name):
+        self._type, self._name = type_, name
+
+    def type(self):
+        return self._type
+
+    def device_name(self):
+        return self._name
+
+
+def get_gpu_info(i):
+    """test_gpus.py:59-66"""
+    t = ctypes.c_int()
+    name = ctypes.create_string_buffer(256)
+    _lib.check(_lib.load().uva_get_gpu_info(i, t, name, 256))
+    return GpuInfo(t.value, name.value.decode())
+
+
+def destroy_gpu_instance():
+    """upscale_processing.py:292, :458"""
+    _lib.load().uva_destroy_gpu_instance()
+
+
+class Mat:
+    """Host f32 planar [c][h][w] image, the subset of ncnn::Mat the reference uses."""
+
+    class PixelType:
+        PIXEL_RGB = 1
+        PIXEL_BGR = 2
+
+    def __init__(self, array):
+        self._a = np.ascontiguousarray(array, dtype=np.float32)
+        self.c, self.h, self.w = self._a.shape
+
+    @staticmethod
+    def from_pixels(array, pixel_type, w, h):
+        """ncnn mat_pixel.cpp from_pixels: u8 HWC -> f32 planar, byte k of a pixel -> plane k
+        (PIXEL_BGR keeps BGR order: no swap).  upscale_processing.py:265-270, :437-442"""
+        if pixel_type not in (Mat.PixelType.PIXEL_BGR, Mat.PixelType.PIXEL_RGB):
+            raise ValueError("unsupported pixel type")
+        a = np.asarray(array)
+        if a.dtype != np.uint8 or a.ndim != 3 or a.shape[0] != h or a.shape[1] != w or a.shape[2] != 3:
+            raise ValueError("from_pixels expects a u8 [h][w][3] array")
+        return Mat(a.transpose(2, 0, 1).astype(np.float32))
+
+    def substract_mean_normalize(self, mean_vals, norm_vals):
+        """ncnn mat.cpp: per channel (x - mean) * norm in fp32.  upscale_processing.py:271-273"""
+        for c in range(self.c):
+            if mean_vals:
+                self._a[c] -= np.float32(mean_vals[c])
+            if norm_vals:
+                self._a[c] *= np.float32(norm_vals[c])
+
+    def __array__(self, dtype=None, copy=None):
+        return self._a if dtype is None else self._a.astype(dtype)
+
+    def numpy(self):
+        return self._a
+
+
+class _Option:
+    def __init__(self):
+        self.use_vulkan_compute = False  # accepted for source compatibility; HIP is always used
+
+
+class Extractor:
+    def __init__(self, net):
+        self._net = net
+        self._in = None
+
+    def input(self, name, mat):
+        if name != "input":
+            return -1
+        self._in = mat
+        return 0
+
+    def extract(self, name):
+        """-> (ret, Mat).  upscale_processing.py:280, :452"""
+        if name != "output" or self._in is None:
+            return -1, None
+        out = self._net._extract(np.asarray(self._in))
+        return 0, Mat(out)
+
+
+class Net:
+    """ncnn.Net stand-in bound to one HIP device (upscale_processing.py:65-71)."""
+
+    def __init__(self):
+        self._L = _lib.load()
+        self._h = self._L.uva_net_create()
+        self.opt = _Option()
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._L.uva_net_destroy(h)
+
+    def set_vulkan_device(self, device_index):
+        _lib.check(self._L.uva_net_set_device(self._h, int(device_index)))
+
+    def load_param(self, path):
+        rc = self._L.uva_net_load_param(self._h, str(path).encode())
+        if rc:
+            self.last_error = self._L.uva_last_error().decode()
+        return rc
+
+    def load_model(self, path):
+        rc = self._L.uva_net_load_model(self._h, str(path).encode())
+        if rc:
+            self.last_error = self._L.uva_last_error().decode()
+        return rc
+
+    def create_extractor(self):
+        return Extractor(self)
+
+    # --- facts -------------------------------------------------------------------------------
+    @property
+    def scale(self):
+        return self._L.uva_net_scale(self._h)
+
+    @property
+    def num_features(self):
+        return self._L.uva_net_num_features(self._h)
+
+    @property
+    def num_convs(self):
+        return self._L.uva_net_num_convs(self._h)
+
+    # --- compute -----------------------------------------------------------------------------
+    def _extract(self, x_chw):
+        x = np.ascontiguousarray(x_chw, dtype=np.float32)
+        if x.ndim != 3 or x.shape[0] != 3:
+            raise ValueError("input Mat must be [3][h][w]")
+        s = self.scale
+        if s <= 0:
+            raise _lib.UvaError("net has no graph: load_param/load_model failed or were not called")
+        _, h, w = x.shape
+        out = np.empty((3, h * s, w * s), np.float32)
+        _lib.check(self._L.uva_net_extract_f32(self._h, x.ctypes.data, h, w, out.ctypes.data))
+        return out
+
+    def process_u8(self, img_bgr, tile_size=0, border=0):
+        """Fused device path for a whole frame: u8 HWC BGR -> u8 HWC BGR (include/uva.h
+        uva_net_process_u8).  tile_size<=0: apply_model semantics; 960/10: upscale_image's."""
+        img = np.ascontiguousarray(img_bgr, dtype=np.uint8)
+        if img.ndim != 3 or img.shape[2] != 3:
+            raise ValueError("frame must be u8 [h][w][3]")
+        s = self.scale
+        if s <= 0:
+            raise _lib.UvaError("net has no graph: load_param/load_model failed or were not called")
+        h, w, _ = img.shape
+        out = np.empty((h * s, w * s, 3), np.uint8)
+        _lib.check(self._L.uva_net_process_u8(self._h, img.ctypes.data, h, w, w * 3, out.ctypes.data,
+                                              w * s * 3, int(tile_size), int(border)))
+        return out
+
+    def process_u8_device(self, d_in, h, w, d_out, tile_size=0, border=0, in_stride=None, out_stride=None):
+        """Asynchronous: raw device pointers (ints) of dense u8 HWC frames in this GPU's HBM."""
+        s = self.scale
+        _lib.check(self._L.uva_net_process_u8_device(
+            self._h, ctypes.c_void_p(d_in), h, w, in_stride or w * 3, ctypes.c_void_p(d_out),
+            out_stride or w * s * 3, int(tile_size), int(border)))
+
+    def synchronize(self):
+        _lib.check(self._L.uva_net_synchronize(self._h))
+
+    def set_profiling(self, on):
+        _lib.check(self._L.uva_net_set_profiling(self._h, 1 if on else 0))
+
+    def kernel_stats(self, kind):
+        n, ms = ctypes.c_longlong(), ctypes.c_double()
+        _lib.check(self._L.uva_net_kernel_stats(self._h, kind, n, ms))
+        return n.value, ms.value
+
+    def debug_read_activation(self, conv_idx, h, w):
+        out = np.empty((self.num_features, h, w), np.float32)
+        _lib.check(self._L.uva_net_debug_read_activation(self._h, conv_idx, out.ctypes.data, h, w))
+        return out
+
+    def debug_packed_weights(self, conv_idx):
+        need = ctypes.c_size_t()
+        _lib.check(self._L.uva_net_debug_packed_weights(self._h, conv_idx, None, 0, need))
+        buf = np.empty(need.value, np.uint16)
+        _lib.check(self._L.uva_net_debug_packed_weights(self._h, conv_idx, buf.ctypes.data, need.value, need))
+        return buf
