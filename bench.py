@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the per-frame super-resolution hot path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one synthetic u8 BGR frame that is already resident in
+HBM (upscale_image arithmetic: head/trunk/tail kernels over all reference tiles, u8 out in HBM).
+N > 1: one process per GPU, frames sharded across ranks as independent units, no data-path
+collective (RCCL is used only for the timing barrier / max-reduce); scaling = weak.
+
+One JSON line on rank 0 with the driver's keys plus
+  roofline     : dominant kernel (trunk conv3x3 64->64) vs the dense fp16 MFMA peak, from HIP
+                 events recorded on the engine's own stream inside the timed region
+  cpu_baseline : the CPU oracle ("port": ncnn is not installable here) on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16
+
+WORKLOADS = {
+    # name: (model key, model file stem, height, width)  -- BASELINE.json configs[1..4]
+    "2x_compact_1080p": ("2x", "2x_Compact_Pretrain", 1080, 1920),
+    "4x_compact_1080p": ("4x", "4x_Compact_Pretrain", 1080, 1920),
+    "1x_hurrdeblur_1080p": ("1x", "1x_HurrDeblur_SubCompact_nf24-nc8_244k_net_g", 1080, 1920),
+    "2x_compact_2160p": ("2x", "2x_Compact_Pretrain", 2160, 3840),
+}
+
+
+def conv_flops_per_px(nf, nconv, scale):
+    """2 * sum_conv(9*Cin*Cout) per input pixel."""
+    return 2 * 9 * (3 * nf + (nconv - 2) * nf * nf + nf * 3 * scale * scale)
+
+
+def shard_frames(n_frames, rank, world):
+    """Frames are independent units: rank r takes frames r, r+world, ... (no exchange step)."""
+    return list(range(rank, n_frames, world))
+
+
+def timed_region(run_steps, sync, barrier, max_over_ranks):
+    """barrier + sync, run, sync + barrier; returns the MAX wall seconds over ranks."""
+    sync()
+    barrier()
+    t0 = time.perf_counter()
+    run_steps()
+    sync()
+    barrier()
+    return max_over_ranks(time.perf_counter() - t0)
+
+
+def cpu_baseline(model_key, h, w, tile):
+    """CPU oracle on a bounded sample: a (h/4 x w/4) crop = 1/16 of the frame's pixels."""
+    from oracle import uvoracle
+    m = uvoracle.load_model(model_key)
+    sh, sw = max(8, h // 4), max(8, w // 4)
+    img = uvoracle.synthetic_frame(sh, sw)
+    threads = uvoracle.max_threads()
+    t0 = time.perf_counter()
+    if tile > 0:
+        m.upscale_image(img, tile_size=tile, border=10, threads=threads)
+    else:
+        m.apply_model(img, threads=threads)
+    dt = time.perf_counter() - t0
+    frac = (sh * sw) / float(h * w)
+    return {
+        "value": round(frac / dt, 5), "unit": "frames/s", "cores": threads, "kind": "port",
+        "sample": f"one {sw}x{sh} crop ({frac:.4f} of a frame) through oracle/oracle.c (fp32, OpenMP), "
+                  f"{dt:.1f} s, scaled to whole frames; ncnn itself is not installable here",
+    }
+
+
+def parity_probe(net, model_key, tile):
+    """GPU vs CPU oracle on a small frame, reported next to the throughput."""
+    from oracle import uvoracle
+    img = uvoracle.synthetic_frame(96, 128)
+    m = uvoracle.load_model(model_key)
+    want = m.upscale_image(img, tile_size=64, border=10) if tile > 0 else m.apply_model(img)
+    got = net.process_u8(img, tile_size=64 if tile > 0 else 0, border=10)
+    d = got.astype(np.float64) - want.astype(np.float64)
+    mse = float((d * d).mean())
+    return {"psnr_db": round(99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse), 2),
+            "max_abs_lsb": int(np.abs(d).max()), "vs": "CPU oracle fp32, 128x96 frame"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="2x_compact_1080p", choices=sorted(WORKLOADS))
+    ap.add_argument("--tile", type=int, default=960, help="reference tile size (960); 0 = whole frame")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from upscale_video_amd import build
+    build.build_lib()
+    from upscale_video_amd import ncnn
+    from oracle import uvoracle
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    key, stem, h, w = WORKLOADS[args.workload]
+    net = ncnn.Net()
+    net.set_vulkan_device(local_rank)
+    base = os.path.join(ROOT, "models", stem)
+    assert net.load_param(base + ".param") == 0 and net.load_model(base + ".bin") == 0, getattr(net, "last_error", "")
+    s = net.scale
+
+    # synthetic frames, resident in HBM before the timed region
+    n_src = 4
+    frames = [torch.from_numpy(uvoracle.synthetic_frame(h, w, seed=20260928 + 17 * rank + i)).cuda() for i in range(n_src)]
+    out = torch.empty((h * s, w * s, 3), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+
+    def step(i):
+        net.process_u8_device(frames[i % n_src].data_ptr(), h, w, out.data_ptr(), tile_size=args.tile, border=10)
+
+    def sync():
+        net.synchronize()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    net.set_profiling(True)
+    elapsed = timed_region(lambda: [step(i) for i in range(args.steps)], sync, barrier, max_over_ranks)
+    n_launch, trunk_ms = net.kernel_stats(1)
+    _, head_ms = net.kernel_stats(0)
+    _, tail_ms = net.kernel_stats(2)
+    net.set_profiling(False)
+
+    total_frames = args.steps * world
+    fps = total_frames / elapsed
+
+    if rank == 0:
+        nf, nconv = net.num_features, net.num_convs
+        trunk_flops_per_launch = 2 * 9 * nf * nf * h * w        # algorithmic: un-tiled frame
+        avg_ms = trunk_ms / max(1, n_launch)
+        achieved = trunk_flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        frame_flops = conv_flops_per_px(nf, nconv, s) * h * w
+        result = {
+            "metric": "frames/sec 1080p->2x Compact (SRVGGNetCompact per-frame SR hot path)" if args.workload == "2x_compact_1080p"
+                      else "frames/sec " + args.workload,
+            "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16 operands / f32 accumulate", "data": "synthetic",
+            "config": {
+                "workload": f"{w}x{h} synthetic u8 BGR frames, {stem}, upscale_image arithmetic "
+                            f"({'reference 960-px tiles, 10-px border' if args.tile > 0 else 'whole frame'}), "
+                            f"frames and results resident in HBM",
+                "frames_per_rank": args.steps, "tile_size": args.tile, "parallelism": f"frame-sharded x{world}, no collective",
+                "frame_tflop": round(frame_flops / 1e12, 4),
+                "whole_path_tflops": round(frame_flops * fps / world / 1e12, 1),
+                "kernel_ms_per_frame": {"head": round(head_ms / args.steps, 4), "trunk": round(trunk_ms / args.steps, 4),
+                                        "tail": round(tail_ms / args.steps, 4)},
+            },
+            "roofline": {
+                "kernel": f"conv3x3_kernel<{nf},0,1> (trunk {nf}->{nf} + PReLU)",
+                "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                "flops_per_launch": trunk_flops_per_launch, "avg_launch_ms": round(avg_ms, 4), "launches": n_launch,
+            },
+        }
+        if world == 1:
+            result["parity"] = parity_probe(net, key, args.tile)
+            if not args.no_cpu_baseline:
+                result["cpu_baseline"] = cpu_baseline(key, h, w, args.tile)
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -143,7 +143,7 @@ int upload(T** dst, const void* src, size_t bytes, hipStream_t st)
 }
 
 template <int NF>
-constexpr size_t conv_lds(int r) { return 2 * Geo<NF>::BUFB + PARAM_LDS + 4 * (2 * r * TW * r * 3); }
+constexpr size_t conv_lds(int r) { return 2 * Geo<NF>::BUFB + PARAM_LDS + PLANE_LDS + 4 * (2 * r * TW * r * 3); }
 
 template <int NF, int MODE, int R>
 int launch_conv_t(uva_net* n, const ConvArgs& a)

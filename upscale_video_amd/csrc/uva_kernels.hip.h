@@ -70,7 +70,7 @@ struct Geo {
     static constexpr int BUFB = NCHUNK * 1024;
 };
 
-constexpr int PARAM_LDS = 512;   // bias[64] + slope[64] floats
+constexpr int PARAM_LDS = 768;   // bias[64] + slope[64] + PReLU med3 selector[64] floats
 
 struct ConvArgs {
     const PlaneDesc* planes;
@@ -134,42 +134,61 @@ __device__ __forceinline__ void tile_barrier()
 
 struct TileId { int plane, ty, tx; };
 
-__device__ __forceinline__ TileId decode_tile(const PlaneDesc* planes, int nplanes, int t)
+// Which plane owns work tile t: planes are sorted by tile_begin, lane i looks at plane i.
+// 'tile_begin_of(i)' reads from LDS (persistent kernels) or global memory (head kernel).
+template <typename F>
+__device__ __forceinline__ int find_plane(F tile_begin_of, int nplanes, int t, int lane)
 {
-    int p = 0;
-    for (int i = 1; i < nplanes; ++i)
-        if (t >= planes[i].tile_begin) p = i;
-    const int local = t - planes[p].tile_begin;
-    const int ntx = planes[p].ntx;
-    TileId id;
-    id.plane = p;
-    id.ty = local / ntx;
-    id.tx = local - id.ty * ntx;
-    return id;
+    const int tb = lane < nplanes ? tile_begin_of(lane) : 0x7fffffff;
+    const unsigned long long m = __ballot(t >= tb);
+    return __builtin_popcountll(m) - 1;
 }
 
-// LDS-DMA piece i (of this wave) of the (TH+2)x(TW+2) halo tile whose first pixel is at tile_base.
-// Piece c = 4*i + wave covers LDS slots [64c, 64c+64); slot q is pixel q / LSPP, octet q % LSPP.
-// 'lane' must be an opaque copy of the lane id (see opaque()): hipcc otherwise hoists these
-// lane-constant offsets out of the persistent tile loop and spills them to scratch, and the
-// scratch reloads' vmcnt(0) waits would serialise the DMA stream.
+// The plane table lives in LDS inside the persistent kernels: per-tile lookups must not be VMEM
+// loads, whose vmcnt wait would also wait for the previous tile's output stores.
+struct PlaneTable {
+    const PlaneDesc* pl;   // LDS copy
+    const int* tile_begin; // LDS, [MAX_PLANES]
+    int nplanes;
+    __device__ __forceinline__ TileId decode(int t, int lane) const
+    {
+        const int* tb = tile_begin;
+        TileId id;
+        id.plane = __builtin_amdgcn_readfirstlane(find_plane([tb](int i) { return tb[i]; }, nplanes, t, lane));
+        const int ntx = __builtin_amdgcn_readfirstlane(pl[id.plane].ntx);
+        const int local = t - __builtin_amdgcn_readfirstlane(pl[id.plane].tile_begin);
+        id.ty = local / ntx;
+        id.tx = local - id.ty * ntx;
+        return id;
+    }
+};
+
+constexpr int PLANE_LDS = MAX_PLANES * 64 + MAX_PLANES * 4;
+
+// LDS-DMA piece i (of this wave) of the (TH+2)x(TW+2) halo tile: piece c = 4*i + wave covers LDS
+// slots [64c, 64c+64); slot q is pixel q / LSPP, octet q % LSPP.  The lane's source position is
+// loop-invariant and kept packed in one register: (halo row << 16) | byte offset inside the row.
 template <int NF>
-__device__ __forceinline__ void issue_dma_piece(const char* tile_base, int pitch, unsigned lds_buf, int i,
-                                                int wave, int lane)
+__device__ __forceinline__ int dma_piece_const(int i, int wave, int lane)
 {
     using G = Geo<NF>;
-    const int c = i * 4 + wave;
-    if (c < G::NCHUNK) {
-        const int q = c * 64 + lane;
-        int p = q / G::LSPP;
-        int s = q - p * G::LSPP;
-        if (s >= G::SPP) s = G::SPP - 1;      // pad slot: re-fetch the neighbouring octet
-        if (p >= NPIX) p = NPIX - 1;          // tail of the last piece: any valid address
-        const int r = p / PW;
-        const int cc = p - r * PW;
-        const char* g = tile_base + ((size_t)(r * pitch + cc) * G::PIXB + s * 16);
-        glds16(g, lds_buf + c * 1024);
-    }
+    static_assert(G::NCHUNK % 4 == 0, "every wave issues the same number of pieces");
+    const int q = (i * 4 + wave) * 64 + lane;
+    int p = q / G::LSPP;
+    int s = q - p * G::LSPP;
+    if (s >= G::SPP) s = G::SPP - 1;      // pad slot: re-fetch the neighbouring octet
+    if (p >= NPIX) p = NPIX - 1;          // tail of the last piece: any valid address
+    const int r = p / PW;
+    const int cc = p - r * PW;
+    return (r << 16) | (cc * G::PIXB + s * 16);
+}
+
+template <int NF>
+__device__ __forceinline__ void issue_dma_piece(const char* tile_base, int pitch_bytes, unsigned lds_buf, int i,
+                                                int wave, int pc)
+{
+    const unsigned off = (unsigned)(pc >> 16) * (unsigned)pitch_bytes + (unsigned)(pc & 0xffff);
+    glds16(tile_base + off, lds_buf + (i * 4 + wave) * 1024);
 }
 
 template <int NF>
@@ -185,10 +204,16 @@ __device__ __forceinline__ int opaque(int v)
     return v;
 }
 
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // Trunk epilogue shared by the head and trunk kernels: per-channel PReLU (ncnn prelu.cpp:
 // x < 0 ? x*slope[c] : x), fp32 -> fp16 RNE, 8-byte stores into the zero-bordered NHWC plane.
+// PReLU without a compare/select pair: x < 0 ? x*s : x  ==  s <= 1 ? max(x, x*s) : min(x, x*s)
+// (exactly, rounding is monotonic), and both are med3(x, x*s, +-inf); prm_lds holds the slopes at
+// [0,64) and the matching +-inf at [64,128).
 template <int NF, int MF>
-__device__ __forceinline__ void store_trunk(const f32x16 (&acc)[MF], const float* slope_lds, _Float16* out_act,
+__device__ __forceinline__ void store_trunk(const f32x16 (&acc)[MF], const float* prm_lds, _Float16* out_act,
                                             const PlaneDesc& pl, int y, int x, int half)
 {
     if (y >= pl.h || x >= pl.w) return;
@@ -199,15 +224,20 @@ __device__ __forceinline__ void store_trunk(const f32x16 (&acc)[MF], const float
         for (int g = 0; g < 4; ++g) {
             if (32 * m + 8 * g >= NF) continue;   // NF is a multiple of 8: groups are all-or-nothing
             const int cb = 32 * m + 8 * g + 4 * half;
-            const f32x4 s4 = *(const f32x4*)(slope_lds + cb);
-            half4 o;
+            const f32x4 s4 = *(const f32x4*)(prm_lds + cb);
+            const f32x4 i4 = *(const f32x4*)(prm_lds + 64 + cb);
+            f32x4 v;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float v = acc[m][4 * g + j];
-                v = v < 0.f ? v * s4[j] : v;
-                o[j] = (_Float16)v;
+                const float x0 = acc[m][4 * g + j];
+                v[j] = __builtin_amdgcn_fmed3f(x0, x0 * s4[j], i4[j]);
             }
-            *(half4*)(dst + cb * 2) = o;
+            const half2v lo = __builtin_convertvector(f32x2{v[0], v[1]}, half2v);
+            const half2v hi = __builtin_convertvector(f32x2{v[2], v[3]}, half2v);
+            uint2 o;
+            o.x = __builtin_bit_cast(unsigned, lo);
+            o.y = __builtin_bit_cast(unsigned, hi);
+            *(uint2*)(dst + cb * 2) = o;
         }
     }
 }
@@ -235,7 +265,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a)
     const unsigned lds0 = lds_offset(smem);
     float* bias_lds = (float*)(smem + 2 * G::BUFB);
     float* slope_lds = bias_lds + 64;
-    uint8_t* stage_all = (uint8_t*)(smem + 2 * G::BUFB + PARAM_LDS);
+    PlaneDesc* planes_lds = (PlaneDesc*)(smem + 2 * G::BUFB + PARAM_LDS);
+    int* tile_begin_lds = (int*)(smem + 2 * G::BUFB + PARAM_LDS + MAX_PLANES * 64);
+    uint8_t* stage_all = (uint8_t*)(smem + 2 * G::BUFB + PARAM_LDS + PLANE_LDS);
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -255,8 +287,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a)
 
     if (threadIdx.x < 64) {
         bias_lds[threadIdx.x] = threadIdx.x < MF * 32 ? a.bias[threadIdx.x] : 0.f;
-        slope_lds[threadIdx.x] = (MODE == 0 && threadIdx.x < MF * 32) ? a.slope[threadIdx.x] : 0.f;
+        const float sl = (MODE == 0 && threadIdx.x < MF * 32) ? a.slope[threadIdx.x] : 0.f;
+        slope_lds[threadIdx.x] = sl;
+        slope_lds[64 + threadIdx.x] = sl <= 1.f ? __builtin_inff() : -__builtin_inff();
+        tile_begin_lds[threadIdx.x] = threadIdx.x < a.nplanes ? a.planes[threadIdx.x].tile_begin : 0x7fffffff;
     }
+    for (int i = threadIdx.x; i < a.nplanes * 16; i += 256) ((int*)planes_lds)[i] = ((const int*)a.planes)[i];
 
     // the layer's weights, resident in registers for the whole kernel
     half8 w[KS][MF];
@@ -265,51 +301,52 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a)
 #pragma unroll
         for (int m = 0; m < MF; ++m) w[ks][m] = a.wpk[(ks * MF + m) * 64 + lane];
 
-    constexpr int CPW = (G::NCHUNK + 3) / 4;   // DMA pieces per wave per tile
+    constexpr int CPW = G::NCHUNK / 4;   // DMA pieces per wave per tile
     static_assert(2 * CPW <= KS, "one DMA piece every other k-step must fit in the k-loop");
+    int dma_pc[CPW];
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) dma_pc[i] = dma_piece_const<NF>(i, wave, lane);
+
+    __syncthreads();   // plane table / bias visible; nothing is in flight yet
+    PlaneTable pt;
+    pt.pl = planes_lds;
+    pt.tile_begin = tile_begin_lds;
+    pt.nplanes = a.nplanes;
+
+    // bias in MFMA C/D layout (row = (reg&3) + 8*(reg>>2) + 4*half): the first MFMA of every
+    // accumulator chain takes it as its C operand, so accumulators need no initialisation
+    f32x16 biasv[MF];
+#pragma unroll
+    for (int m = 0; m < MF; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) biasv[m][r] = bias_lds[32 * m + 8 * (r >> 2) + 4 * half + (r & 3)];
 
     // prologue: tile 0
+    TileId id = pt.decode(t_first, lane);
     {
-        const TileId id = decode_tile(a.planes, a.nplanes, t_first);
-        const PlaneDesc& pl0 = a.planes[id.plane];
+        const PlaneDesc& pl0 = planes_lds[id.plane];
         const char* tb = halo_tile_base<NF>(a.in_act, pl0, id.ty, id.tx);
-        const int lane_o = opaque(lane);
+        const int pitch0 = __builtin_amdgcn_readfirstlane(pl0.pitch) * G::PIXB;
 #pragma unroll
-        for (int i = 0; i < CPW; ++i) issue_dma_piece<NF>(tb, pl0.pitch, lds0, i, wave, lane_o);
+        for (int i = 0; i < CPW; ++i) issue_dma_piece<NF>(tb, pitch0, lds0, i, wave, dma_pc[i]);
     }
     tile_barrier();
 
+    constexpr int PF = 3;   // B fragments are read PF k-steps ahead of the MFMAs that consume them
+
     for (int it = 0; it < niter; ++it) {
         const int t = t_first + it * g8;
-        const TileId id = decode_tile(a.planes, a.nplanes, t);
-        const PlaneDesc& pl = a.planes[id.plane];
+        const PlaneDesc& pl = planes_lds[id.plane];
         const char* buf = smem + (it & 1) * G::BUFB;
 
         // next tile: its DMA pieces are issued between this tile's MFMAs, into the other buffer
-        // (free since the barrier that ended compute(it-1))
-        const bool have_next = it + 1 < niter;
-        const char* next_tb = nullptr;
-        int next_pitch = 0;
-        if (have_next) {
-            const TileId idn = decode_tile(a.planes, a.nplanes, t + g8);
-            const PlaneDesc& pln = a.planes[idn.plane];
-            next_tb = halo_tile_base<NF>(a.in_act, pln, idn.ty, idn.tx);
-            next_pitch = pln.pitch;
-        }
+        // (free since the barrier that ended compute(it-1)).  The last iteration re-fetches its own
+        // tile so that the k-loop stays one straight-line block.
+        const TileId idn = pt.decode(it + 1 < niter ? t + g8 : t, lane);
+        const PlaneDesc& pln = planes_lds[idn.plane];
+        const char* next_tb = halo_tile_base<NF>(a.in_act, pln, idn.ty, idn.tx);
+        const int next_pitch = __builtin_amdgcn_readfirstlane(pln.pitch) * G::PIXB;
         const unsigned next_lds = lds0 + ((it + 1) & 1) * G::BUFB;
-        const int lane_o = opaque(lane);
-
-        f32x16 acc[2][MF];
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int m = 0; m < MF; ++m)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 b4 = *(const f32x4*)(bias_lds + 32 * m + 8 * g + 4 * half);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[n][m][4 * g + j] = b4[j];
-                }
 
         // B-operand base: pixel (row 2*wave+n, col px) of the halo tile at tap (0,0)
         const char* bbase[2];
@@ -317,31 +354,53 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a)
         for (int n = 0; n < 2; ++n)
             bbase[n] = buf + ((2 * wave + n) * PW + px) * G::LPIXB + (NF == 64 ? half * 16 : 0);
 
+        auto read_b = [&](int ks, int n) -> half8 {
+            if constexpr (NF == 64) {
+                // k-step ks: tap ks/4, channel octets 2*(ks%4) + half
+                const int tap = ks >> 2;
+                const int off = ((tap / 3) * PW + (tap % 3)) * G::LPIXB + (ks & 3) * 32;
+                return *(const half8*)(bbase[n] + off);
+            } else {
+                // k-step ks: K octets 2ks (lanes 0-31) and 2ks+1 (lanes 32-63); octet ko is
+                // tap ko/SPP, channel octet ko%SPP.  ko == KO only exists as zero weights.
+                const int koA = 2 * ks, koB = (2 * ks + 1 < G::KO) ? 2 * ks + 1 : 2 * ks;
+                const int tapA = koA / G::SPP, tapB = koB / G::SPP;
+                const int offA = ((tapA / 3) * PW + (tapA % 3)) * G::LPIXB + (koA % G::SPP) * 16;
+                const int offB = ((tapB / 3) * PW + (tapB % 3)) * G::LPIXB + (koB % G::SPP) * 16;
+                return *(const half8*)(bbase[n] + (half ? offB : offA));
+            }
+        };
+
+        f32x16 acc[2][MF];
+        half8 bq[PF + 1][2];
+        __builtin_amdgcn_sched_barrier(0);   // keep the tile decode's LDS reads out of the pipelined region
+#pragma unroll
+        for (int ks = 0; ks < PF; ++ks)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) bq[ks][n] = read_b(ks, n);
+
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            if ((ks & 1) == 0 && ks / 2 < CPW && have_next)
-                issue_dma_piece<NF>(next_tb, next_pitch, next_lds, ks / 2, wave, lane_o);
+            if (ks + PF < KS) {
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                half8 b;
-                if constexpr (NF == 64) {
-                    // k-step ks: tap ks/4, channel octets 2*(ks%4) + half
-                    const int tap = ks >> 2;
-                    const int off = ((tap / 3) * PW + (tap % 3)) * G::LPIXB + (ks & 3) * 32;
-                    b = *(const half8*)(bbase[n] + off);
-                } else {
-                    // k-step ks: K octets 2ks (lanes 0-31) and 2ks+1 (lanes 32-63); octet ko is
-                    // tap ko/SPP, channel octet ko%SPP.  ko == KO only exists as zero weights.
-                    const int koA = 2 * ks, koB = (2 * ks + 1 < G::KO) ? 2 * ks + 1 : 2 * ks;
-                    const int tapA = koA / G::SPP, tapB = koB / G::SPP;
-                    const int offA = ((tapA / 3) * PW + (tapA % 3)) * G::LPIXB + (koA % G::SPP) * 16;
-                    const int offB = ((tapB / 3) * PW + (tapB % 3)) * G::LPIXB + (koB % G::SPP) * 16;
-                    b = *(const half8*)(bbase[n] + (half ? offB : offA));
-                }
+                for (int n = 0; n < 2; ++n) bq[(ks + PF) % (PF + 1)][n] = read_b(ks + PF, n);
+            }
+            if ((ks & 1) == 0 && ks / 2 < CPW)
+                issue_dma_piece<NF>(next_tb, next_pitch, next_lds, ks / 2, wave, dma_pc[ks / 2]);
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
 #pragma unroll
                 for (int m = 0; m < MF; ++m)
-                    acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks][m], b, acc[n][m], 0, 0, 0);
-            }
+                    acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks][m], bq[ks % (PF + 1)][n],
+                                                                        ks == 0 ? biasv[m] : acc[n][m], 0, 0, 0);
+        }
+        // pin the software pipeline: PF k-steps of LDS reads up front, then {MFMAs of one k-step,
+        // LDS reads of one k-step}.  With one wave per SIMD nothing else hides the LDS latency.
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * PF, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * MF, 0);
+            if (ks + PF < KS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         }
 
         // every wave is done reading buf[it&1] and this wave's share of DMA(it+1) has landed
@@ -423,6 +482,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a)
                 __builtin_amdgcn_wave_barrier();
             }
         }
+        id = idn;
     }
 }
 
@@ -447,12 +507,22 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a)
     const int half = lane >> 5;
     const int px = lane & 31;
 
-    const TileId id = decode_tile(a.planes, a.nplanes, blockIdx.x);
+    const PlaneDesc* gpl = a.planes;
+    TileId id;
+    id.plane = __builtin_amdgcn_readfirstlane(
+        find_plane([gpl](int i) { return gpl[i].tile_begin; }, a.nplanes, (int)blockIdx.x, lane));
     const PlaneDesc& pl = a.planes[id.plane];
+    {
+        const int local = (int)blockIdx.x - pl.tile_begin;
+        id.ty = local / pl.ntx;
+        id.tx = local - id.ty * pl.ntx;
+    }
 
     if (threadIdx.x < 64) {
         bias_lds[threadIdx.x] = threadIdx.x < MF * 32 ? a.bias[threadIdx.x] : 0.f;
-        slope_lds[threadIdx.x] = threadIdx.x < MF * 32 ? a.slope[threadIdx.x] : 0.f;
+        const float sl = threadIdx.x < MF * 32 ? a.slope[threadIdx.x] : 0.f;
+        slope_lds[threadIdx.x] = sl;
+        slope_lds[64 + threadIdx.x] = sl <= 1.f ? __builtin_inff() : -__builtin_inff();
     }
     for (int p = threadIdx.x; p < NPIX; p += 256) {
         const int r = p / PW, c = p - (p / PW) * PW;
