@@ -102,6 +102,14 @@ int uva_net_debug_read_activation(uva_net* net, int conv_idx, float* out_chw, in
 int uva_net_set_profiling(uva_net* net, int enable);
 int uva_net_kernel_stats(uva_net* net, int kind, long long* launches, double* total_ms);
 
+/* Debug: replays one trunk-layer launch on the last call's workspace with in-kernel cycle stamps
+ * of workgroup 0 / wave 0: out[8*i + {0,1,2,3,4}] = tile i {start, k-loop done, barrier passed,
+ * epilogue done, epilogue staging written} in s_memtime ticks (out holds 8*max_tiles values).
+ * *tiles = tiles that workgroup processed.  ablate: 0 real kernel, 1 memory traffic only (no MFMA /
+ * LDS reads), 2 compute only (L2-resident input, stores to a sink); *kernel_ms = mean of 10 launches. */
+int uva_net_debug_trunk_stamps(uva_net* net, unsigned long long* out, int max_tiles, int* tiles, int ablate,
+                               float* kernel_ms);
+
 /* Test hook (host only, no device needed): the fp16 MFMA A-operand image convolution #conv_idx is
  * repacked into, [k-step][m-frag][lane][8].  *needed receives the element count. */
 int uva_net_debug_packed_weights(uva_net* net, int conv_idx, uint16_t* out, size_t out_halfs, size_t* needed);

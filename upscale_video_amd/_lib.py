@@ -12,7 +12,7 @@ SYMBOLS = [
     "uva_net_destroy", "uva_net_scale", "uva_net_num_features", "uva_net_num_convs",
     "uva_net_extract_f32", "uva_net_process_u8", "uva_net_process_u8_device", "uva_net_synchronize",
     "uva_net_debug_read_activation", "uva_net_set_profiling", "uva_net_kernel_stats",
-    "uva_net_debug_packed_weights", "uva_last_error", "uva_abi_version",
+    "uva_net_debug_packed_weights", "uva_net_debug_trunk_stamps", "uva_last_error", "uva_abi_version",
 ]
 
 _lib = None
@@ -55,6 +55,7 @@ def load():
     L.uva_net_kernel_stats.argtypes = [c_p, c_i, ctypes.POINTER(ctypes.c_longlong),
                                        ctypes.POINTER(ctypes.c_double)]
     L.uva_net_debug_packed_weights.argtypes = [c_p, c_i, c_p, c_sz, ctypes.POINTER(c_sz)]
+    L.uva_net_debug_trunk_stamps.argtypes = [c_p, c_p, c_i, ctypes.POINTER(c_i), c_i, ctypes.POINTER(ctypes.c_float)]
     L.uva_last_error.restype = ctypes.c_char_p
     L.uva_abi_version.restype = c_i
     for n in SYMBOLS:   # AttributeError here means the .so is stale: rebuild it

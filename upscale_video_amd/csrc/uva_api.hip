@@ -44,7 +44,8 @@ struct Workspace {
     int h = 0, w = 0, tile_size = 0, border = 0;
     std::vector<PlaneDesc> planes;
     PlaneDesc* d_planes = nullptr;
-    int ntiles = 0;
+    int ntiles = 0;     // 8-row work tiles (head, tail, 24-feature trunk)
+    int ntiles4 = 0;    // 4-row work tiles (64-feature trunk kernel)
     size_t act_pixels = 0;
     _Float16* act[2] = {nullptr, nullptr};
     void release()
@@ -89,6 +90,7 @@ struct uva_net {
     size_t h_in_cap = 0, h_out_cap = 0, d_in_cap = 0, d_out_cap = 0;
     float *d_fin = nullptr, *d_fout = nullptr;
     size_t d_fin_cap = 0, d_fout_cap = 0;
+    _Float16* d_sink = nullptr;   // where out-of-image lanes of the trunk kernel store to
     LastCall last;
     // profiling
     bool prof = false;
@@ -117,6 +119,8 @@ struct uva_net {
         if (d_out) (void)hipFree(d_out);
         if (d_fin) (void)hipFree(d_fin);
         if (d_fout) (void)hipFree(d_fout);
+        if (d_sink) (void)hipFree(d_sink);
+        d_sink = nullptr;
         h_in = h_out = d_in = d_out = nullptr;
         d_fin = d_fout = nullptr;
         h_in_cap = h_out_cap = d_in_cap = d_out_cap = d_fin_cap = d_fout_cap = 0;
@@ -142,14 +146,12 @@ int upload(T** dst, const void* src, size_t bytes, hipStream_t st)
     return 0;
 }
 
-template <int NF>
-constexpr size_t conv_lds(int r) { return 2 * Geo<NF>::BUFB + PARAM_LDS + PLANE_LDS + 4 * (2 * r * TW * r * 3); }
 
 template <int NF, int MODE, int R>
 int launch_conv_t(uva_net* n, const ConvArgs& a)
 {
     static bool attr_done[16] = {false};   // per device ordinal
-    const size_t lds = conv_lds<NF>(MODE == 0 ? 1 : R);
+    const size_t lds = conv_lds_bytes<NF>(MODE == 0 ? 0 : R);
     auto kfn = conv3x3_kernel<NF, MODE, R>;
     if (n->device < 16 && !attr_done[n->device]) {
         HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -161,6 +163,30 @@ int launch_conv_t(uva_net* n, const ConvArgs& a)
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, n->stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+// trunk layer of the 64-feature nets: split-channel ping-pong kernel, one 8-wave workgroup per CU, 4-row tiles
+template <int ABL>
+int launch_trunk64_t(uva_net* n, const ConvArgs& a)
+{
+    static bool attr_done[16] = {false};
+    const size_t lds = trunk_lds_bytes<64>();
+    auto kfn = trunk_kernel<64, ABL>;
+    if (n->device >= 16 || !attr_done[n->device]) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (n->device < 16) attr_done[n->device] = true;
+    }
+    const int grid = std::max(8, (n->ncu / 8) * 8);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), lds, n->stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_trunk64(uva_net* n, const ConvArgs& a, int ablate = 0)
+{
+    if (ablate == 1) return launch_trunk64_t<1>(n, a);
+    if (ablate == 2) return launch_trunk64_t<2>(n, a);
+    return launch_trunk64_t<0>(n, a);
 }
 
 template <int NF>
@@ -184,6 +210,19 @@ int launch_conv(uva_net* n, int mode, const ConvArgs& a)
     if (n->g.nf == 64) return launch_conv_nf<64>(n, mode, n->g.scale, a);
     if (n->g.nf == 24) return launch_conv_nf<24>(n, mode, n->g.scale, a);
     return fail("no kernel for this trunk width");
+}
+
+// one trunk layer: the 64-feature nets use the split-channel kernel on 4-row tiles
+int launch_trunk(uva_net* n, const Workspace* ws, ConvArgs ca, int ablate = 0)
+{
+    if (n->g.nf == 64) {
+        ca.ntiles = ws->ntiles4;
+        ca.tiles_per_xcd = (ws->ntiles4 + 7) / 8;
+        return launch_trunk64(n, ca, ablate);
+    }
+    ca.ntiles = ws->ntiles;
+    ca.tiles_per_xcd = (ws->ntiles + 7) / 8;
+    return launch_conv(n, 0, ca);
 }
 
 int launch_head(uva_net* n, bool f32, const HeadArgs& a)
@@ -220,6 +259,7 @@ int ensure_device(uva_net* n)
     n->ncu = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking));
     n->dev_ready = true;
+    HIP_TRY(hipMalloc((void**)&n->d_sink, 64 * 128 + 256));
     // weights: head, trunk..., tail
     const Graph& g = n->g;
     n->layers.resize(g.convs.size());
@@ -286,17 +326,21 @@ int get_workspace(uva_net* n, int h, int w, int tile_size, int border, Workspace
     ws.h = h; ws.w = w; ws.tile_size = tile_size; ws.border = border;
     if (build_planes(h, w, tile_size, border, ws.planes)) return 1;
     size_t pix = 0;
-    int tiles = 0;
+    int tiles = 0, tiles4 = 0;
     for (auto& p : ws.planes) {
         p.nty = (p.h + TH - 1) / TH;
         p.ntx = (p.w + TW - 1) / TW;
         p.pitch = p.ntx * TW + 2;
         p.tile_begin = tiles;
+        p.nty4 = (p.h + 3) / 4;
+        p.tile_begin4 = tiles4;
         p.act_off = (long long)pix;
         tiles += p.nty * p.ntx;
+        tiles4 += p.nty4 * p.ntx;
         pix += (size_t)(p.nty * TH + 2) * p.pitch;
     }
     ws.ntiles = tiles;
+    ws.ntiles4 = tiles4;
     ws.act_pixels = pix;
     if (n->wss.size() >= 6) {   // LRU: keep a handful of geometries resident
         HIP_TRY(hipStreamSynchronize(n->stream));
@@ -381,6 +425,7 @@ int run_graph(uva_net* n, Workspace* ws, bool f32, const void* src, size_t src_s
     ca.nplanes = (int)ws->planes.size();
     ca.ntiles = ws->ntiles;
     ca.tiles_per_xcd = (ws->ntiles + 7) / 8;
+    ca.sink = n->d_sink;
     for (int i = 1; i < nconv - 1; ++i) {
         if (stop_after >= 0 && i > stop_after) return 0;
         ca.in_act = ws->act[(i - 1) & 1];
@@ -388,10 +433,12 @@ int run_graph(uva_net* n, Workspace* ws, bool f32, const void* src, size_t src_s
         ca.wpk = n->layers[i].wpk;
         ca.bias = n->layers[i].bias;
         ca.slope = n->layers[i].slope;
-        if (launch_conv(n, 0, ca)) return 1;
+        if (launch_trunk(n, ws, ca)) return 1;
     }
     if (stop_after >= 0) return 0;
     if (prof) HIP_TRY(hipEventRecord(ev.e[2], n->stream));
+    ca.ntiles = ws->ntiles;
+    ca.tiles_per_xcd = (ws->ntiles + 7) / 8;
     ca.in_act = ws->act[(nconv - 2) & 1];
     ca.out_act = nullptr;
     ca.wpk = n->layers[nconv - 1].wpk;
@@ -626,6 +673,63 @@ int uva_net_kernel_stats(uva_net* n, int kind, long long* launches, double* tota
     if (launches) *launches = n->launches[kind];
     if (total_ms) *total_ms = n->total_ms[kind];
     return 0;
+}
+
+// debug: one trunk-layer launch on the last call's workspace with in-kernel s_memtime stamps
+// (block 0, wave 0): out[8*i + {0,1,2,3,4}] = tile i {start, k-loop done, barrier passed, epilogue done,
+// epilogue staging written}
+int uva_net_debug_trunk_stamps(uva_net* n, unsigned long long* out, int max_tiles, int* tiles, int ablate,
+                               float* kernel_ms)
+{
+    if (!n || !out || !n->dev_ready || !n->last.valid) return fail("no previous call to replay");
+    Workspace* ws = n->last.ws;
+    HIP_TRY(hipSetDevice(n->device));
+    unsigned long long* d = nullptr;
+    const size_t bytes = (size_t)max_tiles * 8 * sizeof(unsigned long long);
+    HIP_TRY(hipMalloc((void**)&d, bytes));
+    HIP_TRY(hipMemsetAsync(d, 0, bytes, n->stream));
+    ConvArgs ca;
+    std::memset(&ca, 0, sizeof ca);
+    ca.planes = ws->d_planes;
+    ca.nplanes = (int)ws->planes.size();
+    ca.ntiles = ws->ntiles;
+    ca.tiles_per_xcd = (ws->ntiles + 7) / 8;
+    ca.in_act = ws->act[0];
+    ca.out_act = ws->act[1];
+    ca.wpk = n->layers[1].wpk;
+    ca.bias = n->layers[1].bias;
+    ca.slope = n->layers[1].slope;
+    ca.dbg = d;
+    ca.sink = n->d_sink;
+    const bool split = n->g.nf == 64;
+    const int grid = std::max(8, (n->ncu / 8) * 8);
+    const int g8 = (split ? 2 : 1) * grid / 8;
+    const int txcd = ((split ? ws->ntiles4 : ws->ntiles) + 7) / 8;
+    const int per_block = (txcd + g8 - 1) / g8;
+    if (per_block > max_tiles) { (void)hipFree(d); return fail("max_tiles too small"); }
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    int rc = launch_trunk(n, ws, ca, ablate);   // warm
+    ca.dbg = nullptr;
+    HIP_TRY(hipEventRecord(e0, n->stream));
+    for (int r = 0; r < 10 && !rc; ++r) rc = launch_trunk(n, ws, ca, ablate);
+    HIP_TRY(hipEventRecord(e1, n->stream));
+    ca.dbg = d;
+    HIP_TRY(hipMemsetAsync(d, 0, bytes, n->stream));
+    if (!rc) rc = launch_trunk(n, ws, ca, ablate);
+    if (!rc) {
+        HIP_TRY(hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, n->stream));
+        HIP_TRY(hipStreamSynchronize(n->stream));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        if (kernel_ms) *kernel_ms = ms / 10;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(d);
+    if (tiles) *tiles = per_block;
+    return rc;
 }
 
 // test hook: the packed MFMA weight image of convolution #conv_idx (host side, no device needed)

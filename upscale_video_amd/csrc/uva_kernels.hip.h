@@ -26,12 +26,28 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <utility>
+
 namespace uva {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{}).
+// Used where a loop body must see its index as a constant expression (if constexpr, builtin
+// immediates) and where '#pragma unroll' would give up on the pre-unrolling size of the body.
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
 
 constexpr int TH = 8;           // work-tile rows
 constexpr int TW = 32;          // work-tile columns (= one MFMA N fragment)
@@ -52,12 +68,14 @@ struct PlaneDesc {
     int src_y0, src_x0;     // plane origin inside the source frame
     int core_y0, core_y1;   // plane-local rows whose output is written (border cropped, :464-477)
     int core_x0, core_x1;   // plane-local columns whose output is written
-    int pad0, pad1;
+    int nty4;               // work tiles of the trunk kernel (4-row tiles)
+    int tile_begin4;        // first global 4-row work-tile index of this plane
 };
 static_assert(sizeof(PlaneDesc) == 64, "PlaneDesc layout");
 
-template <int NF>
+template <int NF, int THT = TH>
 struct Geo {
+    static constexpr int NPIXT = (THT + 2) * PW;             // pixels per halo tile
     static constexpr int SPP = NF / 8;                       // 16-byte channel octets per pixel
     static constexpr int LSPP = (NF == 64) ? 9 : SPP;        // LDS slots per pixel (64ch: +1 pad slot
                                                              //  -> 144 B stride, conflict-free b128)
@@ -65,8 +83,9 @@ struct Geo {
     static constexpr int PIXB = NF * 2;                      // HBM bytes per pixel
     static constexpr int KO = 9 * SPP;                       // K octets (tap-major, then channel octet)
     static constexpr int KS = (KO + 1) / 2;                  // MFMA k-steps of 16
-    static constexpr int NSLOT = NPIX * LSPP;
-    static constexpr int NCHUNK = (NSLOT + 63) / 64;         // 1-KiB LDS-DMA pieces per halo tile
+    static constexpr int NSLOT = NPIXT * LSPP;
+    static constexpr int NCHUNK = ((NSLOT + 63) / 64 + 3) / 4 * 4;   // 1-KiB LDS-DMA pieces per halo tile,
+                                                                      // a multiple of the 4 waves
     static constexpr int BUFB = NCHUNK * 1024;
 };
 
@@ -88,6 +107,8 @@ struct ConvArgs {
     uint8_t* dst_u8;
     size_t dst_stride;
     float* dst_f32;               // planar [3][h*R][w*R]
+    unsigned long long* dbg;      // optional: per-tile s_memtime stamps of block 0 / wave 0 (debug)
+    _Float16* sink;               // >= 64 pixels of scratch: where lanes outside the image store to
 };
 
 struct HeadArgs {
@@ -109,6 +130,14 @@ __device__ __forceinline__ unsigned lds_offset(const void* p)
     return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
 
+// An opaque copy of a lane-constant value: stops hipcc from hoisting everything derived from it out
+// of the persistent tile loop (where it would be spilled to scratch and reloaded behind a vmcnt wait).
+__device__ __forceinline__ int opaque(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 // One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to lds_dst + lane*16.
 // Invisible to hipcc's s_waitcnt bookkeeping by design (it would otherwise drain the DMA before
 // every LDS read); completion is waited for explicitly with vmcnt(0) in tile_barrier().  No
@@ -127,9 +156,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst)
         : "v"(gsrc), "s"(lds_dst));
 }
 
+// End of a tile's k-loop: wait until all but the newest KEEP vector-memory operations of this
+// wave have completed (loads, LDS-DMA included, return in issue order), drain LDS, then barrier.
+template <int KEEP>
 __device__ __forceinline__ void tile_barrier()
 {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    static_assert(KEEP >= 0 && KEEP < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(KEEP) : "memory");
 }
 
 struct TileId { int plane, ty, tx; };
@@ -148,15 +181,16 @@ __device__ __forceinline__ int find_plane(F tile_begin_of, int nplanes, int t, i
 // loads, whose vmcnt wait would also wait for the previous tile's output stores.
 struct PlaneTable {
     const PlaneDesc* pl;   // LDS copy
-    const int* tile_begin; // LDS, [MAX_PLANES]
+    const int* tile_begin; // LDS, [MAX_PLANES]: tile_begin (8-row tiles) or tile_begin4 (4-row tiles)
     int nplanes;
+    template <bool ROWS4 = false>
     __device__ __forceinline__ TileId decode(int t, int lane) const
     {
         const int* tb = tile_begin;
         TileId id;
         id.plane = __builtin_amdgcn_readfirstlane(find_plane([tb](int i) { return tb[i]; }, nplanes, t, lane));
         const int ntx = __builtin_amdgcn_readfirstlane(pl[id.plane].ntx);
-        const int local = t - __builtin_amdgcn_readfirstlane(pl[id.plane].tile_begin);
+        const int local = t - __builtin_amdgcn_readfirstlane(ROWS4 ? pl[id.plane].tile_begin4 : pl[id.plane].tile_begin);
         id.ty = local / ntx;
         id.tx = local - id.ty * ntx;
         return id;
@@ -165,81 +199,123 @@ struct PlaneTable {
 
 constexpr int PLANE_LDS = MAX_PLANES * 64 + MAX_PLANES * 4;
 
-// LDS-DMA piece i (of this wave) of the (TH+2)x(TW+2) halo tile: piece c = 4*i + wave covers LDS
-// slots [64c, 64c+64); slot q is pixel q / LSPP, octet q % LSPP.  The lane's source position is
+// LDS-DMA piece i (of this wave) of the (TH+2)x(TW+2) halo tile: piece c = wave*CPW + i covers LDS
+// slots [64c, 64c+64); slot q is pixel q / LSPP, octet q % LSPP.  A wave's pieces are contiguous, so
+// region [wave*CPW KiB, (wave+1)*CPW KiB) of every ring slot is written by that wave only -- which
+// is what lets the wave reuse the region of a consumed slot as its private output staging area.  The lane's source position is
 // loop-invariant and kept packed in one register: (halo row << 16) | byte offset inside the row.
-template <int NF>
+template <int NF, int THT = TH>
 __device__ __forceinline__ int dma_piece_const(int i, int wave, int lane)
 {
-    using G = Geo<NF>;
-    static_assert(G::NCHUNK % 4 == 0, "every wave issues the same number of pieces");
-    const int q = (i * 4 + wave) * 64 + lane;
+    using G = Geo<NF, THT>;
+    const int q = (wave * (G::NCHUNK / 4) + i) * 64 + lane;
     int p = q / G::LSPP;
     int s = q - p * G::LSPP;
-    if (s >= G::SPP) s = G::SPP - 1;      // pad slot: re-fetch the neighbouring octet
-    if (p >= NPIX) p = NPIX - 1;          // tail of the last piece: any valid address
+    if (s >= G::SPP) s = G::SPP - 1;          // pad slot: re-fetch the neighbouring octet
+    if (p >= G::NPIXT) p = G::NPIXT - 1;      // tail of the last piece: any valid address
     const int r = p / PW;
     const int cc = p - r * PW;
     return (r << 16) | (cc * G::PIXB + s * 16);
 }
 
-template <int NF>
+template <int NF, int THT = TH>
 __device__ __forceinline__ void issue_dma_piece(const char* tile_base, int pitch_bytes, unsigned lds_buf, int i,
                                                 int wave, int pc)
 {
     const unsigned off = (unsigned)(pc >> 16) * (unsigned)pitch_bytes + (unsigned)(pc & 0xffff);
-    glds16(tile_base + off, lds_buf + (i * 4 + wave) * 1024);
+    glds16(tile_base + off, lds_buf + (wave * (Geo<NF, THT>::NCHUNK / 4) + i) * 1024);
 }
 
-template <int NF>
+template <int NF, int THT = TH>
 __device__ __forceinline__ const char* halo_tile_base(const _Float16* act, const PlaneDesc& pl, int ty, int tx)
 {
     return (const char*)act +
-           ((size_t)pl.act_off + (size_t)(ty * TH) * pl.pitch + (size_t)tx * TW) * Geo<NF>::PIXB;
-}
-
-__device__ __forceinline__ int opaque(int v)
-{
-    asm volatile("" : "+v"(v));
-    return v;
+           ((size_t)pl.act_off + (size_t)(ty * THT) * pl.pitch + (size_t)tx * TW) * Geo<NF, THT>::PIXB;
 }
 
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Trunk epilogue shared by the head and trunk kernels: per-channel PReLU (ncnn prelu.cpp:
-// x < 0 ? x*slope[c] : x), fp32 -> fp16 RNE, 8-byte stores into the zero-bordered NHWC plane.
+// x < 0 ? x*slope[c] : x), fp32 -> fp16 RNE, store into the zero-bordered NHWC plane.
 // PReLU without a compare/select pair: x < 0 ? x*s : x  ==  s <= 1 ? max(x, x*s) : min(x, x*s)
 // (exactly, rounding is monotonic), and both are med3(x, x*s, +-inf); prm_lds holds the slopes at
 // [0,64) and the matching +-inf at [64,128).
+// The MFMA C/D layout gives a lane 4 consecutive channels of ONE pixel, i.e. 8-byte pieces at a
+// 128-byte stride: stored directly that is 32 cache lines per instruction and the store path, not
+// HBM, becomes the limit.  So the wave's two rows (2 x 32 pixels) are transposed through a
+// wave-private LDS area and leave as 16 B per lane, 1 KiB contiguous per instruction.
+template <int NF>
+struct StageGeo {
+    static constexpr int SPX = (NF == 64) ? 144 : NF * 2;   // staging bytes per pixel (64ch: padded)
+    static constexpr int BYTES = 64 * SPX;                  // per wave
+};
+
 template <int NF, int MF>
-__device__ __forceinline__ void store_trunk(const f32x16 (&acc)[MF], const float* prm_lds, _Float16* out_act,
-                                            const PlaneDesc& pl, int y, int x, int half)
+__device__ __forceinline__ void store_trunk_rows(const f32x16 (&acc)[2][MF], const float* prm_lds, char* stage,
+                                                 _Float16* out_act, const PlaneDesc& pl, int y0, int x0, int lane,
+                                                 unsigned long long* stamp = nullptr)
 {
-    if (y >= pl.h || x >= pl.w) return;
-    char* dst = (char*)out_act + ((size_t)pl.act_off + (size_t)(y + 1) * pl.pitch + (x + 1)) * (NF * 2);
+    constexpr int SPX = StageGeo<NF>::SPX, PIXB = NF * 2, SPP = NF / 8;
+    const int px = lane & 31, half = lane >> 5;
 #pragma unroll
-    for (int m = 0; m < MF; ++m) {
+    for (int n = 0; n < 2; ++n) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (32 * m + 8 * g >= NF) continue;   // NF is a multiple of 8: groups are all-or-nothing
-            const int cb = 32 * m + 8 * g + 4 * half;
-            const f32x4 s4 = *(const f32x4*)(prm_lds + cb);
-            const f32x4 i4 = *(const f32x4*)(prm_lds + 64 + cb);
-            f32x4 v;
+        for (int m = 0; m < MF; ++m) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float x0 = acc[m][4 * g + j];
-                v[j] = __builtin_amdgcn_fmed3f(x0, x0 * s4[j], i4[j]);
+            for (int g = 0; g < 4; ++g) {
+                if (32 * m + 8 * g >= NF) continue;   // NF is a multiple of 8: groups are all-or-nothing
+                const int cb = 32 * m + 8 * g + 4 * half;
+                const f32x4 s4 = *(const f32x4*)(prm_lds + cb);
+                const f32x4 i4 = *(const f32x4*)(prm_lds + 64 + cb);
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x = acc[n][m][4 * g + j];
+                    v[j] = __builtin_amdgcn_fmed3f(x, x * s4[j], i4[j]);
+                }
+                const half2v lo = __builtin_convertvector(f32x2{v[0], v[1]}, half2v);
+                const half2v hi = __builtin_convertvector(f32x2{v[2], v[3]}, half2v);
+                uint2 o;
+                o.x = __builtin_bit_cast(unsigned, lo);
+                o.y = __builtin_bit_cast(unsigned, hi);
+                *(uint2*)(stage + (n * 32 + px) * SPX + cb * 2) = o;
             }
-            const half2v lo = __builtin_convertvector(f32x2{v[0], v[1]}, half2v);
-            const half2v hi = __builtin_convertvector(f32x2{v[2], v[3]}, half2v);
-            uint2 o;
-            o.x = __builtin_bit_cast(unsigned, lo);
-            o.y = __builtin_bit_cast(unsigned, hi);
-            *(uint2*)(dst + cb * 2) = o;
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (stamp) *stamp = __builtin_amdgcn_s_memtime();
+    const int vx = min(TW, pl.w - x0);          // valid pixels of this tile row (uniform)
+    const int pitch = pl.pitch;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int y = y0 + n;
+        if (y >= pl.h) continue;                // uniform
+        char* grow = (char*)out_act + ((size_t)pl.act_off + (size_t)(y + 1) * pitch + (x0 + 1)) * PIXB;
+#pragma unroll
+        for (int k = 0; k < (32 * SPP + 63) / 64; ++k) {
+            const int q = k * 64 + lane;
+            const int pix = q / SPP, slot = q - pix * SPP;
+            if (q < 32 * SPP && pix < vx)
+                *(uint4*)(grow + pix * PIXB + slot * 16) = *(const uint4*)(stage + (n * 32 + pix) * SPX + slot * 16);
+        }
+    }
+}
+
+constexpr int PARAMS_AND_PLANES_LDS = 768 + MAX_PLANES * 64 + MAX_PLANES * 4;
+// r = 0: trunk (no output staging); r = 1, 2, 4: tail with u8 staging of 2r rows x TW*r*3 bytes per wave
+constexpr int conv_stage_bytes(int r) { return r == 0 ? 0 : 4 * (2 * r * TW * r * 3); }
+template <int NF>
+constexpr int conv_nbuf(int r)
+{
+    return 3 * Geo<NF>::BUFB + PARAMS_AND_PLANES_LDS + conv_stage_bytes(r) <= 160 * 1024 ? 3 : 2;
+}
+template <int NF>
+constexpr int conv_lds_bytes(int r)
+{
+    return conv_nbuf<NF>(r) * Geo<NF>::BUFB + PARAMS_AND_PLANES_LDS + conv_stage_bytes(r);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -261,13 +337,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a)
     constexpr int STAGE_ROWB = TW * R * 3;             // bytes per staged output row
     constexpr int STAGEB = 2 * R * STAGE_ROWB;         // per wave: 2 tile rows -> 2R output rows
 
+    // LDS: NBUF halo-tile buffers (a ring: tile it lives in buffer it % NBUF and tile it+NBUF-1 is
+    // being streamed in while tile it is computed), then parameters, plane table, tail staging.
+    constexpr int NBUF = conv_nbuf<NF>(MODE == 0 ? 0 : R);
+    constexpr int LA = NBUF - 1;                       // tiles of DMA look-ahead
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = lds_offset(smem);
-    float* bias_lds = (float*)(smem + 2 * G::BUFB);
+    float* bias_lds = (float*)(smem + NBUF * G::BUFB);
     float* slope_lds = bias_lds + 64;
-    PlaneDesc* planes_lds = (PlaneDesc*)(smem + 2 * G::BUFB + PARAM_LDS);
-    int* tile_begin_lds = (int*)(smem + 2 * G::BUFB + PARAM_LDS + MAX_PLANES * 64);
-    uint8_t* stage_all = (uint8_t*)(smem + 2 * G::BUFB + PARAM_LDS + PLANE_LDS);
+    PlaneDesc* planes_lds = (PlaneDesc*)(smem + NBUF * G::BUFB + PARAM_LDS);
+    int* tile_begin_lds = (int*)(smem + NBUF * G::BUFB + PARAM_LDS + MAX_PLANES * 64);
+    uint8_t* stage_all = (uint8_t*)(smem + NBUF * G::BUFB + PARAM_LDS + PLANE_LDS);
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -302,7 +382,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a)
         for (int m = 0; m < MF; ++m) w[ks][m] = a.wpk[(ks * MF + m) * 64 + lane];
 
     constexpr int CPW = G::NCHUNK / 4;   // DMA pieces per wave per tile
-    static_assert(2 * CPW <= KS, "one DMA piece every other k-step must fit in the k-loop");
+    static_assert(CPW <= KS, "one DMA piece per k-step must fit in the k-loop");
     int dma_pc[CPW];
 #pragma unroll
     for (int i = 0; i < CPW; ++i) dma_pc[i] = dma_piece_const<NF>(i, wave, lane);
@@ -315,38 +395,48 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a)
 
     // bias in MFMA C/D layout (row = (reg&3) + 8*(reg>>2) + 4*half): the first MFMA of every
     // accumulator chain takes it as its C operand, so accumulators need no initialisation
+    // (trunk only: the tails are short of registers and add the bias in their epilogue instead)
     f32x16 biasv[MF];
 #pragma unroll
     for (int m = 0; m < MF; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) biasv[m][r] = bias_lds[32 * m + 8 * (r >> 2) + 4 * half + (r & 3)];
+        for (int r = 0; r < 16; ++r)
+            biasv[m][r] = (MODE == 0) ? bias_lds[32 * m + 8 * (r >> 2) + 4 * half + (r & 3)] : 0.f;
 
-    // prologue: tile 0
-    TileId id = pt.decode(t_first, lane);
-    {
-        const PlaneDesc& pl0 = planes_lds[id.plane];
-        const char* tb = halo_tile_base<NF>(a.in_act, pl0, id.ty, id.tx);
-        const int pitch0 = __builtin_amdgcn_readfirstlane(pl0.pitch) * G::PIXB;
+    // prologue: tiles 0 .. LA-1 (tile indices past the end re-fetch the last tile: harmless)
+    TileId ids[LA + 1];
 #pragma unroll
-        for (int i = 0; i < CPW; ++i) issue_dma_piece<NF>(tb, pitch0, lds0, i, wave, dma_pc[i]);
+    for (int j = 0; j < LA; ++j) {
+        ids[j] = pt.decode(t_first + min(j, niter - 1) * g8, lane);
+        const PlaneDesc& plj = planes_lds[ids[j].plane];
+        const char* tb = halo_tile_base<NF>(a.in_act, plj, ids[j].ty, ids[j].tx);
+        const int pitchj = __builtin_amdgcn_readfirstlane(plj.pitch) * G::PIXB;
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) issue_dma_piece<NF>(tb, pitchj, lds0 + j * G::BUFB, i, wave, dma_pc[i]);
     }
-    tile_barrier();
+    tile_barrier<0>();
 
-    constexpr int PF = 3;   // B fragments are read PF k-steps ahead of the MFMAs that consume them
+    // B fragments are read PF k-steps ahead of the MFMAs that consume them (tails: fewer, their
+    // epilogue needs the registers)
+    constexpr int PF = (MODE == 0) ? 3 : 1;
+    int cur = 0;            // ring slot of the tile being computed
 
+    const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
     for (int it = 0; it < niter; ++it) {
-        const int t = t_first + it * g8;
+        if (stamp) a.dbg[8 * it + 0] = __builtin_amdgcn_s_memtime();
+        const TileId id = ids[0];
         const PlaneDesc& pl = planes_lds[id.plane];
-        const char* buf = smem + (it & 1) * G::BUFB;
+        const char* buf = smem + cur * G::BUFB;
 
-        // next tile: its DMA pieces are issued between this tile's MFMAs, into the other buffer
-        // (free since the barrier that ended compute(it-1)).  The last iteration re-fetches its own
-        // tile so that the k-loop stays one straight-line block.
-        const TileId idn = pt.decode(it + 1 < niter ? t + g8 : t, lane);
-        const PlaneDesc& pln = planes_lds[idn.plane];
-        const char* next_tb = halo_tile_base<NF>(a.in_act, pln, idn.ty, idn.tx);
+        // look-ahead tile it+LA: its DMA pieces are issued between this tile's MFMAs into the ring
+        // slot that compute(it-1) released at the last barrier.  Past the end the last tile is
+        // re-fetched so that the k-loop stays one straight-line block.
+        const int fill = cur + LA >= NBUF ? cur + LA - NBUF : cur + LA;
+        ids[LA] = pt.decode(t_first + min(it + LA, niter - 1) * g8, lane);
+        const PlaneDesc& pln = planes_lds[ids[LA].plane];
+        const char* next_tb = halo_tile_base<NF>(a.in_act, pln, ids[LA].ty, ids[LA].tx);
         const int next_pitch = __builtin_amdgcn_readfirstlane(pln.pitch) * G::PIXB;
-        const unsigned next_lds = lds0 + ((it + 1) & 1) * G::BUFB;
+        const unsigned next_lds = lds0 + fill * G::BUFB;
 
         // B-operand base: pixel (row 2*wave+n, col px) of the halo tile at tap (0,0)
         const char* bbase[2];
@@ -354,7 +444,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a)
         for (int n = 0; n < 2; ++n)
             bbase[n] = buf + ((2 * wave + n) * PW + px) * G::LPIXB + (NF == 64 ? half * 16 : 0);
 
-        auto read_b = [&](int ks, int n) -> half8 {
+        auto read_b = [&](int ks, int n) __attribute__((always_inline)) -> half8 {
             if constexpr (NF == 64) {
                 // k-step ks: tap ks/4, channel octets 2*(ks%4) + half
                 const int tap = ks >> 2;
@@ -385,8 +475,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a)
 #pragma unroll
                 for (int n = 0; n < 2; ++n) bq[(ks + PF) % (PF + 1)][n] = read_b(ks + PF, n);
             }
-            if ((ks & 1) == 0 && ks / 2 < CPW)
-                issue_dma_piece<NF>(next_tb, next_pitch, next_lds, ks / 2, wave, dma_pc[ks / 2]);
+            if (ks < CPW) issue_dma_piece<NF>(next_tb, next_pitch, next_lds, ks, wave, dma_pc[ks]);
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -403,14 +492,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a)
             if (ks + PF < KS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         }
 
-        // every wave is done reading buf[it&1] and this wave's share of DMA(it+1) has landed
-        tile_barrier();
+        // every wave is done reading ring slot 'cur', and this wave's share of tile it+1 has landed:
+        // only the CPW pieces of each later look-ahead tile may still be in flight
+        if (stamp) a.dbg[8 * it + 1] = __builtin_amdgcn_s_memtime();
+        tile_barrier<(LA - 1) * CPW>();
+        if (stamp) a.dbg[8 * it + 2] = __builtin_amdgcn_s_memtime();
 
         if constexpr (MODE == 0) {
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-                store_trunk<NF, MF>(acc[n], slope_lds, a.out_act, pl, id.ty * TH + 2 * wave + n,
-                                    id.tx * TW + px, half);
+            // staging area: this wave's own DMA region of the ring slot that was just consumed (only
+            // this wave's later LDS-DMA ever writes it, and that is issued after these reads)
+            static_assert(StageGeo<NF>::BYTES <= CPW * 1024, "staging must fit the wave's DMA region");
+            store_trunk_rows<NF, MF>(acc, slope_lds, smem + cur * G::BUFB + wave * (CPW * 1024), a.out_act, pl,
+                                     id.ty * TH + 2 * wave, id.tx * TW, opaque(lane),
+                                     stamp ? a.dbg + 8 * it + 4 : nullptr);
         } else {
             const float norm = (float)(1 / 255.0);   // substract_mean_normalize norm_vals (:272, :444)
             uint8_t* stage = stage_all + wave * STAGEB;
@@ -439,7 +533,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a)
                                                       (size_t)(pl.src_x0 + xc) * 3 + ch] * norm;
                             else
                                 res = a.src_f32[((size_t)ch * pl.h + yc) * pl.w + xc];
-                            const float v = acc[n][m][4 * g + j] + res;
+                            const float v = (acc[n][m][4 * g + j] + bias_lds[co]) + res;
                             if constexpr (MODE == 1) {
                                 float q = __builtin_rintf(v * 255.0f);      // v_rndne_f32: ties to even
                                 q = fminf(fmaxf(q, 0.f), 255.f);
@@ -482,8 +576,334 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a)
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        id = idn;
+        if (stamp) a.dbg[8 * it + 3] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+        for (int j = 0; j < LA; ++j) ids[j] = ids[j + 1];
+        cur = cur + 1 == NBUF ? 0 : cur + 1;
     }
+    // LDS-DMA of the re-fetched look-ahead tiles must not outlive the workgroup's LDS allocation
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ----------------------------------------------------------------------------------------------
+// trunk_kernel<NF> (NF = 64): the dominant kernel -- one trunk layer 64 -> 64 (+bias, PReLU), fp16
+// NHWC in and out.
+//
+// One persistent 8-wave workgroup per CU = two waves per SIMD, run as two 4-wave GROUPS in
+// ping-pong: while group A is in its k-loop (MFMA-bound, the matrix pipe to itself), group B runs
+// the epilogue of its previous tile (PReLU, fp16 conversion, stores), waits for its LDS-DMA and
+// issues nothing that needs the matrix pipe; at the next workgroup barrier the roles swap.  The
+// barriers keep the two groups exactly half a period apart -- left to themselves (two independent
+// workgroups per CU) they phase-lock into computing together and idling together.
+//
+// To fit two waves per SIMD a wave owns 32 of the 64 output channels (144 weight registers instead
+// of 288) and 2 rows x 32 pixels of its group's 4-row x 32-column work tile:
+//     wave-in-group = 2*rp + mh :  rows 2*rp, 2*rp+1,  output channels 32*mh .. 32*mh+31.
+// A B fragment (32 pixels x 16 channels of one tap) read from LDS therefore feeds one MFMA per
+// wave and is read by both mh waves: LDS read traffic is ~50 % of LDS bandwidth during a k-loop,
+// the price of the register room.  Otherwise conv3x3_kernel's design: weights stationary in
+// registers, halo tiles streamed by LDS-DMA into a 2-slot ring per group, zero-bordered planes.
+// ----------------------------------------------------------------------------------------------
+constexpr int TH4 = 4;
+
+// LDS ring of the trunk kernel: 5 slots shared by the two groups.  Work tiles are consumed in the
+// order k = 0, 1, 2, ... = g0's 1st, g1's 1st, g0's 2nd, g1's 2nd, ... (one k-loop phase each); tile
+// k lives in slot k % 5.  During the k-loop of tile k the computing group streams in tile k+3 (the
+// OTHER group's next-but-one k-loop) and proves it landed at the end of its own next k-loop, two
+// phases later -- HBM latency under load is several microseconds here, a one-phase look-ahead left
+// the DMA ~1000 cycles short.  Slot k % 5 is refilled (with tile k+5) during k-loop k+2, i.e. by the
+// same group and after its epilogue of tile k, so that epilogue may use the slot as staging space.
+constexpr int TRUNK_SLOTS = 5;
+constexpr int TRUNK_LOOKAHEAD = 3;
+template <int NF>
+struct TrunkGeo {
+    using G = Geo<NF, TH4>;
+    static constexpr int PIECES = (G::NSLOT + 63) / 64;      // 29 one-KiB DMA pieces per halo tile
+    static constexpr int SLOTB = PIECES * 1024;
+    static constexpr int CPW = (PIECES + 3) / 4;             // per wave (the last ones may repeat a piece)
+    static constexpr int STAGE_PX = 80;                      // staging bytes per pixel: 32 ch fp16 + pad
+    static constexpr int STAGE_WAVE = 64 * STAGE_PX;         // 2 rows x 32 pixels per wave
+};
+static_assert(4 * TrunkGeo<64>::STAGE_WAVE <= TrunkGeo<64>::SLOTB, "epilogue staging must fit a ring slot");
+template <int NF>
+constexpr int trunk_lds_bytes() { return TRUNK_SLOTS * TrunkGeo<NF>::SLOTB + PARAMS_AND_PLANES_LDS; }
+
+// piece i of wave 'wave': c = 4*i + wave, or a repeat of the wave's previous piece past the end
+template <int NF>
+__device__ __forceinline__ int trunk_piece_index(int i, int wave)
+{
+    const int c = 4 * i + wave;
+    return c < TrunkGeo<NF>::PIECES ? c : c - 4;
+}
+template <int NF>
+__device__ __forceinline__ int trunk_piece_const(int i, int wave, int lane)
+{
+    using G = Geo<NF, TH4>;
+    const int q = trunk_piece_index<NF>(i, wave) * 64 + lane;
+    int p = q / G::LSPP;
+    int s = q - p * G::LSPP;
+    if (s >= G::SPP) s = G::SPP - 1;          // pad slot: re-fetch the neighbouring octet
+    if (p >= G::NPIXT) p = G::NPIXT - 1;      // tail of the last piece: any valid address
+    const int r = p / PW;
+    const int cc = p - r * PW;
+    return (r << 16) | (cc * G::PIXB + s * 16);
+}
+template <int NF>
+__device__ __forceinline__ void trunk_issue_piece(const char* tile_base, int pitch_bytes, unsigned lds_slot, int i,
+                                                  int wave, int pc)
+{
+    const unsigned off = (unsigned)(pc >> 16) * (unsigned)pitch_bytes + (unsigned)(pc & 0xffff);
+    glds16(tile_base + off, lds_slot + trunk_piece_index<NF>(i, wave) * 1024);
+}
+
+__device__ __forceinline__ void group_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// ABL (debug ablations, never used by the product path): 0 = the real kernel; 1 = no MFMAs and no
+// LDS reads (memory traffic only); 2 = every tile re-fetches tile 0 and stores to the sink (compute
+// only, memory traffic stays in L2)
+template <int NF, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
+{
+    static_assert(NF == 64, "the split-channel trunk kernel is written for 64 features");
+    using G = Geo<NF, TH4>;
+    using TG = TrunkGeo<NF>;
+    constexpr int KS = G::KS;
+    constexpr int CPW = TG::CPW;
+    constexpr int SLOTB = TG::SLOTB;
+    constexpr int PF = 6;   // B fragments are read PF steps ahead of their MFMAs
+    static_assert(CPW <= KS, "one DMA piece per k-step must fit in the k-loop");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = lds_offset(smem);
+    float* bias_lds = (float*)(smem + TRUNK_SLOTS * SLOTB);
+    float* prm_lds = bias_lds + 64;                  // slopes [0,64), med3 selectors [64,128)
+    PlaneDesc* planes_lds = (PlaneDesc*)(smem + TRUNK_SLOTS * SLOTB + PARAM_LDS);
+    int* tile_begin_lds = (int*)(smem + TRUNK_SLOTS * SLOTB + PARAM_LDS + MAX_PLANES * 64);
+
+    const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave8 >> 2;   // ping-pong group
+    const int wave = wave8 & 3;   // wave within the group
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5;
+    const int px = lane & 31;
+    const int mh = wave & 1;      // which 32 output channels
+    const int rp = wave >> 1;     // which row pair of the 4-row tile
+
+    // persistent schedule, XCD-contiguous (see conv3x3_kernel).  Sequence number k of this
+    // workgroup is work tile t0 + (k & 1) + (k >> 1) * g8: the two groups take neighbouring tiles.
+    const int g8 = 2 * (gridDim.x >> 3);
+    const int xcd = blockIdx.x & 7;
+    const int slot = blockIdx.x >> 3;
+    const int t_lim = min((xcd + 1) * a.tiles_per_xcd, a.ntiles);
+    const int t0 = xcd * a.tiles_per_xcd + 2 * slot;
+    if (t0 >= t_lim) return;
+    const int niter0 = (t_lim - t0 + g8 - 1) / g8;
+    const int niter1 = t0 + 1 < t_lim ? (t_lim - t0 - 1 + g8 - 1) / g8 : 0;
+    const int niter = grp ? niter1 : niter0;
+    auto seq_tile = [&](int k) __attribute__((always_inline)) {   // clamped to a valid tile
+        const int t = t0 + (k & 1) + (k >> 1) * g8;
+        return ABL == 2 ? t0 : (t < t_lim ? t : t0);
+    };
+
+    if (threadIdx.x < 64) {
+        bias_lds[threadIdx.x] = a.bias[threadIdx.x];
+        const float sl = a.slope[threadIdx.x];
+        prm_lds[threadIdx.x] = sl;
+        prm_lds[64 + threadIdx.x] = sl <= 1.f ? __builtin_inff() : -__builtin_inff();
+        tile_begin_lds[threadIdx.x] = threadIdx.x < a.nplanes ? a.planes[threadIdx.x].tile_begin4 : 0x7fffffff;
+    }
+    for (int i = threadIdx.x; i < a.nplanes * 16; i += 512) ((int*)planes_lds)[i] = ((const int*)a.planes)[i];
+
+    // this wave's half of the layer's weights, resident in registers for the whole kernel
+    half8 w[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) w[ks] = a.wpk[(ks * 2 + mh) * 64 + lane];
+
+    int dma_pc[CPW];
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) dma_pc[i] = trunk_piece_const<NF>(i, wave, lane);
+
+    __syncthreads();
+    PlaneTable pt;
+    pt.pl = planes_lds;
+    pt.tile_begin = tile_begin_lds;
+    pt.nplanes = a.nplanes;
+
+    // accumulator chains start from C = 0 (an inline constant, no registers); the bias is added in
+    // the epilogue, which has VALU slots to spare, rather than held in 16 more registers
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+
+    char* const sink = (char*)a.sink + lane * G::PIXB;  // where lanes outside the image store to
+
+    auto issue_tile = [&](int k, int ring_slot) __attribute__((always_inline)) {
+        const TileId idk = pt.decode<true>(seq_tile(k), lane);
+        const PlaneDesc& plk = planes_lds[idk.plane];
+        const char* tb = halo_tile_base<NF, TH4>(a.in_act, plk, idk.ty, idk.tx);
+        const int pitchk = __builtin_amdgcn_readfirstlane(plk.pitch) * G::PIXB;
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) trunk_issue_piece<NF>(tb, pitchk, lds0 + ring_slot * SLOTB, i, wave, dma_pc[i]);
+    };
+    // prologue: tiles 0 and 2 by group 0, tile 1 by group 1
+    issue_tile(grp, grp);
+    if (grp == 0) issue_tile(2, 2);
+    tile_barrier<0>();
+    if (grp == 1) group_barrier();   // group 1 runs half a period behind group 0
+    int cur = grp;                   // ring slot of this group's current tile: (2*it + grp) % 5
+
+    const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+    for (int it = 0; it < niter0; ++it) {
+        const bool active = it < niter;
+        const int k = 2 * it + grp;
+        f32x16 acc[2];
+        int cur_plane = 0, cur_ty = 0, cur_tx = 0;
+        if (stamp) a.dbg[8 * it + 0] = __builtin_amdgcn_s_memtime();
+        {
+            // ---- k-loop phase: this group owns the matrix pipe -------------------------------
+            __builtin_amdgcn_s_setprio(2);
+            const char* buf = smem + cur * SLOTB;
+            // look-ahead: tile k+3 (the other group's) into the slot tile k-2 left two phases ago
+            const TileId idn = pt.decode<true>(seq_tile(k + TRUNK_LOOKAHEAD), lane);
+            const PlaneDesc& pln = planes_lds[idn.plane];
+            const char* next_tb = halo_tile_base<NF, TH4>(a.in_act, pln, idn.ty, idn.tx);
+            const int next_pitch = __builtin_amdgcn_readfirstlane(pln.pitch) * G::PIXB;
+            const int fill = cur + TRUNK_LOOKAHEAD >= TRUNK_SLOTS ? cur + TRUNK_LOOKAHEAD - TRUNK_SLOTS
+                                                                  : cur + TRUNK_LOOKAHEAD;
+            const unsigned next_lds = lds0 + fill * SLOTB;
+
+            // own tile (for the epilogue): decoded here, where the LDS latency hides under the MFMAs
+            const TileId idc = pt.decode<true>(seq_tile(k), lane);
+            cur_plane = idc.plane; cur_ty = idc.ty; cur_tx = idc.tx;
+
+            // B operand: LDS row 2*rp + R (R = 0..3) of the halo tile, column px + dx, channel octets
+            // 2*c + half.  The wave's two output rows overlap in their input rows: halo row R is tap
+            // row dy = R of output row 0 and tap row dy = R-1 of output row 1, so ONE fragment read
+            // feeds both accumulators (with different weights) for R = 1, 2 -- 48 LDS reads per tile
+            // instead of 72.  Steps are ordered so that consecutive MFMAs alternate accumulators:
+            //   s = 0..23 : (R=0, i=s/2) for even s -> acc0 only;  (R=3, i=s/2) for odd s -> acc1 only
+            //   s = 24..35: (R=1, i=s-24) -> both;   s = 36..47: (R=2, i=s-36) -> both
+            // with i = 4*dx + c.
+            const char* bbase = buf + ((2 * rp) * PW + px) * G::LPIXB + half * 16;
+            auto step_R = [](int s2) __attribute__((always_inline)) { return s2 < 24 ? ((s2 & 1) ? 3 : 0) : (s2 < 36 ? 1 : 2); };
+            auto step_i = [](int s2) __attribute__((always_inline)) { return s2 < 24 ? (s2 >> 1) : (s2 < 36 ? s2 - 24 : s2 - 36); };
+            auto read_b = [&](int s2) __attribute__((always_inline)) -> half8 {
+                const int R = step_R(s2), i2 = step_i(s2);
+                return *(const half8*)(bbase + (R * PW + (i2 >> 2)) * G::LPIXB + (i2 & 3) * 32);
+            };
+            constexpr int NSTEP = 48;
+            half8 bq[PF + 1];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s2 = 0; s2 < PF; ++s2)
+                if (ABL != 1) bq[s2] = read_b(s2);
+#pragma unroll
+            for (int s2 = 0; s2 < NSTEP; ++s2) {
+                if (ABL != 1 && s2 + PF < NSTEP) bq[(s2 + PF) % (PF + 1)] = read_b(s2 + PF);
+                if (s2 < CPW) trunk_issue_piece<NF>(next_tb, next_pitch, next_lds, s2, wave, dma_pc[s2]);
+                const int R = step_R(s2), i2 = step_i(s2);
+                const half8 b = bq[s2 % (PF + 1)];
+                if constexpr (ABL == 1) {
+                    if (s2 == 0) { acc[0] = zero16; acc[1] = zero16; }
+                    acc[s2 & 1][s2 & 15] += (float)w[s2 % KS][0];
+                } else {
+                    if (R <= 2)   // output row 0, tap (dy = R, dx)
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[(R * 3 + (i2 >> 2)) * 4 + (i2 & 3)], b,
+                                                                        s2 == 0 ? zero16 : acc[0], 0, 0, 0);
+                    if (R >= 1)   // output row 1, tap (dy = R-1, dx)
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[((R - 1) * 3 + (i2 >> 2)) * 4 + (i2 & 3)], b,
+                                                                        s2 == 1 ? zero16 : acc[1], 0, 0, 0);
+                }
+            }
+            // alone on its SIMD's matrix pipe, the wave must hide LDS latency itself
+            __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+#pragma unroll
+            for (int s2 = 0; s2 < 24; ++s2) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int s2 = 24; s2 < NSTEP; ++s2) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                if (s2 + PF < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+        if (stamp) a.dbg[8 * it + 1] = __builtin_amdgcn_s_memtime();
+        // Roles swap.  Of this wave's VMEM traffic only the CPW pieces just issued (tile k+3) may
+        // still be in flight: loads retire in order, so "at most CPW outstanding" proves that the
+        // pieces of tile k+1 (issued one k-loop of this group ago, read by the other group next)
+        // have landed, whatever older stores are still pending.
+        tile_barrier<CPW>();
+        if (stamp) a.dbg[8 * it + 2] = __builtin_amdgcn_s_memtime();
+        if (active) {
+            // ---- epilogue phase: bias, PReLU (med3 form, see store_trunk_rows), fp16 RNE.  A lane
+            // holds 4 channels of one pixel; stored as is, a wave-store would touch 32 cache lines
+            // with 16 bytes each and the L2 request rate, not HBM, would bound the kernel.  So the
+            // wave transposes its 2 rows x 32 pixels x 32 channels through the ring slot it has
+            // just finished reading and stores 64 contiguous bytes per pixel.
+            TileId id;
+            id.plane = cur_plane; id.ty = cur_ty; id.tx = cur_tx;
+            const PlaneDesc& pl = planes_lds[id.plane];
+            const int lane_o = opaque(lane);
+            char* const stage = smem + cur * SLOTB + wave * TG::STAGE_WAVE;
+            // per-channel parameters of this lane's 16 channels, fetched up front (one LDS latency,
+            // not eight): bias, slope, med3 selector
+            f32x4 b4[4], s4[4], i4[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cl = 32 * mh + 8 * g + 4 * (lane_o >> 5);
+                b4[g] = *(const f32x4*)(bias_lds + cl);
+                s4[g] = *(const f32x4*)(prm_lds + cl);
+                i4[g] = *(const f32x4*)(prm_lds + 64 + cl);
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cl = 8 * g + 4 * (lane_o >> 5);     // channel within this wave's 32
+                    f32x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float xv = acc[n][4 * g + j] + b4[g][j];
+                        v[j] = __builtin_amdgcn_fmed3f(xv, xv * s4[g][j], i4[g][j]);
+                    }
+                    const half2v lo = __builtin_convertvector(f32x2{v[0], v[1]}, half2v);
+                    const half2v hi = __builtin_convertvector(f32x2{v[2], v[3]}, half2v);
+                    uint2 o;
+                    o.x = __builtin_bit_cast(unsigned, lo);
+                    o.y = __builtin_bit_cast(unsigned, hi);
+                    *(uint2*)(stage + (n * 32 + (lane_o & 31)) * TG::STAGE_PX + cl * 2) = o;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (stamp) a.dbg[8 * it + 4] = __builtin_amdgcn_s_memtime();
+            // 256 sixteen-byte chunks: chunk q = pixel q/4 (row q/128, column (q/4)%32), quarter q%4
+            const int y0 = id.ty * TH4 + 2 * rp;
+            char* const obase = (char*)a.out_act +
+                ((size_t)pl.act_off + (size_t)(y0 + 1) * pl.pitch + (id.tx * TW + 1)) * G::PIXB + 64 * mh;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int q = c * 64 + lane_o;
+                const int pix = q >> 2, quarter = q & 3;
+                const int n = pix >> 5, xl = pix & 31;
+                const uint4 val = *(const uint4*)(stage + pix * TG::STAGE_PX + quarter * 16);
+                const bool ok = ABL != 2 && y0 + n < pl.h && id.tx * TW + xl < pl.w;
+                char* dst = ok ? obase + ((size_t)n * pl.pitch + xl) * G::PIXB + quarter * 16 : sink;
+                *(uint4*)dst = val;
+            }
+        }
+        if (stamp) a.dbg[8 * it + 3] = __builtin_amdgcn_s_memtime();
+        group_barrier();
+        cur = cur + 2 >= TRUNK_SLOTS ? cur + 2 - TRUNK_SLOTS : cur + 2;
+    }
+    if (grp == 0) group_barrier();
+    // nothing of the re-fetched look-ahead tiles may land after the workgroup's LDS is released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -497,7 +917,7 @@ template <int NF, int SRC>
 __global__ __launch_bounds__(256) void head_kernel(HeadArgs a)
 {
     constexpr int MF = (NF + 31) / 32;
-    __shared__ __attribute__((aligned(16))) char hsm[NPIX * 8 + PARAM_LDS];
+    __shared__ __attribute__((aligned(16))) char hsm[NPIX * 8 + PARAM_LDS + 4 * StageGeo<NF>::BYTES];
     half4* tile = (half4*)hsm;
     float* bias_lds = (float*)(hsm + NPIX * 8);
     float* slope_lds = bias_lds + 64;
@@ -546,13 +966,13 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a)
         for (int m = 0; m < MF; ++m) w[ks][m] = a.wpk[(ks * MF + m) * 64 + lane];
     __syncthreads();
 
+    f32x16 acc[2][MF];
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
-        f32x16 acc[MF];
 #pragma unroll
         for (int m = 0; m < MF; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[n][m][r] = 0.f;
         const int pb = (2 * wave + n) * PW + px;
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
@@ -568,7 +988,7 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a)
             b[4] = hi[0]; b[5] = hi[1]; b[6] = hi[2]; b[7] = hi[3];
 #pragma unroll
             for (int m = 0; m < MF; ++m)
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks][m], b, acc[m], 0, 0, 0);
+                acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks][m], b, acc[n][m], 0, 0, 0);
         }
 #pragma unroll
         for (int m = 0; m < MF; ++m)
@@ -576,10 +996,11 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a)
             for (int g = 0; g < 4; ++g) {
                 const f32x4 b4 = *(const f32x4*)(bias_lds + 32 * m + 8 * g + 4 * half);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[m][4 * g + j] = acc[m][4 * g + j] * a.in_scale + b4[j];
+                for (int j = 0; j < 4; ++j) acc[n][m][4 * g + j] = acc[n][m][4 * g + j] * a.in_scale + b4[j];
             }
-        store_trunk<NF, MF>(acc, slope_lds, a.out_act, pl, id.ty * TH + 2 * wave + n, id.tx * TW + px, half);
     }
+    store_trunk_rows<NF, MF>(acc, slope_lds, hsm + NPIX * 8 + PARAM_LDS + wave * StageGeo<NF>::BYTES, a.out_act, pl,
+                             id.ty * TH + 2 * wave, id.tx * TW, lane);
 }
 
 }  // namespace uva
