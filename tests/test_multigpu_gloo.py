@@ -1,0 +1,87 @@
+"""N > 1 path of bench.py on CPU: two gloo ranks shard frames as independent units (no data-path
+collective), and the timing protocol (barrier + sync both sides, MAX over ranks) aggregates to a
+whole-job rate.  The per-frame work here is the CPU oracle on tiny frames (test infrastructure);
+on the GPU box the same protocol wraps uva_net_process_u8_device."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n_frames, q):
+    sys.path.insert(0, ROOT)
+    import time
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from oracle import uvoracle
+    m = uvoracle.load_model("1x")
+    mine = bench.shard_frames(n_frames, rank, world)
+    outs = {}
+
+    def run():
+        for f in mine:
+            outs[f] = m.apply_model(uvoracle.synthetic_frame(16, 24, seed=f), threads=1)
+        if rank == 1:
+            time.sleep(0.2)          # the slow rank must set the job time
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    elapsed = bench.timed_region(run, lambda: None, dist.barrier, max_over_ranks)
+    checksum = float(sum(int(v.astype(np.int64).sum()) for v in outs.values()))
+    t = torch.tensor([checksum, float(len(mine))], dtype=torch.float64)
+    dist.all_reduce(t)               # test bookkeeping only, not part of the data path
+    q.put((rank, mine, elapsed, float(t[0]), int(t[1])))
+    dist.destroy_process_group()
+
+
+def test_frame_sharding_two_ranks_gloo():
+    import torch.multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    from oracle import uvoracle
+    uvoracle.build()
+    n_frames, world, port = 7, 2, 29517 + os.getpid() % 1000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, f0, e0, c0, n0), (r1, f1, e1, c1, n1) = res
+    assert f0 == [0, 2, 4, 6] and f1 == [1, 3, 5]           # disjoint, complete, no exchange
+    assert n0 == n1 == n_frames
+    assert e0 == e1 and e0 >= 0.2                          # MAX over ranks: the slow rank decides
+    m = uvoracle.load_model("1x")
+    want = float(sum(int(m.apply_model(uvoracle.synthetic_frame(16, 24, seed=f), threads=1).astype(np.int64).sum())
+                     for f in range(n_frames)))
+    assert c0 == c1 == want                                # every frame processed exactly once
+
+
+def test_shard_frames_properties():
+    sys.path.insert(0, ROOT)
+    import bench
+    for n in (0, 1, 5, 64):
+        for world in (1, 2, 4, 8):
+            parts = [bench.shard_frames(n, r, world) for r in range(world)]
+            flat = sorted(f for p in parts for f in p)
+            assert flat == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_conv_flops_match_baseline_table():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.conv_flops_per_px(64, 18, 2) == 1196928
+    assert bench.conv_flops_per_px(64, 18, 4) == 1238400
+    assert bench.conv_flops_per_px(24, 10, 1) == 85536
