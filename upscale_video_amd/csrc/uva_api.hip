@@ -216,9 +216,16 @@ int launch_conv(uva_net* n, int mode, const ConvArgs& a)
 int launch_trunk(uva_net* n, const Workspace* ws, ConvArgs ca, int ablate = 0)
 {
     if (n->g.nf == 64) {
-        ca.ntiles = ws->ntiles4;
-        ca.tiles_per_xcd = (ws->ntiles4 + 7) / 8;
-        return launch_trunk64(n, ca, ablate);
+        // a workgroup's tile schedule must fit its LDS table: split very large frames into launches
+        const int grid = std::max(8, (n->ncu / 8) * 8);
+        const int per_launch = 8 * (2 * (grid / 8)) * ((TRUNK_SCHED_MAX - TRUNK_LOOKAHEAD) / 2 - 1);
+        for (int base = 0; base < ws->ntiles4; base += per_launch) {
+            ca.tile_base = base;
+            ca.ntiles = std::min(per_launch, ws->ntiles4 - base);
+            ca.tiles_per_xcd = (ca.ntiles + 7) / 8;
+            if (launch_trunk64(n, ca, ablate)) return 1;
+        }
+        return 0;
     }
     ca.ntiles = ws->ntiles;
     ca.tiles_per_xcd = (ws->ntiles + 7) / 8;

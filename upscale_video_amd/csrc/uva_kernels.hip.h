@@ -109,6 +109,8 @@ struct ConvArgs {
     float* dst_f32;               // planar [3][h*R][w*R]
     unsigned long long* dbg;      // optional: per-tile s_memtime stamps of block 0 / wave 0 (debug)
     _Float16* sink;               // >= 64 pixels of scratch: where lanes outside the image store to
+    int tile_base;                // trunk_kernel: first global work tile of this launch (huge frames
+                                  // are split so that a workgroup's schedule fits its LDS table)
 };
 
 struct HeadArgs {
@@ -128,6 +130,15 @@ struct HeadArgs {
 __device__ __forceinline__ unsigned lds_offset(const void* p)
 {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+
+// A wave-uniform pointer that lives in VGPRs (e.g. computed from LDS reads), moved to SGPRs.
+__device__ __forceinline__ const char* uniform_ptr(const char* p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const char*)(((unsigned long long)hi << 32) | lo);
 }
 
 // An opaque copy of a lane-constant value: stops hipcc from hoisting everything derived from it out
@@ -154,6 +165,21 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst)
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(gsrc), "s"(lds_dst));
+}
+
+// Same, with the tile's base address in SGPRs and a 32-bit per-lane byte offset (the "saddr" form):
+// no 64-bit vector address arithmetic per piece.
+__device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_dst));
 }
 
 // End of a tile's k-loop: wait until all but the newest KEEP vector-memory operations of this
@@ -613,6 +639,7 @@ constexpr int TH4 = 4;
 // phases later -- HBM latency under load is several microseconds here, a one-phase look-ahead left
 // the DMA ~1000 cycles short.  Slot k % 5 is refilled (with tile k+5) during k-loop k+2, i.e. by the
 // same group and after its epilogue of tile k, so that epilogue may use the slot as staging space.
+constexpr int TRUNK_SCHED_MAX = 576;   // schedule entries (16 B each) a workgroup can hold
 constexpr int TRUNK_SLOTS = 5;
 constexpr int TRUNK_LOOKAHEAD = 3;
 template <int NF>
@@ -626,7 +653,8 @@ struct TrunkGeo {
 };
 static_assert(4 * TrunkGeo<64>::STAGE_WAVE <= TrunkGeo<64>::SLOTB, "epilogue staging must fit a ring slot");
 template <int NF>
-constexpr int trunk_lds_bytes() { return TRUNK_SLOTS * TrunkGeo<NF>::SLOTB + PARAMS_AND_PLANES_LDS; }
+constexpr int trunk_lds_bytes() { return TRUNK_SLOTS * TrunkGeo<NF>::SLOTB + PARAMS_AND_PLANES_LDS + TRUNK_SCHED_MAX * 16; }
+static_assert(trunk_lds_bytes<64>() <= 160 * 1024, "trunk kernel LDS budget");
 
 // piece i of wave 'wave': c = 4*i + wave, or a repeat of the wave's previous piece past the end
 template <int NF>
@@ -653,7 +681,7 @@ __device__ __forceinline__ void trunk_issue_piece(const char* tile_base, int pit
                                                   int wave, int pc)
 {
     const unsigned off = (unsigned)(pc >> 16) * (unsigned)pitch_bytes + (unsigned)(pc & 0xffff);
-    glds16(tile_base + off, lds_slot + trunk_piece_index<NF>(i, wave) * 1024);
+    glds16_s(tile_base, off, lds_slot + trunk_piece_index<NF>(i, wave) * 1024);
 }
 
 __device__ __forceinline__ void group_barrier()
@@ -673,15 +701,17 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
     constexpr int KS = G::KS;
     constexpr int CPW = TG::CPW;
     constexpr int SLOTB = TG::SLOTB;
-    constexpr int PF = 6;   // B fragments are read PF steps ahead of their MFMAs
-    static_assert(CPW <= KS, "one DMA piece per k-step must fit in the k-loop");
+    constexpr int PF = 6;      // B fragments are read PF steps ahead of their MFMAs
+    constexpr int CPW_K = 4;   // DMA pieces of the look-ahead tile issued inside the k-loop (each blocks
+                               // the wave's MFMA issue for ~60-150 cycles); the other CPW - CPW_K are
+                               // issued by the same wave at the start of its (shorter) epilogue phase
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = lds_offset(smem);
     float* bias_lds = (float*)(smem + TRUNK_SLOTS * SLOTB);
     float* prm_lds = bias_lds + 64;                  // slopes [0,64), med3 selectors [64,128)
     PlaneDesc* planes_lds = (PlaneDesc*)(smem + TRUNK_SLOTS * SLOTB + PARAM_LDS);
-    int* tile_begin_lds = (int*)(smem + TRUNK_SLOTS * SLOTB + PARAM_LDS + MAX_PLANES * 64);
+    uint4* sched_lds = (uint4*)(smem + TRUNK_SLOTS * SLOTB + PARAMS_AND_PLANES_LDS);
 
     const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int grp = wave8 >> 2;   // ping-pong group
@@ -703,17 +733,12 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
     const int niter0 = (t_lim - t0 + g8 - 1) / g8;
     const int niter1 = t0 + 1 < t_lim ? (t_lim - t0 - 1 + g8 - 1) / g8 : 0;
     const int niter = grp ? niter1 : niter0;
-    auto seq_tile = [&](int k) __attribute__((always_inline)) {   // clamped to a valid tile
-        const int t = t0 + (k & 1) + (k >> 1) * g8;
-        return ABL == 2 ? t0 : (t < t_lim ? t : t0);
-    };
 
     if (threadIdx.x < 64) {
         bias_lds[threadIdx.x] = a.bias[threadIdx.x];
         const float sl = a.slope[threadIdx.x];
         prm_lds[threadIdx.x] = sl;
         prm_lds[64 + threadIdx.x] = sl <= 1.f ? __builtin_inff() : -__builtin_inff();
-        tile_begin_lds[threadIdx.x] = threadIdx.x < a.nplanes ? a.planes[threadIdx.x].tile_begin4 : 0x7fffffff;
     }
     for (int i = threadIdx.x; i < a.nplanes * 16; i += 512) ((int*)planes_lds)[i] = ((const int*)a.planes)[i];
 
@@ -727,10 +752,29 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
     for (int i = 0; i < CPW; ++i) dma_pc[i] = trunk_piece_const<NF>(i, wave, lane);
 
     __syncthreads();
-    PlaneTable pt;
-    pt.pl = planes_lds;
-    pt.tile_begin = tile_begin_lds;
-    pt.nplanes = a.nplanes;
+    // Tile schedule of this workgroup, built once: entry k = {byte offset of the tile's halo origin
+    // inside the activation buffers (lo, hi), row pitch in bytes, (valid rows << 8) | valid columns}.
+    // The per-tile work then needs one uniform 16-byte LDS read instead of a plane search, and none
+    // of it sits in front of the k-loop.
+    const int nsched = 2 * niter0 + TRUNK_LOOKAHEAD;
+    for (int k = threadIdx.x; k < nsched; k += 512) {
+        int t = t0 + (k & 1) + (k >> 1) * g8;
+        const bool real = t < t_lim;
+        if (!real || ABL == 2) t = t0;                       // past the end: a harmless re-fetch
+        t += a.tile_base;
+        int p = 0;
+        for (int q = 1; q < a.nplanes; ++q)
+            if (t >= planes_lds[q].tile_begin4) p = q;
+        const PlaneDesc& pl = planes_lds[p];
+        const int local = t - pl.tile_begin4;
+        const int ty = local / pl.ntx, tx = local - (local / pl.ntx) * pl.ntx;
+        const unsigned long long off =
+            ((unsigned long long)pl.act_off + (unsigned long long)(ty * TH4) * pl.pitch + (unsigned long long)tx * TW) * G::PIXB;
+        const int vy = real ? min(TH4, pl.h - ty * TH4) : 0;
+        const int vx = real ? min(TW, pl.w - tx * TW) : 0;
+        sched_lds[k] = make_uint4((unsigned)off, (unsigned)(off >> 32), (unsigned)(pl.pitch * G::PIXB), (unsigned)((vy << 8) | vx));
+    }
+    __syncthreads();
 
     // accumulator chains start from C = 0 (an inline constant, no registers); the bias is added in
     // the epilogue, which has VALU slots to spare, rather than held in 16 more registers
@@ -740,50 +784,53 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
 
     char* const sink = (char*)a.sink + lane * G::PIXB;  // where lanes outside the image store to
 
-    auto issue_tile = [&](int k, int ring_slot) __attribute__((always_inline)) {
-        const TileId idk = pt.decode<true>(seq_tile(k), lane);
-        const PlaneDesc& plk = planes_lds[idk.plane];
-        const char* tb = halo_tile_base<NF, TH4>(a.in_act, plk, idk.ty, idk.tx);
-        const int pitchk = __builtin_amdgcn_readfirstlane(plk.pitch) * G::PIXB;
-#pragma unroll
-        for (int i = 0; i < CPW; ++i) trunk_issue_piece<NF>(tb, pitchk, lds0 + ring_slot * SLOTB, i, wave, dma_pc[i]);
+    struct Sched { const char* base; unsigned long long off; int pitch; int vy, vx; };
+    auto read_sched = [&](int k) __attribute__((always_inline)) {
+        const uint4 e = sched_lds[k];
+        Sched r;
+        const unsigned lo = __builtin_amdgcn_readfirstlane(e.x), hi = __builtin_amdgcn_readfirstlane(e.y);
+        r.off = ((unsigned long long)hi << 32) | lo;
+        r.base = (const char*)a.in_act + r.off;
+        r.pitch = __builtin_amdgcn_readfirstlane(e.z);
+        const int v = __builtin_amdgcn_readfirstlane(e.w);
+        r.vy = v >> 8; r.vx = v & 255;
+        return r;
     };
-    // prologue: tiles 0 and 2 by group 0, tile 1 by group 1
-    issue_tile(grp, grp);
-    if (grp == 0) issue_tile(2, 2);
+    // prologue: tiles 0 and 2 by group 0, tile 1 by group 1 (all pieces)
+    {
+        const Sched s0 = read_sched(grp);
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) trunk_issue_piece<NF>(s0.base, s0.pitch, lds0 + grp * SLOTB, i, wave, dma_pc[i]);
+        if (grp == 0) {
+            const Sched s2 = read_sched(2);
+#pragma unroll
+            for (int i = 0; i < CPW; ++i) trunk_issue_piece<NF>(s2.base, s2.pitch, lds0 + 2 * SLOTB, i, wave, dma_pc[i]);
+        }
+    }
     tile_barrier<0>();
     if (grp == 1) group_barrier();   // group 1 runs half a period behind group 0
     int cur = grp;                   // ring slot of this group's current tile: (2*it + grp) % 5
+    Sched la = read_sched(grp + TRUNK_LOOKAHEAD);   // look-ahead tile of the first k-loop
 
     const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
     for (int it = 0; it < niter0; ++it) {
         const bool active = it < niter;
         const int k = 2 * it + grp;
         f32x16 acc[2];
-        int cur_plane = 0, cur_ty = 0, cur_tx = 0;
+        const int fill = cur + TRUNK_LOOKAHEAD >= TRUNK_SLOTS ? cur + TRUNK_LOOKAHEAD - TRUNK_SLOTS : cur + TRUNK_LOOKAHEAD;
+        const unsigned la_lds = lds0 + fill * SLOTB;   // look-ahead tile k+3 -> the slot tile k-2 left
         if (stamp) a.dbg[8 * it + 0] = __builtin_amdgcn_s_memtime();
         {
-            // ---- k-loop phase: this group owns the matrix pipe -------------------------------
+            // ---- k-loop phase: this group owns the matrix pipe; nothing but MFMAs, their LDS reads
+            // and CPW_K DMA pieces is issued here ------------------------------------------------
             __builtin_amdgcn_s_setprio(2);
             const char* buf = smem + cur * SLOTB;
-            // look-ahead: tile k+3 (the other group's) into the slot tile k-2 left two phases ago
-            const TileId idn = pt.decode<true>(seq_tile(k + TRUNK_LOOKAHEAD), lane);
-            const PlaneDesc& pln = planes_lds[idn.plane];
-            const char* next_tb = halo_tile_base<NF, TH4>(a.in_act, pln, idn.ty, idn.tx);
-            const int next_pitch = __builtin_amdgcn_readfirstlane(pln.pitch) * G::PIXB;
-            const int fill = cur + TRUNK_LOOKAHEAD >= TRUNK_SLOTS ? cur + TRUNK_LOOKAHEAD - TRUNK_SLOTS
-                                                                  : cur + TRUNK_LOOKAHEAD;
-            const unsigned next_lds = lds0 + fill * SLOTB;
-
-            // own tile (for the epilogue): decoded here, where the LDS latency hides under the MFMAs
-            const TileId idc = pt.decode<true>(seq_tile(k), lane);
-            cur_plane = idc.plane; cur_ty = idc.ty; cur_tx = idc.tx;
 
             // B operand: LDS row 2*rp + R (R = 0..3) of the halo tile, column px + dx, channel octets
             // 2*c + half.  The wave's two output rows overlap in their input rows: halo row R is tap
             // row dy = R of output row 0 and tap row dy = R-1 of output row 1, so ONE fragment read
             // feeds both accumulators (with different weights) for R = 1, 2 -- 48 LDS reads per tile
-            // instead of 72.  Steps are ordered so that consecutive MFMAs alternate accumulators:
+            // instead of 72.  Steps:
             //   s = 0..23 : (R=0, i=s/2) for even s -> acc0 only;  (R=3, i=s/2) for odd s -> acc1 only
             //   s = 24..35: (R=1, i=s-24) -> both;   s = 36..47: (R=2, i=s-36) -> both
             // with i = 4*dx + c.
@@ -803,7 +850,11 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
 #pragma unroll
             for (int s2 = 0; s2 < NSTEP; ++s2) {
                 if (ABL != 1 && s2 + PF < NSTEP) bq[(s2 + PF) % (PF + 1)] = read_b(s2 + PF);
-                if (s2 < CPW) trunk_issue_piece<NF>(next_tb, next_pitch, next_lds, s2, wave, dma_pc[s2]);
+                if constexpr (CPW_K > 0) {
+                    constexpr int EVERY = NSTEP / (CPW_K > 0 ? CPW_K : 1);
+                    if (s2 % EVERY == EVERY / 2 && s2 / EVERY < CPW_K)
+                        trunk_issue_piece<NF>(la.base, la.pitch, la_lds, s2 / EVERY, wave, dma_pc[s2 / EVERY]);
+                }
                 const int R = step_R(s2), i2 = step_i(s2);
                 const half8 b = bq[s2 % (PF + 1)];
                 if constexpr (ABL == 1) {
@@ -833,21 +884,24 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
             __builtin_amdgcn_s_setprio(0);
         }
         if (stamp) a.dbg[8 * it + 1] = __builtin_amdgcn_s_memtime();
-        // Roles swap.  Of this wave's VMEM traffic only the CPW pieces just issued (tile k+3) may
-        // still be in flight: loads retire in order, so "at most CPW outstanding" proves that the
-        // pieces of tile k+1 (issued one k-loop of this group ago, read by the other group next)
-        // have landed, whatever older stores are still pending.
-        tile_barrier<CPW>();
+        // Roles swap.  Of this wave's VMEM loads only the CPW_K pieces just issued (tile k+3) may
+        // still be in flight: loads retire in order, so "at most CPW_K outstanding" proves that all
+        // pieces of tile k+1 (issued one k-loop and one epilogue of this group ago, read by the other
+        // group next) have landed, whatever older stores are still pending.
+        tile_barrier<CPW_K>();
         if (stamp) a.dbg[8 * it + 2] = __builtin_amdgcn_s_memtime();
+        // ---- epilogue phase ---------------------------------------------------------------------
+        // the rest of the look-ahead tile's pieces, ahead of this phase's stores in the queue
+#pragma unroll
+        for (int i = CPW_K; i < CPW; ++i) trunk_issue_piece<NF>(la.base, la.pitch, la_lds, i, wave, dma_pc[i]);
+        const Sched own = read_sched(k);
+        la = read_sched(min(k + 2 + TRUNK_LOOKAHEAD, nsched - 1));   // for this group's next k-loop
         if (active) {
-            // ---- epilogue phase: bias, PReLU (med3 form, see store_trunk_rows), fp16 RNE.  A lane
-            // holds 4 channels of one pixel; stored as is, a wave-store would touch 32 cache lines
-            // with 16 bytes each and the L2 request rate, not HBM, would bound the kernel.  So the
-            // wave transposes its 2 rows x 32 pixels x 32 channels through the ring slot it has
-            // just finished reading and stores 64 contiguous bytes per pixel.
-            TileId id;
-            id.plane = cur_plane; id.ty = cur_ty; id.tx = cur_tx;
-            const PlaneDesc& pl = planes_lds[id.plane];
+            // bias, PReLU (med3 form, see store_trunk_rows), fp16 RNE.  A lane holds 4 channels of one
+            // pixel; stored as is, a wave-store would touch 32 cache lines with 16 bytes each and the
+            // L2 request rate, not HBM, would bound the kernel.  So the wave transposes its 2 rows x
+            // 32 pixels x 32 channels through the ring slot it has just finished reading and stores
+            // 64 contiguous bytes per pixel.
             const int lane_o = opaque(lane);
             char* const stage = smem + cur * SLOTB + wave * TG::STAGE_WAVE;
             // per-channel parameters of this lane's 16 channels, fetched up front (one LDS latency,
@@ -882,18 +936,18 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (stamp) a.dbg[8 * it + 4] = __builtin_amdgcn_s_memtime();
-            // 256 sixteen-byte chunks: chunk q = pixel q/4 (row q/128, column (q/4)%32), quarter q%4
-            const int y0 = id.ty * TH4 + 2 * rp;
-            char* const obase = (char*)a.out_act +
-                ((size_t)pl.act_off + (size_t)(y0 + 1) * pl.pitch + (id.tx * TW + 1)) * G::PIXB + 64 * mh;
+            // 256 sixteen-byte chunks: chunk q = pixel q/4 (row q/128, column (q/4)%32), quarter q%4.
+            // Output pixel (row 2*rp + n, column xl) of the tile sits one row and one column inside
+            // the halo origin.
+            char* const obase = (char*)a.out_act + own.off + ((size_t)(2 * rp + 1) * own.pitch + G::PIXB) + 64 * mh;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int q = c * 64 + lane_o;
                 const int pix = q >> 2, quarter = q & 3;
                 const int n = pix >> 5, xl = pix & 31;
                 const uint4 val = *(const uint4*)(stage + pix * TG::STAGE_PX + quarter * 16);
-                const bool ok = ABL != 2 && y0 + n < pl.h && id.tx * TW + xl < pl.w;
-                char* dst = ok ? obase + ((size_t)n * pl.pitch + xl) * G::PIXB + quarter * 16 : sink;
+                const bool ok = ABL != 2 && 2 * rp + n < own.vy && xl < own.vx;
+                char* dst = ok ? obase + ((size_t)n * own.pitch + xl * G::PIXB) + quarter * 16 : sink;
                 *(uint4*)dst = val;
             }
         }
