@@ -86,6 +86,20 @@ def cpu_baseline(model_key, h, w, tile, min_seconds=10.0):
     }
 
 
+def pmc_traffic(args, nf):
+    """HBM bytes per trunk launch from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE collected in
+    separate runs of this command on the same build, FETCH_SIZE doubled per MI355X_MICROARCH.md's
+    gfx950 correction); bench.py cannot run the profiler on itself, so the committed summary of the
+    matching workload is reported, or null when there is none."""
+    path = os.path.join(ROOT, "profiles", "r01_b_trunk_pmc.json")
+    if args.workload != "2x_compact_1080p" or args.tile != 960 or nf != 64 or not os.path.exists(path):
+        return None
+    try:
+        return int(json.load(open(path))["hbm_bytes_per_launch"])
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def parity_probe(net, model_key, tile):
     """GPU vs CPU oracle on a small frame, reported next to the throughput."""
     from oracle import uvoracle
@@ -197,7 +211,7 @@ def main():
             "roofline": {
                 "kernel": (f"trunk_kernel<{nf}>" if nf == 64 else f"conv3x3_kernel<{nf},0,1>") + f" (trunk {nf}->{nf} + PReLU)",
                 "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": pmc_traffic(args, nf),
                 "flops_per_launch": trunk_flops_per_launch, "avg_launch_ms": round(avg_ms, 4), "launches": n_launch,
             },
         }
