@@ -19,7 +19,8 @@ rng = np.random.default_rng(0)
 img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
 net.process_u8(img, tile_size=960, border=10)
 cap = 256
-for ablate, label in ((0, "real kernel"), (1, "memory only (no MFMA / LDS reads)"), (2, "compute only (L2-resident in, sink out)")):
+for ablate, label in ((0, "real kernel"), (1, "memory only (no MFMA / LDS reads)"), (2, "compute only (L2-resident in, sink out)"),
+                      (3, "TAIL kernel conv3x3_kernel<64,1,2> (stamps: 0 start, 1 k-loop done, 2 barrier, 3 epilogue done)")):
     buf = np.zeros(cap * 8, np.uint64)
     n = ctypes.c_int()
     ms = ctypes.c_float()
@@ -29,6 +30,8 @@ for ablate, label in ((0, "real kernel"), (1, "memory only (no MFMA / LDS reads)
     gap = s[1:, 0] - s[:-1, 3]
     per = s[1:, 0] - s[:-1, 0]
     print(f"== {label}: {ms.value * 1e3:.1f} us per launch, {n.value} tiles per group (s_memtime ticks)")
+    print(f"  workgroup 0: entry -> first k-loop {s[0, 0] - s[0, 5]} ticks, loop {s[-1, 3] - s[0, 0]}, drain {s[0, 6] - s[-1, 3]}, "
+          f"total {s[0, 6] - s[0, 5]} ticks = {(s[0, 6] - s[0, 5]) / (ms.value * 1e3):.0f} ticks/us of the launch time")
     for name, v in (("k-loop", kloop), ("dma wait+barrier", wait), ("epilogue", epi), (" math+stage", s[:, 4] - s[:, 2]),
                     (" readback+st", s[:, 3] - s[:, 4]), ("end barrier+ovh", gap), ("tile period", per)):
         print(f"  {name:14s} median {np.median(v):8.1f}  min {v.min():6d}  max {v.max():6d}")

@@ -717,6 +717,41 @@ int uva_net_debug_trunk_stamps(uva_net* n, unsigned long long* out, int max_tile
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
+    if (ablate == 3) {
+        // the u8 tail kernel of the last host-route call instead of a trunk layer
+        if (n->last.f32 || !n->d_out) { (void)hipFree(d); return fail("tail stamps need a previous uva_net_process_u8 call"); }
+        const int nconv = (int)n->g.convs.size();
+        ca.in_act = ws->act[(nconv - 2) & 1];
+        ca.out_act = nullptr;
+        ca.wpk = n->layers[nconv - 1].wpk;
+        ca.bias = n->layers[nconv - 1].bias;
+        ca.slope = nullptr;
+        ca.src_u8 = (const uint8_t*)n->last.src;
+        ca.src_stride = n->last.src_stride;
+        ca.dst_u8 = n->d_out;
+        ca.dst_stride = (size_t)ws->w * n->g.scale * 3;
+        int rc3 = launch_conv(n, 1, ca);
+        ca.dbg = nullptr;
+        HIP_TRY(hipEventRecord(e0, n->stream));
+        for (int r = 0; r < 10 && !rc3; ++r) rc3 = launch_conv(n, 1, ca);
+        HIP_TRY(hipEventRecord(e1, n->stream));
+        ca.dbg = d;
+        HIP_TRY(hipMemsetAsync(d, 0, bytes, n->stream));
+        if (!rc3) rc3 = launch_conv(n, 1, ca);
+        if (!rc3) {
+            HIP_TRY(hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, n->stream));
+            HIP_TRY(hipStreamSynchronize(n->stream));
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+            if (kernel_ms) *kernel_ms = ms / 10;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        (void)hipFree(d);
+        const int grid3 = std::max(8, (n->ncu / 8) * 8);
+        if (tiles) *tiles = (ca.tiles_per_xcd + grid3 / 8 - 1) / (grid3 / 8);
+        return rc3;
+    }
     int rc = launch_trunk(n, ws, ca, ablate);   // warm
     ca.dbg = nullptr;
     HIP_TRY(hipEventRecord(e0, n->stream));

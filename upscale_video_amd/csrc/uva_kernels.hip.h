@@ -706,6 +706,7 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
                                // the wave's MFMA issue for ~60-150 cycles); the other CPW - CPW_K are
                                // issued by the same wave at the start of its (shorter) epilogue phase
 
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = lds_offset(smem);
     float* bias_lds = (float*)(smem + TRUNK_SLOTS * SLOTB);
@@ -740,22 +741,11 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
         prm_lds[threadIdx.x] = sl;
         prm_lds[64 + threadIdx.x] = sl <= 1.f ? __builtin_inff() : -__builtin_inff();
     }
-    for (int i = threadIdx.x; i < a.nplanes * 16; i += 512) ((int*)planes_lds)[i] = ((const int*)a.planes)[i];
-
-    // this wave's half of the layer's weights, resident in registers for the whole kernel
-    half8 w[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) w[ks] = a.wpk[(ks * 2 + mh) * 64 + lane];
-
-    int dma_pc[CPW];
-#pragma unroll
-    for (int i = 0; i < CPW; ++i) dma_pc[i] = trunk_piece_const<NF>(i, wave, lane);
-
-    __syncthreads();
-    // Tile schedule of this workgroup, built once: entry k = {byte offset of the tile's halo origin
-    // inside the activation buffers (lo, hi), row pitch in bytes, (valid rows << 8) | valid columns}.
-    // The per-tile work then needs one uniform 16-byte LDS read instead of a plane search, and none
-    // of it sits in front of the k-loop.
+    // Tile schedule of this workgroup, built once straight from the plane table in global memory
+    // (wave-uniform reads): entry k = {byte offset of the tile's halo origin inside the activation
+    // buffers (lo, hi), row pitch in bytes, (valid rows << 8) | valid columns}.  The per-tile work
+    // then needs one uniform 16-byte LDS read instead of a plane search, and none of it sits in
+    // front of the k-loop.
     const int nsched = 2 * niter0 + TRUNK_LOOKAHEAD;
     for (int k = threadIdx.x; k < nsched; k += 512) {
         int t = t0 + (k & 1) + (k >> 1) * g8;
@@ -764,8 +754,8 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
         t += a.tile_base;
         int p = 0;
         for (int q = 1; q < a.nplanes; ++q)
-            if (t >= planes_lds[q].tile_begin4) p = q;
-        const PlaneDesc& pl = planes_lds[p];
+            if (t >= a.planes[q].tile_begin4) p = q;
+        const PlaneDesc pl = a.planes[p];
         const int local = t - pl.tile_begin4;
         const int ty = local / pl.ntx, tx = local - (local / pl.ntx) * pl.ntx;
         const unsigned long long off =
@@ -774,6 +764,9 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
         const int vx = real ? min(TW, pl.w - tx * TW) : 0;
         sched_lds[k] = make_uint4((unsigned)off, (unsigned)(off >> 32), (unsigned)(pl.pitch * G::PIXB), (unsigned)((vy << 8) | vx));
     }
+    int dma_pc[CPW];
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) dma_pc[i] = trunk_piece_const<NF>(i, wave, lane);
     __syncthreads();
 
     // accumulator chains start from C = 0 (an inline constant, no registers); the bias is added in
@@ -807,12 +800,18 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
             for (int i = 0; i < CPW; ++i) trunk_issue_piece<NF>(s2.base, s2.pitch, lds0 + 2 * SLOTB, i, wave, dma_pc[i]);
         }
     }
+    // this wave's half of the layer's weights, resident in registers for the whole kernel; loaded
+    // behind the first tiles' DMA so that both latencies overlap
+    half8 w[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) w[ks] = a.wpk[(ks * 2 + mh) * 64 + lane];
     tile_barrier<0>();
     if (grp == 1) group_barrier();   // group 1 runs half a period behind group 0
     int cur = grp;                   // ring slot of this group's current tile: (2*it + grp) % 5
     Sched la = read_sched(grp + TRUNK_LOOKAHEAD);   // look-ahead tile of the first k-loop
 
     const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+    if (stamp) a.dbg[5] = t_entry;
     for (int it = 0; it < niter0; ++it) {
         const bool active = it < niter;
         const int k = 2 * it + grp;
@@ -958,6 +957,7 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
     if (grp == 0) group_barrier();
     // nothing of the re-fetched look-ahead tiles may land after the workgroup's LDS is released
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (stamp) a.dbg[6] = __builtin_amdgcn_s_memtime();
 }
 
 // ----------------------------------------------------------------------------------------------
