@@ -365,7 +365,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a)
 
     // LDS: NBUF halo-tile buffers (a ring: tile it lives in buffer it % NBUF and tile it+NBUF-1 is
     // being streamed in while tile it is computed), then parameters, plane table, tail staging.
-    constexpr int NBUF = conv_nbuf<NF>(MODE == 0 ? 0 : R);
+    // trunk (24 features): 3 slots.  Tails: 2 slots -- their tile barrier then waits for ALL vector
+    // memory traffic, which lets the epilogue's residual pixels be plain loads issued at the top of
+    // the iteration (a deeper DMA look-ahead would force the compiler-inserted wait for those loads
+    // to also wait for the youngest DMA pieces).
+    constexpr int NBUF = MODE == 0 ? conv_nbuf<NF>(0) : 2;
     constexpr int LA = NBUF - 1;                       // tiles of DMA look-ahead
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = lds_offset(smem);
@@ -444,7 +448,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a)
 
     // B fragments are read PF k-steps ahead of the MFMAs that consume them (tails: fewer, their
     // epilogue needs the registers)
-    constexpr int PF = (MODE == 0) ? 3 : 1;
+    constexpr int PF = (MODE == 0) ? 3 : (R == 4 ? 1 : 2);
     int cur = 0;            // ring slot of the tile being computed
 
     const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
@@ -463,6 +467,24 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a)
         const char* next_tb = halo_tile_base<NF>(a.in_act, pln, ids[LA].ty, ids[LA].tx);
         const int next_pitch = __builtin_amdgcn_readfirstlane(pln.pitch) * G::PIXB;
         const unsigned next_lds = lds0 + fill * G::BUFB;
+
+        // tails: this lane's two source pixels (the residual branch of the graph), fetched now so
+        // that their HBM latency (the frame was last touched ~17 layers ago) hides under the k-loop
+        float resid[2][3];
+        if constexpr (MODE != 0) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int yc = min(id.ty * TH + 2 * wave + n, pl.h - 1), xc = min(id.tx * TW + px, pl.w - 1);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if constexpr (MODE == 1)
+                        resid[n][c] = (float)a.src_u8[(size_t)(pl.src_y0 + yc) * a.src_stride +
+                                                      (size_t)(pl.src_x0 + xc) * 3 + c];
+                    else
+                        resid[n][c] = a.src_f32[((size_t)c * pl.h + yc) * pl.w + xc];
+                }
+            }
+        }
 
         // B-operand base: pixel (row 2*wave+n, col px) of the halo tile at tap (0,0)
         const char* bbase[2];
@@ -539,7 +561,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a)
                 const int y = id.ty * TH + 2 * wave + n;
                 const int x = id.tx * TW + px;
                 const bool inside = (y < pl.h) && (x < pl.w);
-                const int yc = min(y, pl.h - 1), xc = min(x, pl.w - 1);
 #pragma unroll
                 for (int m = 0; m < MF; ++m) {
 #pragma unroll
@@ -553,12 +574,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a)
                             const int ch = co / (R * R);
                             const int rem = co - ch * (R * R);
                             const int i = rem / R, jj = rem - (rem / R) * R;
-                            float res;
-                            if constexpr (MODE == 1)
-                                res = (float)a.src_u8[(size_t)(pl.src_y0 + yc) * a.src_stride +
-                                                      (size_t)(pl.src_x0 + xc) * 3 + ch] * norm;
-                            else
-                                res = a.src_f32[((size_t)ch * pl.h + yc) * pl.w + xc];
+                            // ch is a compile-time constant for R = 1 and 4, and depends on the
+                            // lane half for R = 2 (half 0: channels 0 and 2, half 1: channel 1)
+                            const float rsel = ch == 0 ? resid[n][0] : (ch == 1 ? resid[n][1] : resid[n][2]);
+                            const float res = MODE == 1 ? rsel * norm : rsel;
                             const float v = (acc[n][m][4 * g + j] + bias_lds[co]) + res;
                             if constexpr (MODE == 1) {
                                 float q = __builtin_rintf(v * 255.0f);      // v_rndne_f32: ties to even
