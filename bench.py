@@ -216,6 +216,14 @@ def main():
             },
         }
         if world == 1:
+            # informational: the host-pointer route of the C ABI (pageable numpy in/out, pinned staging,
+            # H2D + kernels + D2H, synchronous) -- what one reference worker calls per frame; never `value`
+            host_in = frames[0].cpu().numpy()
+            net.process_u8(host_in, tile_size=args.tile, border=10)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                net.process_u8(host_in, tile_size=args.tile, border=10)
+            result["config"]["host_route_fps_pcie_inclusive"] = round(5 / (time.perf_counter() - t0), 2)
             result["parity"] = parity_probe(net, key, args.tile)
             if not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(key, h, w, args.tile)
