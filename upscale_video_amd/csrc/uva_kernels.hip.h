@@ -721,7 +721,7 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
     constexpr int CPW = TG::CPW;
     constexpr int SLOTB = TG::SLOTB;
     constexpr int PF = 6;      // B fragments are read PF steps ahead of their MFMAs
-    constexpr int CPW_K = 4;   // DMA pieces of the look-ahead tile issued inside the k-loop (each blocks
+    constexpr int CPW_K = 5;   // DMA pieces of the look-ahead tile issued inside the k-loop (each blocks
                                // the wave's MFMA issue for ~60-150 cycles); the other CPW - CPW_K are
                                // issued by the same wave at the start of its (shorter) epilogue phase
 
@@ -909,11 +909,13 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
         tile_barrier<CPW_K>();
         if (stamp) a.dbg[8 * it + 2] = __builtin_amdgcn_s_memtime();
         // ---- epilogue phase ---------------------------------------------------------------------
-        // the rest of the look-ahead tile's pieces, ahead of this phase's stores in the queue
+        // schedule entries first (their LDS latency hides under the DMA issue below), then the rest of
+        // the look-ahead tile's pieces, ahead of this phase's stores in the queue
+        const Sched own = read_sched(k);
+        const Sched la_next = read_sched(min(k + 2 + TRUNK_LOOKAHEAD, nsched - 1));   // for this group's next k-loop
 #pragma unroll
         for (int i = CPW_K; i < CPW; ++i) trunk_issue_piece<NF>(la.base, la.pitch, la_lds, i, wave, dma_pc[i]);
-        const Sched own = read_sched(k);
-        la = read_sched(min(k + 2 + TRUNK_LOOKAHEAD, nsched - 1));   // for this group's next k-loop
+        la = la_next;
         if (active) {
             // bias, PReLU (med3 form, see store_trunk_rows), fp16 RNE.  A lane holds 4 channels of one
             // pixel; stored as is, a wave-store would touch 32 cache lines with 16 bytes each and the
