@@ -35,6 +35,8 @@ WORKLOADS = {
     "4x_compact_1080p": ("4x", "4x_Compact_Pretrain", 1080, 1920),
     "1x_hurrdeblur_1080p": ("1x", "1x_HurrDeblur_SubCompact_nf24-nc8_244k_net_g", 1080, 1920),
     "2x_compact_2160p": ("2x", "2x_Compact_Pretrain", 2160, 3840),
+    # BASELINE.json configs[2]: 1x HurrDeblur -> u8 -> 2x Compact, both on the device
+    "chain_1x_2x_1080p": ("2x", "2x_Compact_Pretrain", 1080, 1920),
 }
 
 
@@ -113,6 +115,18 @@ def parity_probe(net, model_key, tile):
             "max_abs_lsb": int(np.abs(d).max()), "vs": "CPU oracle fp32, 128x96 frame"}
 
 
+def chain_parity_probe(pre, net):
+    """1x -> u8 -> 2x on the GPU vs the same chain through the CPU oracle (config 3)."""
+    from oracle import uvoracle
+    img = uvoracle.synthetic_frame(96, 128)
+    want = uvoracle.load_model("2x").upscale_image(uvoracle.load_model("1x").apply_model(img), tile_size=64, border=10)
+    got = net.process_u8(pre.process_u8(img, tile_size=0), tile_size=64, border=10)
+    d = got.astype(np.float64) - want.astype(np.float64)
+    mse = float((d * d).mean())
+    return {"psnr_db": round(99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse), 2),
+            "max_abs_lsb": int(np.abs(d).max()), "vs": "CPU oracle fp32 chain 1x->u8->2x, 128x96 frame"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,10 +180,28 @@ def main():
     out = torch.empty((h * s, w * s, 3), dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
 
+    pre = None
+    if args.workload.startswith("chain_"):
+        pre = ncnn.Net()      # the '-m a' pass: whole frame, no tiling (apply_model)
+        pre.set_vulkan_device(local_rank)
+        pbase = os.path.join(ROOT, "models", "1x_HurrDeblur_SubCompact_nf24-nc8_244k_net_g")
+        assert pre.load_param(pbase + ".param") == 0 and pre.load_model(pbase + ".bin") == 0
+        mid = [torch.empty((h, w, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        torch.cuda.synchronize()
+
     def step(i):
-        net.process_u8_device(frames[i % n_src].data_ptr(), h, w, out.data_ptr(), tile_size=args.tile, border=10)
+        src = frames[i % n_src].data_ptr()
+        if pre is not None:
+            m = mid[i & 1]
+            pre.wait_for(net)                     # mid[i&1] was last read two frames ago by `net`
+            pre.process_u8_device(src, h, w, m.data_ptr(), tile_size=0)
+            net.wait_for(pre)
+            src = m.data_ptr()
+        net.process_u8_device(src, h, w, out.data_ptr(), tile_size=args.tile, border=10)
 
     def sync():
+        if pre is not None:
+            pre.synchronize()
         net.synchronize()
         torch.cuda.synchronize()
 
@@ -192,6 +224,8 @@ def main():
         avg_ms = trunk_ms / max(1, n_launch)
         achieved = trunk_flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         frame_flops = conv_flops_per_px(nf, nconv, s) * h * w
+        if pre is not None:
+            frame_flops += conv_flops_per_px(pre.num_features, pre.num_convs, 1) * h * w
         result = {
             "metric": "frames/sec 1080p->2x Compact (SRVGGNetCompact per-frame SR hot path)" if args.workload == "2x_compact_1080p"
                       else "frames/sec " + args.workload,
@@ -224,7 +258,7 @@ def main():
             for _ in range(5):
                 net.process_u8(host_in, tile_size=args.tile, border=10)
             result["config"]["host_route_fps_pcie_inclusive"] = round(5 / (time.perf_counter() - t0), 2)
-            result["parity"] = parity_probe(net, key, args.tile)
+            result["parity"] = parity_probe(net, key, args.tile) if pre is None else chain_parity_probe(pre, net)
             if not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(key, h, w, args.tile)
         print(json.dumps(result), flush=True)

@@ -90,6 +90,13 @@ int uva_net_process_u8_device(uva_net* net, const void* d_in, int h, int w, size
 
 int uva_net_synchronize(uva_net* net);
 
+/* Device-side ordering between two nets of one process (each net owns a stream): everything
+ * `producer` has been asked to do so far completes before anything `net` is asked to do from now
+ * on.  Used to chain the 1x HurrDeblur pass into the 2x pass without leaving the GPU (the reference
+ * hops through an 8-bit PNG between them, upscale/upscale_processing.py:888-909; a u8 frame in HBM
+ * carries exactly the same information). */
+int uva_net_wait_for(uva_net* net, uva_net* producer);
+
 /* ---- introspection used by the parity tests and bench.py ------------------------------ */
 
 /* Activation after convolution #conv_idx (+PReLU) of the last extract/process call with

@@ -589,6 +589,19 @@ int uva_net_synchronize(uva_net* n)
     return 0;
 }
 
+int uva_net_wait_for(uva_net* n, uva_net* producer)
+{
+    if (!n || !producer) return fail("null net");
+    if (n == producer || !producer->dev_ready) return 0;
+    if (ensure_device(n)) return 1;
+    if (producer->device != n->device) return fail("uva_net_wait_for: nets are on different devices");
+    hipEvent_t e = take_event(n);
+    HIP_TRY(hipEventRecord(e, producer->stream));
+    HIP_TRY(hipStreamWaitEvent(n->stream, e, 0));
+    n->ev_free.push_back(e);   // safe to recycle: the wait has captured the recorded state
+    return 0;
+}
+
 int uva_net_process_u8_device(uva_net* n, const void* d_in, int h, int w, size_t in_stride, void* d_out,
                               size_t out_stride, int tile_size, int border)
 {

@@ -198,6 +198,10 @@ class Net:
             self._h, ctypes.c_void_p(d_in), h, w, in_stride or w * 3, ctypes.c_void_p(d_out),
             out_stride or w * s * 3, int(tile_size), int(border)))
 
+    def wait_for(self, producer):
+        """Device-side ordering: work queued on `producer` so far finishes before this net's next work."""
+        _lib.check(self._L.uva_net_wait_for(self._h, producer._h))
+
     def synchronize(self):
         _lib.check(self._L.uva_net_synchronize(self._h))
 
