@@ -720,7 +720,8 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
     constexpr int KS = G::KS;
     constexpr int CPW = TG::CPW;
     constexpr int SLOTB = TG::SLOTB;
-    constexpr int PF = 6;      // B fragments are read PF steps ahead of their MFMAs
+    constexpr int PF = 4;      // B fragments are read PF steps ahead of their MFMAs (measured: 3-4 best,
+                               // 2 exposes LDS latency, 6+ costs more than it hides)
     constexpr int CPW_K = 5;   // DMA pieces of the look-ahead tile issued inside the k-loop (each blocks
                                // the wave's MFMA issue for ~60-150 cycles); the other CPW - CPW_K are
                                // issued by the same wave at the start of its (shorter) epilogue phase
