@@ -596,26 +596,55 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (stamp) a.dbg[8 * it + 4] = __builtin_amdgcn_s_memtime();
                 const int x_lo = max(pl.core_x0, id.tx * TW) - id.tx * TW;
                 const int x_hi = min(min(pl.core_x1, pl.w), id.tx * TW + TW) - id.tx * TW;
                 const int b_lo = x_lo * R * 3, b_hi = x_hi * R * 3;
                 constexpr int WORDS = STAGE_ROWB / 4;
-                for (int idx = lane; idx < 2 * R * WORDS; idx += 64) {
-                    const int sr = idx / WORDS;              // staged row: n*R + i
-                    const int k = idx - sr * WORDS;
-                    const int n = sr / R, i = sr - n * R;
-                    const int y = id.ty * TH + 2 * wave + n;
-                    if (y < pl.core_y0 || y >= min(pl.core_y1, pl.h)) continue;
-                    uint8_t* drow = a.dst_u8 + ((size_t)(pl.src_y0 + y) * R + i) * a.dst_stride +
-                                    (size_t)(pl.src_x0 + id.tx * TW) * R * 3;
-                    const uint8_t* srow = stage + sr * STAGE_ROWB;
-                    const int b0 = 4 * k;
-                    if (b0 >= b_lo && b0 + 4 <= b_hi && (((size_t)(drow + b0)) & 3) == 0) {
-                        *(uint32_t*)(drow + b0) = *(const uint32_t*)(srow + b0);
-                    } else {
+                const int y_t = id.ty * TH + 2 * wave;                  // this wave's first tile row
+                uint8_t* const dbase = a.dst_u8 + (size_t)(pl.src_y0 + y_t) * R * a.dst_stride +
+                                       (size_t)(pl.src_x0 + id.tx * TW) * R * 3;
+                // wave-uniform fast paths: both rows and all 32 columns inside the core region, and
+                // every output row of the tile 16- (or 4-) byte aligned
+                const bool full = b_lo == 0 && b_hi == STAGE_ROWB && y_t >= pl.core_y0 &&
+                                  y_t + 2 <= min(pl.core_y1, pl.h);
+                const size_t align_bits = (size_t)dbase | a.dst_stride;
+                if (full && (align_bits & 15) == 0) {
+                    constexpr int Q = STAGE_ROWB / 16;                  // 16-byte chunks per row
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (b0 + e >= b_lo && b0 + e < b_hi) drow[b0 + e] = srow[b0 + e];
+                    for (int c = 0; c < (2 * R * Q + 63) / 64; ++c) {
+                        const int idx = c * 64 + lane;
+                        const int sr = idx / Q, k = idx - sr * Q;
+                        if (idx < 2 * R * Q)
+                            *(uint4*)(dbase + (size_t)sr * a.dst_stride + 16 * k) =
+                                *(const uint4*)(stage + sr * STAGE_ROWB + 16 * k);
+                    }
+                } else if (full && (align_bits & 3) == 0) {
+#pragma unroll
+                    for (int c = 0; c < (2 * R * WORDS + 63) / 64; ++c) {
+                        const int idx = c * 64 + lane;
+                        const int sr = idx / WORDS, k = idx - sr * WORDS;
+                        if (idx < 2 * R * WORDS)
+                            *(uint32_t*)(dbase + (size_t)sr * a.dst_stride + 4 * k) =
+                                *(const uint32_t*)(stage + sr * STAGE_ROWB + 4 * k);
+                    }
+                } else {
+                    for (int idx = lane; idx < 2 * R * WORDS; idx += 64) {
+                        const int sr = idx / WORDS;              // staged row: n*R + i
+                        const int k = idx - sr * WORDS;
+                        const int n = sr / R;
+                        const int y = y_t + n;
+                        if (y < pl.core_y0 || y >= min(pl.core_y1, pl.h)) continue;
+                        uint8_t* drow = dbase + (size_t)sr * a.dst_stride;
+                        const uint8_t* srow = stage + sr * STAGE_ROWB;
+                        const int b0 = 4 * k;
+                        if (b0 >= b_lo && b0 + 4 <= b_hi && (((size_t)(drow + b0)) & 3) == 0) {
+                            *(uint32_t*)(drow + b0) = *(const uint32_t*)(srow + b0);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (b0 + e >= b_lo && b0 + e < b_hi) drow[b0 + e] = srow[b0 + e];
+                        }
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
