@@ -142,6 +142,14 @@ def main():
         gold[tag + "_in"] = img
         gold[tag + "_f32"] = f_ind.astype(np.float32)
         gold[tag + "_u8"] = u_ind
+    # BASELINE config 1: one 256x256 frame, 2x Compact (u8 result only, to keep the fixture small)
+    img = uvoracle.synthetic_frame(256, 256)
+    _, u_ind = run_model("2x", img)
+    u_c = uvoracle.load_model("2x").upscale_image(img)       # 256 < 960: a single tile, no border
+    print(f"2x 256x256 smooth (config 1): u8 mismatches={int((u_ind != u_c).sum())}/{u_c.size}")
+    assert np.abs(u_ind.astype(int) - u_c.astype(int)).max() <= 1
+    gold["config1_2x_256x256_in"] = img
+    gold["config1_2x_256x256_u8"] = u_ind
     if args.write_golden:
         out = os.path.join(os.path.dirname(_HERE), "tests", "golden", "independent_torch.npz")
         np.savez_compressed(out, **gold)

@@ -30,6 +30,8 @@ for ablate, label in ((0, "real kernel"), (1, "memory only (no MFMA / LDS reads)
     gap = s[1:, 0] - s[:-1, 3]
     per = s[1:, 0] - s[:-1, 0]
     print(f"== {label}: {ms.value * 1e3:.1f} us per launch, {n.value} tiles per group (s_memtime ticks)")
+    if ablate < 3:
+        print(f"  prologue: entry -> schedule built {s[0, 7] - s[0, 5]}, -> first DMA issued {s[1, 7] - s[0, 7]}, -> landed + weights + barrier {s[0, 0] - s[1, 7]}")
     print(f"  workgroup 0: entry -> first k-loop {s[0, 0] - s[0, 5]} ticks, loop {s[-1, 3] - s[0, 0]}, drain {s[0, 6] - s[-1, 3]}, "
           f"total {s[0, 6] - s[0, 5]} ticks = {(s[0, 6] - s[0, 5]) / (ms.value * 1e3):.0f} ticks/us of the launch time")
     for name, v in (("k-loop", kloop), ("dma wait+barrier", wait), ("epilogue", epi), (" math+stage", s[:, 4] - s[:, 2]),

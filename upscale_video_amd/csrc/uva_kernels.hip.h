@@ -817,6 +817,7 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
 #pragma unroll
     for (int i = 0; i < CPW; ++i) dma_pc[i] = trunk_piece_const<NF>(i, wave, lane);
     __syncthreads();
+    const unsigned long long t_sched = __builtin_amdgcn_s_memtime();
 
     // accumulator chains start from C = 0 (an inline constant, no registers); the bias is added in
     // the epilogue, which has VALU slots to spare, rather than held in 16 more registers
@@ -850,17 +851,25 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
         }
     }
     // this wave's half of the layer's weights, resident in registers for the whole kernel; loaded
-    // behind the first tiles' DMA so that both latencies overlap
+    // behind the first tiles' DMA so that both latencies overlap.  Group 1 starts half a period
+    // later, so it fetches its weights during that wait and leaves the CU's load path to group 0.
+    const unsigned long long t_dma = __builtin_amdgcn_s_memtime();
     half8 w[KS];
+    if (grp == 0) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) w[ks] = a.wpk[(ks * 2 + mh) * 64 + lane];
+        for (int ks = 0; ks < KS; ++ks) w[ks] = a.wpk[(ks * 2 + mh) * 64 + lane];
+    }
     tile_barrier<0>();
-    if (grp == 1) group_barrier();   // group 1 runs half a period behind group 0
+    if (grp == 1) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) w[ks] = a.wpk[(ks * 2 + mh) * 64 + lane];
+        group_barrier();             // group 1 runs half a period behind group 0
+    }
     int cur = grp;                   // ring slot of this group's current tile: (2*it + grp) % 5
     Sched la = read_sched(grp + TRUNK_LOOKAHEAD);   // look-ahead tile of the first k-loop
 
     const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
-    if (stamp) a.dbg[5] = t_entry;
+    if (stamp) { a.dbg[5] = t_entry; a.dbg[7] = t_sched; a.dbg[15] = t_dma; }
     for (int it = 0; it < niter0; ++it) {
         const bool active = it < niter;
         const int k = 2 * it + grp;
