@@ -440,6 +440,7 @@ int run_graph(uva_net* n, Workspace* ws, bool f32, const void* src, size_t src_s
         ca.wpk = n->layers[i].wpk;
         ca.bias = n->layers[i].bias;
         ca.slope = n->layers[i].slope;
+        ca.reverse = i & 1;   // layer 1 walks backwards over what the head wrote last, layer 2 forwards, ...
         if (launch_trunk(n, ws, ca)) return 1;
     }
     if (stop_after >= 0) return 0;
@@ -447,6 +448,7 @@ int run_graph(uva_net* n, Workspace* ws, bool f32, const void* src, size_t src_s
     ca.ntiles = ws->ntiles;
     ca.tiles_per_xcd = (ws->ntiles + 7) / 8;
     ca.in_act = ws->act[(nconv - 2) & 1];
+    ca.reverse = (nconv - 1) & 1;
     ca.out_act = nullptr;
     ca.wpk = n->layers[nconv - 1].wpk;
     ca.bias = n->layers[nconv - 1].bias;

@@ -111,6 +111,9 @@ struct ConvArgs {
     _Float16* sink;               // >= 64 pixels of scratch: where lanes outside the image store to
     int tile_base;                // trunk_kernel: first global work tile of this launch (huge frames
                                   // are split so that a workgroup's schedule fits its LDS table)
+    int reverse;                  // walk the tiles last-to-first: consecutive layers alternate direction so
+                                  // that a layer starts on what the previous one wrote last, i.e. on what is
+                                  // still in the 256 MB Infinity Cache
 };
 
 struct HeadArgs {
@@ -434,10 +437,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a)
             biasv[m][r] = (MODE == 0) ? bias_lds[32 * m + 8 * (r >> 2) + 4 * half + (r & 3)] : 0.f;
 
     // prologue: tiles 0 .. LA-1 (tile indices past the end re-fetch the last tile: harmless)
+    auto tile_of = [&](int i) __attribute__((always_inline)) {   // this workgroup's i-th tile
+        const int t = t_first + i * g8;
+        return a.reverse ? a.ntiles - 1 - t : t;
+    };
     TileId ids[LA + 1];
 #pragma unroll
     for (int j = 0; j < LA; ++j) {
-        ids[j] = pt.decode(t_first + min(j, niter - 1) * g8, lane);
+        ids[j] = pt.decode(tile_of(min(j, niter - 1)), lane);
         const PlaneDesc& plj = planes_lds[ids[j].plane];
         const char* tb = halo_tile_base<NF>(a.in_act, plj, ids[j].ty, ids[j].tx);
         const int pitchj = __builtin_amdgcn_readfirstlane(plj.pitch) * G::PIXB;
@@ -462,7 +469,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a)
         // slot that compute(it-1) released at the last barrier.  Past the end the last tile is
         // re-fetched so that the k-loop stays one straight-line block.
         const int fill = cur + LA >= NBUF ? cur + LA - NBUF : cur + LA;
-        ids[LA] = pt.decode(t_first + min(it + LA, niter - 1) * g8, lane);
+        ids[LA] = pt.decode(tile_of(min(it + LA, niter - 1)), lane);
         const PlaneDesc& pln = planes_lds[ids[LA].plane];
         const char* next_tb = halo_tile_base<NF>(a.in_act, pln, ids[LA].ty, ids[LA].tx);
         const int next_pitch = __builtin_amdgcn_readfirstlane(pln.pitch) * G::PIXB;
@@ -800,6 +807,7 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
         int t = t0 + (k & 1) + (k >> 1) * g8;
         const bool real = t < t_lim;
         if (!real || ABL == 2) t = t0;                       // past the end: a harmless re-fetch
+        if (a.reverse) t = a.ntiles - 1 - t;
         t += a.tile_base;
         int p = 0;
         for (int q = 1; q < a.nplanes; ++q)
