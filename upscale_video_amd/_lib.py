@@ -3,7 +3,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libuva.so")
+LIB_PATH = os.environ.get("UVA_LIB_PATH") or os.path.join(_HERE, "libuva.so")   # override: A/B builds
 
 # every symbol include/uva.h declares
 SYMBOLS = [

@@ -26,6 +26,8 @@ def needs_build():
 
 def build_lib(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU).  Returns the .so path."""
+    if os.environ.get("UVA_LIB_PATH"):      # an A/B build selected by the caller: leave it alone
+        return os.environ["UVA_LIB_PATH"]
     if not force and not needs_build():
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",

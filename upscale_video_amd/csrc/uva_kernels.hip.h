@@ -791,6 +791,13 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
     const int niter1 = t0 + 1 < t_lim ? (t_lim - t0 - 1 + g8 - 1) / g8 : 0;
     const int niter = grp ? niter1 : niter0;
 
+    // this wave's half of the layer's weights, resident in registers for the whole kernel.  Group 0
+    // requests them first of all, so that they stream in under the schedule build below.
+    half8 w[KS];
+    if (grp == 0) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) w[ks] = a.wpk[(ks * 2 + mh) * 64 + lane];
+    }
     if (threadIdx.x < 64) {
         bias_lds[threadIdx.x] = a.bias[threadIdx.x];
         const float sl = a.slope[threadIdx.x];
@@ -858,15 +865,9 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
             for (int i = 0; i < CPW; ++i) trunk_issue_piece<NF>(s2.base, s2.pitch, lds0 + 2 * SLOTB, i, wave, dma_pc[i]);
         }
     }
-    // this wave's half of the layer's weights, resident in registers for the whole kernel; loaded
-    // behind the first tiles' DMA so that both latencies overlap.  Group 1 starts half a period
-    // later, so it fetches its weights during that wait and leaves the CU's load path to group 0.
+    // Group 1 starts half a period later: it fetches its weights during that wait and leaves the
+    // CU's load path to group 0 until then.
     const unsigned long long t_dma = __builtin_amdgcn_s_memtime();
-    half8 w[KS];
-    if (grp == 0) {
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) w[ks] = a.wpk[(ks * 2 + mh) * 64 + lane];
-    }
     tile_barrier<0>();
     if (grp == 1) {
 #pragma unroll
