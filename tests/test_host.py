@@ -77,6 +77,22 @@ def _unpack_conv(pk, nf, cout):
     return w.reshape(cout, nf, 3, 3)
 
 
+def _unpack_trunk64(pk):
+    """trunk_kernel<64> (v_mfma_f32_16x16x32_f16): [18 k-steps = 2*tap + ch][4 blocks][64 lanes][8];
+    lane = (octet << 4) | i holds output channel 16*mb + i, input channels 32*ch + 8*octet .. +7."""
+    img = pk.view(np.float16).astype(np.float32).reshape(18, 4, 64, 8)
+    w = np.zeros((64, 64, 9), np.float32)
+    seen = np.zeros((64, 64, 9), bool)
+    for ks in range(18):
+        for mb in range(4):
+            for lane in range(64):
+                co, ci0 = 16 * mb + (lane & 15), 32 * (ks & 1) + 8 * (lane >> 4)
+                w[co, ci0:ci0 + 8, ks >> 1] = img[ks, mb, lane]
+                seen[co, ci0:ci0 + 8, ks >> 1] = True
+    assert seen.all()
+    return w.reshape(64, 64, 3, 3)
+
+
 @pytest.mark.parametrize("key", ["2x", "4x", "1x"])
 def test_packed_weights_are_a_permutation_of_oihw(uva, oracle_models, key):
     """The kernel's B operand supplies, for k-step ks and lane half h, K octet ko = 2ks+h = channels
@@ -86,7 +102,8 @@ def test_packed_weights_are_a_permutation_of_oihw(uva, oracle_models, key):
     nf = net.num_features
     for idx in (1, net.num_convs // 2, net.num_convs - 1):
         w, _, _ = om.conv(idx)
-        got = _unpack_conv(net.debug_packed_weights(idx), nf, w.shape[0])
+        trunk64 = nf == 64 and idx + 1 < net.num_convs
+        got = _unpack_trunk64(net.debug_packed_weights(idx)) if trunk64 else _unpack_conv(net.debug_packed_weights(idx), nf, w.shape[0])
         with np.errstate(over="ignore"):
             want = w.astype(np.float16).astype(np.float32)
         assert np.array_equal(got, want), (key, idx)

@@ -274,6 +274,7 @@ int ensure_device(uva_net* n)
         std::vector<uint16_t> pk;
         int mf = 0;
         if (i == 0) pack_head(g.convs[i], pk, &mf);
+        else if (g.nf == 64 && i + 1 < g.convs.size()) { pack_trunk64(g.convs[i], pk); mf = 2; }   // trunk_kernel<64>
         else pack_conv3x3(g.convs[i], g.nf, pk, nullptr, &mf);
         DeviceLayer& dl = n->layers[i];
         if (upload(&dl.wpk, pk.data(), pk.size() * 2, n->stream)) return 1;
@@ -796,6 +797,7 @@ int uva_net_debug_packed_weights(uva_net* n, int conv_idx, uint16_t* out, size_t
     if (conv_idx < 0 || conv_idx >= (int)n->g.convs.size()) return fail("conv_idx out of range");
     std::vector<uint16_t> pk;
     if (conv_idx == 0) pack_head(n->g.convs[0], pk, nullptr);
+    else if (n->g.nf == 64 && conv_idx + 1 < (int)n->g.convs.size()) pack_trunk64(n->g.convs[conv_idx], pk);
     else pack_conv3x3(n->g.convs[conv_idx], n->g.nf, pk, nullptr, nullptr);
     if (needed) *needed = pk.size();
     if (out && out_halfs >= pk.size()) std::memcpy(out, pk.data(), pk.size() * 2);

@@ -756,8 +756,7 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
     constexpr int KS = G::KS;
     constexpr int CPW = TG::CPW;
     constexpr int SLOTB = TG::SLOTB;
-    constexpr int PF = 4;      // B fragments are read PF steps ahead of their MFMAs (measured: 3-4 best,
-                               // 2 exposes LDS latency, 6+ costs more than it hides)
+    constexpr int PFF = 6;     // B fragments are read PFF fragments (~1.5-3 steps) ahead of their MFMAs
     constexpr int CPW_K = 5;   // DMA pieces of the look-ahead tile issued inside the k-loop (each blocks
                                // the wave's MFMA issue for ~60-150 cycles); the other CPW - CPW_K are
                                // issued by the same wave at the start of its (shorter) epilogue phase
@@ -796,7 +795,7 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
     half8 w[KS];
     if (grp == 0) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) w[ks] = a.wpk[(ks * 2 + mh) * 64 + lane];
+        for (int i = 0; i < KS; ++i) w[i] = a.wpk[((i >> 1) * 4 + 2 * mh + (i & 1)) * 64 + lane];
     }
     if (threadIdx.x < 64) {
         bias_lds[threadIdx.x] = a.bias[threadIdx.x];
@@ -836,9 +835,7 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
 
     // accumulator chains start from C = 0 (an inline constant, no registers); the bias is added in
     // the epilogue, which has VALU slots to spare, rather than held in 16 more registers
-    f32x16 zero16;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     char* const sink = (char*)a.sink + lane * G::PIXB;  // where lanes outside the image store to
 
@@ -871,7 +868,7 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
     tile_barrier<0>();
     if (grp == 1) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) w[ks] = a.wpk[(ks * 2 + mh) * 64 + lane];
+        for (int i = 0; i < KS; ++i) w[i] = a.wpk[((i >> 1) * 4 + 2 * mh + (i & 1)) * 64 + lane];
         group_barrier();             // group 1 runs half a period behind group 0
     }
     int cur = grp;                   // ring slot of this group's current tile: (2*it + grp) % 5
@@ -882,7 +879,7 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
     for (int it = 0; it < niter0; ++it) {
         const bool active = it < niter;
         const int k = 2 * it + grp;
-        f32x16 acc[2];
+        f32x4 acc[2][2][2];   // [output row n][column half c][16-channel block m]
         const int fill = cur + TRUNK_LOOKAHEAD >= TRUNK_SLOTS ? cur + TRUNK_LOOKAHEAD - TRUNK_SLOTS : cur + TRUNK_LOOKAHEAD;
         const unsigned la_lds = lds0 + fill * SLOTB;   // look-ahead tile k+3 -> the slot tile k-2 left
         if (stamp) a.dbg[8 * it + 0] = __builtin_amdgcn_s_memtime();
@@ -892,60 +889,75 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
             __builtin_amdgcn_s_setprio(2);
             const char* buf = smem + cur * SLOTB;
 
-            // B operand: LDS row 2*rp + R (R = 0..3) of the halo tile, column px + dx, channel octets
-            // 2*c + half.  The wave's two output rows overlap in their input rows: halo row R is tap
-            // row dy = R of output row 0 and tap row dy = R-1 of output row 1, so ONE fragment read
-            // feeds both accumulators (with different weights) for R = 1, 2 -- 48 LDS reads per tile
-            // instead of 72.  Steps:
-            //   s = 0..23 : (R=0, i=s/2) for even s -> acc0 only;  (R=3, i=s/2) for odd s -> acc1 only
-            //   s = 24..35: (R=1, i=s-24) -> both;   s = 36..47: (R=2, i=s-36) -> both
-            // with i = 4*dx + c.
-            const char* bbase = buf + ((2 * rp) * PW + px) * G::LPIXB + half * 16;
-            auto step_R = [](int s2) __attribute__((always_inline)) { return s2 < 24 ? ((s2 & 1) ? 3 : 0) : (s2 < 36 ? 1 : 2); };
-            auto step_i = [](int s2) __attribute__((always_inline)) { return s2 < 24 ? (s2 >> 1) : (s2 < 36 ? s2 - 24 : s2 - 36); };
-            auto read_b = [&](int s2) __attribute__((always_inline)) -> half8 {
-                const int R = step_R(s2), i2 = step_i(s2);
-                return *(const half8*)(bbase + (R * PW + (i2 >> 2)) * G::LPIXB + (i2 & 3) * 32);
+            // v_mfma_f32_16x16x32_f16: A = 16 output channels x 32 k (lane: channel lane&15, k octet
+            // lane>>4), B = 32 k x 16 pixels (lane: pixel lane&15, k octet lane>>4), C = 4 registers.  At
+            // the package power cap this shape sustains ~15 % more flop/s than 32x32x16 (half the
+            // accumulator register traffic per flop; tools/mfma_power_bench.hip), and the kernel is
+            // power-bound.  A k-step is (tap, input-channel half ch): a B fragment is one 16-byte LDS
+            // read per lane -- pixel (halo row 2*rp + R, column 16*c + (lane&15) + dx), channels
+            // 32*ch + 8*(lane>>4) .. +7.  The wave's two output rows overlap in their input rows: halo
+            // row R is tap row dy = R of output row 0 and dy = R-1 of output row 1, so one fragment
+            // feeds 2 (R = 0, 3) or 4 (R = 1, 2) MFMAs: 48 LDS reads per 144 MFMAs.
+            //   step st = 0..23: R = st & 3, ch = (st >> 2) & 1, dx = st >> 3; fragments 2*st + c.
+            // Consecutive MFMAs share their A operand (the weights) pairwise, which the power bench
+            // shows to be cheaper still.
+            const char* bbase = buf + ((2 * rp) * PW + (lane & 15)) * G::LPIXB + (lane >> 4) * 16;
+            auto read_b = [&](int f) __attribute__((always_inline)) -> half8 {
+                const int st = f >> 1, c = f & 1;
+                const int R = st & 3, ch = (st >> 2) & 1, dx = st >> 3;
+                return *(const half8*)(bbase + (R * PW + dx + 16 * c) * G::LPIXB + ch * 64);
             };
-            constexpr int NSTEP = 48;
-            half8 bq[PF + 1];
+            constexpr int NSTEP = 24, NFRAG = 48;
+            constexpr int RQ = PFF + 2;
+            half8 bq[RQ];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s2 = 0; s2 < PF; ++s2)
-                if (ABL != 1) bq[s2] = read_b(s2);
+            for (int f = 0; f < PFF; ++f)
+                if (ABL != 1) bq[f] = read_b(f);
 #pragma unroll
-            for (int s2 = 0; s2 < NSTEP; ++s2) {
-                if (ABL != 1 && s2 + PF < NSTEP) bq[(s2 + PF) % (PF + 1)] = read_b(s2 + PF);
+            for (int st = 0; st < NSTEP; ++st) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    if (ABL != 1 && 2 * st + c + PFF < NFRAG) bq[(2 * st + c + PFF) % RQ] = read_b(2 * st + c + PFF);
                 if constexpr (CPW_K > 0) {
                     constexpr int EVERY = NSTEP / (CPW_K > 0 ? CPW_K : 1);
-                    if (s2 % EVERY == EVERY / 2 && s2 / EVERY < CPW_K)
-                        trunk_issue_piece<NF>(la.base, la.pitch, la_lds, s2 / EVERY, wave, dma_pc[s2 / EVERY]);
+                    if (st % EVERY == EVERY / 2 && st / EVERY < CPW_K)
+                        trunk_issue_piece<NF>(la.base, la.pitch, la_lds, st / EVERY, wave, dma_pc[st / EVERY]);
                 }
-                const int R = step_R(s2), i2 = step_i(s2);
-                const half8 b = bq[s2 % (PF + 1)];
+                const int R = st & 3, ch = (st >> 2) & 1, dx = st >> 3;
                 if constexpr (ABL == 1) {
-                    if (s2 == 0) { acc[0] = zero16; acc[1] = zero16; }
-                    acc[s2 & 1][s2 & 15] += (float)w[s2 % KS][0];
+                    if (st == 0) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) acc[q >> 2][(q >> 1) & 1][q & 1] = zero4;
+                    }
+                    acc[st & 1][(st >> 1) & 1][(st >> 2) & 1][st & 3] += (float)w[st][0];
                 } else {
-                    if (R <= 2)   // output row 0, tap (dy = R, dx)
-                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[(R * 3 + (i2 >> 2)) * 4 + (i2 & 3)], b,
-                                                                        s2 == 0 ? zero16 : acc[0], 0, 0, 0);
-                    if (R >= 1)   // output row 1, tap (dy = R-1, dx)
-                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[((R - 1) * 3 + (i2 >> 2)) * 4 + (i2 & 3)], b,
-                                                                        s2 == 1 ? zero16 : acc[1], 0, 0, 0);
+                    const half8 b0 = bq[(2 * st) % RQ], b1 = bq[(2 * st + 1) % RQ];
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        if (n == 0 ? R > 2 : R < 1) continue;       // output row n, tap (dy = R - n, dx)
+                        const bool first = st == n;                  // st 0 starts row 0, st 1 starts row 1
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            const half8 wv = w[(((R - n) * 3 + dx) * 2 + ch) * 2 + m];
+                            acc[n][0][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, b0, first ? zero4 : acc[n][0][m], 0, 0, 0);
+                            acc[n][1][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, b1, first ? zero4 : acc[n][1][m], 0, 0, 0);
+                        }
+                    }
                 }
             }
-            // alone on its SIMD's matrix pipe, the wave must hide LDS latency itself
-            __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+            // alone on its SIMD's matrix pipe, the wave must hide LDS latency itself: pin the
+            // interleaving of fragment reads and MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, PFF, 0);
 #pragma unroll
-            for (int s2 = 0; s2 < 24; ++s2) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-#pragma unroll
-            for (int s2 = 24; s2 < NSTEP; ++s2) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                if (s2 + PF < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            for (int st = 0; st < NSTEP; ++st) {
+                const int R = st & 3;
+                const bool light = R == 0 || R == 3;       // 4 MFMAs; the other steps have 8
+                const bool rd = 2 * st + PFF < NFRAG;
+                if (light) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); else __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                if (rd) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (light) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); else __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                if (rd) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
             __builtin_amdgcn_s_setprio(0);
         }
@@ -974,32 +986,34 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
             char* const stage = smem + cur * SLOTB + wave * TG::STAGE_WAVE;
             // per-channel parameters of this lane's 16 channels, fetched up front (one LDS latency,
             // not eight): bias, slope, med3 selector
-            f32x4 b4[4], s4[4], i4[4];
+            f32x4 b4[2], s4[2], i4[2];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int cl = 32 * mh + 8 * g + 4 * (lane_o >> 5);
-                b4[g] = *(const f32x4*)(bias_lds + cl);
-                s4[g] = *(const f32x4*)(prm_lds + cl);
-                i4[g] = *(const f32x4*)(prm_lds + 64 + cl);
+            for (int m = 0; m < 2; ++m) {
+                const int cl = 32 * mh + 16 * m + 4 * (lane_o >> 4);
+                b4[m] = *(const f32x4*)(bias_lds + cl);
+                s4[m] = *(const f32x4*)(prm_lds + cl);
+                i4[m] = *(const f32x4*)(prm_lds + 64 + cl);
             }
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int cl = 8 * g + 4 * (lane_o >> 5);     // channel within this wave's 32
-                    f32x4 v;
+                for (int c = 0; c < 2; ++c)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float xv = acc[n][4 * g + j] + b4[g][j];
-                        v[j] = __builtin_amdgcn_fmed3f(xv, xv * s4[g][j], i4[g][j]);
+                    for (int m = 0; m < 2; ++m) {
+                        const int cl = 16 * m + 4 * (lane_o >> 4);     // channel within this wave's 32
+                        f32x4 v;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float xv = acc[n][c][m][j] + b4[m][j];
+                            v[j] = __builtin_amdgcn_fmed3f(xv, xv * s4[m][j], i4[m][j]);
+                        }
+                        const half2v lo = __builtin_convertvector(f32x2{v[0], v[1]}, half2v);
+                        const half2v hi = __builtin_convertvector(f32x2{v[2], v[3]}, half2v);
+                        uint2 o;
+                        o.x = __builtin_bit_cast(unsigned, lo);
+                        o.y = __builtin_bit_cast(unsigned, hi);
+                        *(uint2*)(stage + (n * 32 + 16 * c + (lane_o & 15)) * TG::STAGE_PX + cl * 2) = o;
                     }
-                    const half2v lo = __builtin_convertvector(f32x2{v[0], v[1]}, half2v);
-                    const half2v hi = __builtin_convertvector(f32x2{v[2], v[3]}, half2v);
-                    uint2 o;
-                    o.x = __builtin_bit_cast(unsigned, lo);
-                    o.y = __builtin_bit_cast(unsigned, hi);
-                    *(uint2*)(stage + (n * 32 + (lane_o & 31)) * TG::STAGE_PX + cl * 2) = o;
-                }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -249,6 +249,20 @@ void pack_conv3x3(const ConvWeights& c, int nf, std::vector<uint16_t>& out, int*
     if (mf_out) *mf_out = mf;
 }
 
+void pack_trunk64(const ConvWeights& c, std::vector<uint16_t>& out)
+{
+    out.assign((size_t)18 * 4 * 64 * 8, 0);
+    for (int ks = 0; ks < 18; ++ks)
+        for (int mb = 0; mb < 4; ++mb)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int co = 16 * mb + (lane & 15), tap = ks >> 1;
+                for (int e = 0; e < 8; ++e) {
+                    const int ci = 32 * (ks & 1) + 8 * (lane >> 4) + e;
+                    out[(((size_t)ks * 4 + mb) * 64 + lane) * 8 + e] = f32_to_f16_bits(c.w[((size_t)co * 64 + ci) * 9 + tap]);
+                }
+            }
+}
+
 void pack_head(const ConvWeights& c, std::vector<uint16_t>& out, int* mf_out)
 {
     const int mf = (c.cout + 31) / 32;

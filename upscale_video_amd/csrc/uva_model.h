@@ -39,6 +39,10 @@ float f16_bits_to_f32(uint16_t h);
 // lane = (half << 5) | i supplies output channel 32*m + i and K octet ko = 2*ks + half
 // (tap = ko / (nf/8), input channels 8*(ko % (nf/8)) .. +7).  Out-of-range -> 0.
 void pack_conv3x3(const ConvWeights& c, int nf, std::vector<uint16_t>& out, int* ks_out, int* mf_out);
+// The 64-feature trunk kernel uses v_mfma_f32_16x16x32_f16: image [18 k-steps][4 channel blocks][64
+// lanes][8] fp16, k-step = 2*tap + ch; lane = (octet << 4) | i supplies output channel 16*mb + i and
+// input channels 32*ch + 8*octet .. +7 of that tap.
+void pack_trunk64(const ConvWeights& c, std::vector<uint16_t>& out);
 // Head (cin = 3): K = [tap][4] (3 channels + zero), octet o = 2*ks + half holds taps 2o, 2o+1;
 // image [3][MF][64][8].
 void pack_head(const ConvWeights& c, std::vector<uint16_t>& out, int* mf_out);
