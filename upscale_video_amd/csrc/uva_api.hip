@@ -44,6 +44,7 @@ struct Workspace {
     int h = 0, w = 0, tile_size = 0, border = 0;
     std::vector<PlaneDesc> planes;
     PlaneDesc* d_planes = nullptr;
+    uint4* d_sched4 = nullptr;   // per 4-row work tile: trunk_kernel's schedule entry (ConvArgs::sched4)
     int ntiles = 0;     // 8-row work tiles (head, tail, 24-feature trunk)
     int ntiles4 = 0;    // 4-row work tiles (64-feature trunk kernel)
     size_t act_pixels = 0;
@@ -51,6 +52,8 @@ struct Workspace {
     void release()
     {
         if (d_planes) (void)hipFree(d_planes);
+        if (d_sched4) (void)hipFree(d_sched4);
+        d_sched4 = nullptr;
         if (act[0]) (void)hipFree(act[0]);
         if (act[1]) (void)hipFree(act[1]);
         d_planes = nullptr;
@@ -219,6 +222,7 @@ int launch_trunk(uva_net* n, const Workspace* ws, ConvArgs ca, int ablate = 0)
         // a workgroup's tile schedule must fit its LDS table: split very large frames into launches
         const int grid = std::max(8, (n->ncu / 8) * 8);
         const int per_launch = 8 * (2 * (grid / 8)) * ((TRUNK_SCHED_MAX - TRUNK_LOOKAHEAD) / 2 - 1);
+        ca.sched4 = ws->d_sched4;
         for (int base = 0; base < ws->ntiles4; base += per_launch) {
             ca.tile_base = base;
             ca.ntiles = std::min(per_launch, ws->ntiles4 - base);
@@ -364,6 +368,22 @@ int get_workspace(uva_net* n, int h, int w, int tile_size, int border, Workspace
     HIP_TRY(hipMalloc((void**)&ws.d_planes, ws.planes.size() * sizeof(PlaneDesc)));
     HIP_TRY(hipMemcpyAsync(ws.d_planes, ws.planes.data(), ws.planes.size() * sizeof(PlaneDesc),
                            hipMemcpyHostToDevice, n->stream));
+    std::vector<uint4> sched4;
+    if (n->g.nf == 64) {
+        using G4 = Geo<64, 4>;
+        sched4.reserve((size_t)tiles4);
+        for (const auto& p : ws.planes)
+            for (int ty = 0; ty < p.nty4; ++ty)
+                for (int tx = 0; tx < p.ntx; ++tx) {
+                    const unsigned long long off =
+                        ((unsigned long long)p.act_off + (unsigned long long)(ty * 4) * p.pitch + (unsigned long long)tx * TW) * G4::PIXB;
+                    const int vy = std::min(4, p.h - ty * 4), vx = std::min(TW, p.w - tx * TW);
+                    sched4.push_back(make_uint4((unsigned)off, (unsigned)(off >> 32), (unsigned)(p.pitch * G4::PIXB),
+                                                (unsigned)((vy << 8) | vx)));
+                }
+        HIP_TRY(hipMalloc((void**)&ws.d_sched4, sched4.size() * sizeof(uint4)));
+        HIP_TRY(hipMemcpyAsync(ws.d_sched4, sched4.data(), sched4.size() * sizeof(uint4), hipMemcpyHostToDevice, n->stream));
+    }
     HIP_TRY(hipStreamSynchronize(n->stream));
     n->wss.push_front(ws);
     *out = &n->wss.front();

@@ -111,6 +111,8 @@ struct ConvArgs {
     _Float16* sink;               // >= 64 pixels of scratch: where lanes outside the image store to
     int tile_base;                // trunk_kernel: first global work tile of this launch (huge frames
                                   // are split so that a workgroup's schedule fits its LDS table)
+    const uint4* sched4;          // trunk_kernel: per 4-row work tile {halo origin byte offset lo, hi, row pitch
+                                  // in bytes, (valid rows << 8) | valid columns}, built by the host per geometry
     int reverse;                  // walk the tiles last-to-first: consecutive layers alternate direction so
                                   // that a layer starts on what the previous one wrote last, i.e. on what is
                                   // still in the 256 MB Infinity Cache
@@ -739,6 +741,16 @@ __device__ __forceinline__ void trunk_issue_piece(const char* tile_base, int pit
     glds16_s(tile_base, off, lds_slot + trunk_piece_index<NF>(i, wave) * 1024);
 }
 
+// 16 bytes through the scalar cache: the address must be wave-uniform.  The constant address space
+// makes hipcc emit s_load_dwordx4 (its own counter, lgkmcnt) instead of a vector load + readfirstlane.
+__device__ __forceinline__ uint4 scalar_load16(const uint4* p)
+{
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef const u32x4 __attribute__((address_space(4))) * const_ptr;
+    const u32x4 v = *(const_ptr)(unsigned long long)p;
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
 __device__ __forceinline__ void group_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -790,47 +802,33 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
     const int niter1 = t0 + 1 < t_lim ? (t_lim - t0 - 1 + g8 - 1) / g8 : 0;
     const int niter = grp ? niter1 : niter0;
 
+    // Tile schedule of this workgroup: its entries of the host-built per-tile table (one 16-byte
+    // load per entry, requested before anything else) are copied into LDS, so the per-tile work
+    // needs one uniform LDS read instead of a plane search, and none of it sits in front of a k-loop.
+    const int nsched = 2 * niter0 + TRUNK_LOOKAHEAD;
+    auto sched_tile = [&](int k, bool& real) __attribute__((always_inline)) {
+        int t = t0 + (k & 1) + (k >> 1) * g8;
+        real = t < t_lim;
+        if (!real || ABL == 2) t = t0;                           // past the end: a harmless re-fetch
+        if (a.reverse) t = a.ntiles - 1 - t;
+        return t + a.tile_base;
+    };
+    uint4 sched_e0 = make_uint4(0, 0, 0, 0);
+    bool sched_real0 = false;
+    if ((int)threadIdx.x < nsched) sched_e0 = a.sched4[sched_tile(threadIdx.x, sched_real0)];
+    float prm_b = 0.f, prm_s = 0.f;
+    if (threadIdx.x < 64) { prm_b = a.bias[threadIdx.x]; prm_s = a.slope[threadIdx.x]; }
     // this wave's half of the layer's weights, resident in registers for the whole kernel.  Group 0
-    // requests them first of all, so that they stream in under the schedule build below.
+    // requests them right behind the schedule entries, so that they stream in under the first tiles'
+    // DMA issue below.
     half8 w[KS];
     if (grp == 0) {
 #pragma unroll
         for (int i = 0; i < KS; ++i) w[i] = a.wpk[((i >> 1) * 4 + 2 * mh + (i & 1)) * 64 + lane];
     }
-    if (threadIdx.x < 64) {
-        bias_lds[threadIdx.x] = a.bias[threadIdx.x];
-        const float sl = a.slope[threadIdx.x];
-        prm_lds[threadIdx.x] = sl;
-        prm_lds[64 + threadIdx.x] = sl <= 1.f ? __builtin_inff() : -__builtin_inff();
-    }
-    // Tile schedule of this workgroup, built once straight from the plane table in global memory
-    // (wave-uniform reads): entry k = {byte offset of the tile's halo origin inside the activation
-    // buffers (lo, hi), row pitch in bytes, (valid rows << 8) | valid columns}.  The per-tile work
-    // then needs one uniform 16-byte LDS read instead of a plane search, and none of it sits in
-    // front of the k-loop.
-    const int nsched = 2 * niter0 + TRUNK_LOOKAHEAD;
-    for (int k = threadIdx.x; k < nsched; k += 512) {
-        int t = t0 + (k & 1) + (k >> 1) * g8;
-        const bool real = t < t_lim;
-        if (!real || ABL == 2) t = t0;                       // past the end: a harmless re-fetch
-        if (a.reverse) t = a.ntiles - 1 - t;
-        t += a.tile_base;
-        int p = 0;
-        for (int q = 1; q < a.nplanes; ++q)
-            if (t >= a.planes[q].tile_begin4) p = q;
-        const PlaneDesc pl = a.planes[p];
-        const int local = t - pl.tile_begin4;
-        const int ty = local / pl.ntx, tx = local - (local / pl.ntx) * pl.ntx;
-        const unsigned long long off =
-            ((unsigned long long)pl.act_off + (unsigned long long)(ty * TH4) * pl.pitch + (unsigned long long)tx * TW) * G::PIXB;
-        const int vy = real ? min(TH4, pl.h - ty * TH4) : 0;
-        const int vx = real ? min(TW, pl.w - tx * TW) : 0;
-        sched_lds[k] = make_uint4((unsigned)off, (unsigned)(off >> 32), (unsigned)(pl.pitch * G::PIXB), (unsigned)((vy << 8) | vx));
-    }
     int dma_pc[CPW];
 #pragma unroll
     for (int i = 0; i < CPW; ++i) dma_pc[i] = trunk_piece_const<NF>(i, wave, lane);
-    __syncthreads();
     const unsigned long long t_sched = __builtin_amdgcn_s_memtime();
 
     // accumulator chains start from C = 0 (an inline constant, no registers); the bias is added in
@@ -851,21 +849,51 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
         r.vy = v >> 8; r.vx = v & 255;
         return r;
     };
-    // prologue: tiles 0 and 2 by group 0, tile 1 by group 1 (all pieces)
+    // prologue: tiles 0 and 2 by group 0, tile 1 by group 1 (all pieces).  Their schedule entries
+    // come straight from the global table through the scalar cache (wave-uniform addresses): scalar
+    // loads have their own counter, so the DMA issue does not queue behind the weights in flight.
+    auto sched_scalar = [&](int k) __attribute__((always_inline)) {
+        bool real;
+        const uint4 e = scalar_load16(a.sched4 + __builtin_amdgcn_readfirstlane(sched_tile(k, real)));
+        Sched r;
+        const unsigned lo = __builtin_amdgcn_readfirstlane(e.x), hi = __builtin_amdgcn_readfirstlane(e.y);
+        r.off = ((unsigned long long)hi << 32) | lo;
+        r.base = (const char*)a.in_act + r.off;
+        r.pitch = __builtin_amdgcn_readfirstlane(e.z);
+        r.vy = 0; r.vx = 0;
+        return r;
+    };
     {
-        const Sched s0 = read_sched(grp);
+        const Sched s0 = sched_scalar(grp);
 #pragma unroll
         for (int i = 0; i < CPW; ++i) trunk_issue_piece<NF>(s0.base, s0.pitch, lds0 + grp * SLOTB, i, wave, dma_pc[i]);
         if (grp == 0) {
-            const Sched s2 = read_sched(2);
+            const Sched s2 = sched_scalar(2);
 #pragma unroll
             for (int i = 0; i < CPW; ++i) trunk_issue_piece<NF>(s2.base, s2.pitch, lds0 + 2 * SLOTB, i, wave, dma_pc[i]);
         }
     }
+    const unsigned long long t_dma = __builtin_amdgcn_s_memtime();
+    // everything requested so far has landed -> publish the schedule table, then the workgroup barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int real0 = sched_real0;
+    asm volatile("" : "+v"(real0));     // keeps this select (and the load's wait) down here, behind the DMA issue
+    if (!real0) sched_e0.w = 0;
+    if ((int)threadIdx.x < nsched) sched_lds[threadIdx.x] = sched_e0;
+    for (int k = threadIdx.x + 512; k < nsched; k += 512) {   // huge frames only
+        bool real;
+        uint4 e = a.sched4[sched_tile(k, real)];
+        if (!real) e.w = 0;
+        sched_lds[k] = e;
+    }
+    if (threadIdx.x < 64) {
+        bias_lds[threadIdx.x] = prm_b;
+        prm_lds[threadIdx.x] = prm_s;
+        prm_lds[64 + threadIdx.x] = prm_s <= 1.f ? __builtin_inff() : -__builtin_inff();
+    }
+    tile_barrier<0>();
     // Group 1 starts half a period later: it fetches its weights during that wait and leaves the
     // CU's load path to group 0 until then.
-    const unsigned long long t_dma = __builtin_amdgcn_s_memtime();
-    tile_barrier<0>();
     if (grp == 1) {
 #pragma unroll
         for (int i = 0; i < KS; ++i) w[i] = a.wpk[((i >> 1) * 4 + 2 * mh + (i & 1)) * 64 + lane];
