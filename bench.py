@@ -28,6 +28,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16
+# What the matrix pipes alone sustain at the 1400 W package cap with non-zero operands (nothing but
+# register-operand v_mfma_f32_16x16x32_f16 on all 1024 SIMDs; tools/mfma_power_bench.hip, measured in
+# profiles/r01_d_mfma_power_bench.txt).  The trunk kernel runs with the package pinned at the cap, so
+# this -- not the 2.4 GHz figure above -- is the roof it can actually approach.  Informational only:
+# `peak` / `frac` stay on the nominal figure.
+MFMA_F16_SUSTAINED_AT_POWER_CAP_TFLOPS = 1880.0
 
 WORKLOADS = {
     # name: (model key, model file stem, height, width)  -- BASELINE.json configs[1..4]
@@ -93,11 +99,12 @@ def pmc_traffic(args, nf):
     separate runs of this command on the same build, FETCH_SIZE doubled per MI355X_MICROARCH.md's
     gfx950 correction); bench.py cannot run the profiler on itself, so the committed summary of the
     matching workload is reported, or null when there is none."""
-    path = os.path.join(ROOT, "profiles", "r01_b_trunk_pmc.json")
-    if args.workload != "2x_compact_1080p" or args.tile != 960 or nf != 64 or not os.path.exists(path):
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_trunk_pmc.json")))   # latest round/letter last
+    if args.workload != "2x_compact_1080p" or args.tile != 960 or nf != 64 or not paths:
         return None
     try:
-        return int(json.load(open(path))["hbm_bytes_per_launch"])
+        return int(json.load(open(paths[-1]))["hbm_bytes_per_launch"])
     except Exception:  # noqa: BLE001
         return None
 
@@ -247,6 +254,8 @@ def main():
                 "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": pmc_traffic(args, nf),
                 "flops_per_launch": trunk_flops_per_launch, "avg_launch_ms": round(avg_ms, 4), "launches": n_launch,
+                "peak_sustained_at_power_cap": MFMA_F16_SUSTAINED_AT_POWER_CAP_TFLOPS,
+                "frac_of_sustained": round(achieved / MFMA_F16_SUSTAINED_AT_POWER_CAP_TFLOPS, 4) if nf == 64 else None,
             },
         }
         if world == 1:
