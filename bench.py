@@ -259,14 +259,35 @@ def main():
             },
         }
         if world == 1:
-            # informational: the host-pointer route of the C ABI (pageable numpy in/out, pinned staging,
-            # H2D + kernels + D2H, synchronous) -- what one reference worker calls per frame; never `value`
+            # informational, never `value`: the host-pointer routes of the C ABI, PCIe inclusive.
+            #  (E) frames in page-locked host memory, pipelined submit/collect: H2D, kernels and D2H of
+            #      consecutive frames overlap (SURVEY.md 8d "host-to-host with stream overlap")
+            #  sync: pageable numpy in/out, one synchronous call per frame (what one reference worker does)
             host_in = frames[0].cpu().numpy()
             net.process_u8(host_in, tile_size=args.tile, border=10)
             t0 = time.perf_counter()
             for _ in range(5):
                 net.process_u8(host_in, tile_size=args.tile, border=10)
-            result["config"]["host_route_fps_pcie_inclusive"] = round(5 / (time.perf_counter() - t0), 2)
+            result["config"]["host_route_sync_pageable_fps"] = round(5 / (time.perf_counter() - t0), 2)
+            depth, n_host = 3, 60
+            pin_in = [ncnn.pinned_empty((h, w, 3)) for _ in range(depth)]
+            pin_out = [ncnn.pinned_empty((h * s, w * s, 3)) for _ in range(depth)]
+            for b in pin_in:
+                b[...] = host_in
+            def host_pipeline(n_frames):
+                inflight = []
+                for i in range(n_frames):
+                    if len(inflight) == depth:
+                        net.collect_u8(inflight.pop(0))
+                    inflight.append(net.submit_u8(pin_in[i % depth], out=pin_out[i % depth], tile_size=args.tile, border=10))
+                while inflight:
+                    net.collect_u8(inflight.pop(0))
+            host_pipeline(6)
+            t0 = time.perf_counter()
+            host_pipeline(n_host)
+            result["config"]["host_route_fps_pcie_inclusive"] = round(n_host / (time.perf_counter() - t0), 2)
+            ref_out = net.process_u8(host_in, tile_size=args.tile, border=10)
+            assert np.array_equal(pin_out[(n_host - 1) % depth], ref_out), "pipelined host route differs from the synchronous one"
             result["parity"] = parity_probe(net, key, args.tile) if pre is None else chain_parity_probe(pre, net)
             if not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(key, h, w, args.tile)

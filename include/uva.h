@@ -82,6 +82,20 @@ int uva_net_extract_f32(uva_net* net, const float* in_chw, int h, int w, float* 
 int uva_net_process_u8(uva_net* net, const uint8_t* in, int h, int w, size_t in_stride,
                        uint8_t* out, size_t out_stride, int tile_size, int border);
 
+/* Pipelined form of uva_net_process_u8 for callers that stream frames (SURVEY.md 8d "host-to-host
+ * with stream overlap"): submit returns at once with a ticket >= 0 (-1 on error); the frame's H2D
+ * copy, kernels and D2H copy run on three streams, so consecutive frames overlap.  At most 3 frames
+ * may be in flight; tickets are collected in any order.  `in` must stay valid until submit returns
+ * when it is pageable (it is staged) and until collect returns when it is pinned (uva_host_alloc,
+ * hipHostMalloc, hipHostRegister: copied from directly); `out` must stay valid until collect
+ * returns, which is when it holds the result.  uva_net_process_u8 == submit + collect. */
+long long uva_net_submit_u8(uva_net* net, const uint8_t* in, int h, int w, size_t in_stride,
+                            uint8_t* out, size_t out_stride, int tile_size, int border);
+int uva_net_collect_u8(uva_net* net, long long ticket);
+/* Page-locked host memory for frames handed to the two calls above (no staging copy). */
+void* uva_host_alloc(size_t bytes);
+void uva_host_free(void* p);
+
 /* Same, with in/out already resident in this device's HBM (dense rows: in_stride = 3*w,
  * out_stride = 3*w*s unless stated).  Asynchronous on the net's stream; follow with
  * uva_net_synchronize().  This is the call bench.py times. */

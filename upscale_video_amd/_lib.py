@@ -11,7 +11,7 @@ SYMBOLS = [
     "uva_net_create", "uva_net_set_device", "uva_net_load_param", "uva_net_load_model",
     "uva_net_destroy", "uva_net_scale", "uva_net_num_features", "uva_net_num_convs",
     "uva_net_extract_f32", "uva_net_process_u8", "uva_net_process_u8_device", "uva_net_synchronize",
-    "uva_net_wait_for",
+    "uva_net_wait_for", "uva_net_submit_u8", "uva_net_collect_u8", "uva_host_alloc", "uva_host_free",
     "uva_net_debug_read_activation", "uva_net_set_profiling", "uva_net_kernel_stats",
     "uva_net_debug_packed_weights", "uva_net_debug_trunk_stamps", "uva_last_error", "uva_abi_version",
 ]
@@ -51,6 +51,13 @@ def load():
     L.uva_net_wait_for.argtypes = [c_p, c_p]
     L.uva_net_extract_f32.argtypes = [c_p, c_p, c_i, c_i, c_p]
     L.uva_net_process_u8.argtypes = [c_p, c_p, c_i, c_i, c_sz, c_p, c_sz, c_i, c_i]
+    L.uva_net_submit_u8.argtypes = [c_p, c_p, c_i, c_i, c_sz, c_p, c_sz, c_i, c_i]
+    L.uva_net_submit_u8.restype = ctypes.c_longlong
+    L.uva_net_collect_u8.argtypes = [c_p, ctypes.c_longlong]
+    L.uva_host_alloc.argtypes = [c_sz]
+    L.uva_host_alloc.restype = c_p
+    L.uva_host_free.argtypes = [c_p]
+    L.uva_host_free.restype = None
     L.uva_net_process_u8_device.argtypes = [c_p, c_p, c_i, c_i, c_sz, c_p, c_sz, c_i, c_i]
     L.uva_net_debug_read_activation.argtypes = [c_p, c_i, c_p, c_i, c_i]
     L.uva_net_set_profiling.argtypes = [c_p, c_i]

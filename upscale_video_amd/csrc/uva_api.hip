@@ -73,6 +73,8 @@ struct LastCall {
     bool f32 = false;
     const void* src = nullptr;
     size_t src_stride = 0;
+    void* dst = nullptr;       // u8 route: device result buffer of the call
+    size_t dst_stride = 0;
 };
 
 std::mutex g_nets_mu;
@@ -88,13 +90,27 @@ struct uva_net {
     hipStream_t stream = nullptr;
     std::vector<DeviceLayer> layers;
     std::list<Workspace> wss;   // most recently used first
-    // staging for the host-pointer entry points
-    uint8_t *h_in = nullptr, *h_out = nullptr, *d_in = nullptr, *d_out = nullptr;
-    size_t h_in_cap = 0, h_out_cap = 0, d_in_cap = 0, d_out_cap = 0;
+    // staging for the f32 (Extractor) entry point
     float *d_fin = nullptr, *d_fout = nullptr;
     size_t d_fin_cap = 0, d_fout_cap = 0;
     _Float16* d_sink = nullptr;   // where out-of-image lanes of the trunk kernel store to
     LastCall last;
+    // pipelined host route (uva_net_submit_u8 / uva_net_collect_u8): H2D, kernels and D2H of
+    // consecutive frames overlap on three streams; PIPE_SLOTS frames may be in flight
+    static constexpr int PIPE_SLOTS = 3;
+    struct PipeSlot {
+        bool busy = false;
+        long long ticket = -1;
+        uint8_t *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;   // h_*: pinned staging
+        size_t d_in_cap = 0, d_out_cap = 0, h_in_cap = 0, h_out_cap = 0;
+        hipEvent_t ev_h2d = nullptr, ev_done = nullptr, ev_d2h = nullptr;
+        uint8_t* user_out = nullptr;     // where collect copies the staged result (null: D2H went there directly)
+        size_t user_out_stride = 0, out_row = 0;
+        int out_rows = 0;
+    };
+    PipeSlot pipe[PIPE_SLOTS];
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    long long next_ticket = 0;
     // profiling
     bool prof = false;
     std::vector<hipEvent_t> ev_free;
@@ -116,17 +132,27 @@ struct uva_net {
         layers.clear();
         for (auto& w : wss) w.release();
         wss.clear();
-        if (h_in) (void)hipHostFree(h_in);
-        if (h_out) (void)hipHostFree(h_out);
-        if (d_in) (void)hipFree(d_in);
-        if (d_out) (void)hipFree(d_out);
         if (d_fin) (void)hipFree(d_fin);
         if (d_fout) (void)hipFree(d_fout);
         if (d_sink) (void)hipFree(d_sink);
         d_sink = nullptr;
-        h_in = h_out = d_in = d_out = nullptr;
+        if (s_h2d) (void)hipStreamSynchronize(s_h2d);
+        if (s_d2h) (void)hipStreamSynchronize(s_d2h);
+        for (auto& ps : pipe) {
+            if (ps.d_in) (void)hipFree(ps.d_in);
+            if (ps.d_out) (void)hipFree(ps.d_out);
+            if (ps.h_in) (void)hipHostFree(ps.h_in);
+            if (ps.h_out) (void)hipHostFree(ps.h_out);
+            if (ps.ev_h2d) (void)hipEventDestroy(ps.ev_h2d);
+            if (ps.ev_done) (void)hipEventDestroy(ps.ev_done);
+            if (ps.ev_d2h) (void)hipEventDestroy(ps.ev_d2h);
+            ps = PipeSlot();
+        }
+        if (s_h2d) (void)hipStreamDestroy(s_h2d);
+        if (s_d2h) (void)hipStreamDestroy(s_d2h);
+        s_h2d = s_d2h = nullptr;
         d_fin = d_fout = nullptr;
-        h_in_cap = h_out_cap = d_in_cap = d_out_cap = d_fin_cap = d_fout_cap = 0;
+        d_fin_cap = d_fout_cap = 0;
         for (auto& s : ev_pending)
             for (auto e : s.e) (void)hipEventDestroy(e);
         ev_pending.clear();
@@ -608,6 +634,7 @@ int uva_net_synchronize(uva_net* n)
     if (!n->dev_ready) return 0;
     HIP_TRY(hipSetDevice(n->device));
     HIP_TRY(hipStreamSynchronize(n->stream));
+    if (n->s_d2h) HIP_TRY(hipStreamSynchronize(n->s_d2h));   // in-flight pipelined frames (results stay collectable)
     resolve_events(n);
     return 0;
 }
@@ -635,28 +662,118 @@ int uva_net_process_u8_device(uva_net* n, const void* d_in, int h, int w, size_t
     Workspace* ws = nullptr;
     if (get_workspace(n, h, w, tile_size, border, &ws)) return 1;
     n->last.valid = true; n->last.ws = ws; n->last.f32 = false; n->last.src = d_in; n->last.src_stride = in_stride;
+    n->last.dst = d_out; n->last.dst_stride = out_stride;
     return run_graph(n, ws, false, d_in, in_stride, d_out, out_stride, -1);
+}
+
+// ---- pipelined host route -----------------------------------------------------------------------
+namespace {
+bool is_pinned_host(const void* p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();   // an ordinary malloc'ed pointer: not an error
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+}  // namespace
+
+void* uva_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        fail("uva_host_alloc: hipHostMalloc failed");
+        return nullptr;
+    }
+    return p;
+}
+
+void uva_host_free(void* p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
+long long uva_net_submit_u8(uva_net* n, const uint8_t* in, int h, int w, size_t in_stride, uint8_t* out,
+                            size_t out_stride, int tile_size, int border)
+{
+    if (check_dims(n, h, w)) return -1;
+    if (!in || !out) { fail("null frame pointer"); return -1; }
+    if (ensure_device(n)) return -1;
+    auto tryhip = [](hipError_t e, const char* what) { return e == hipSuccess ? 0 : fail(std::string(what) + ": " + hipGetErrorString(e)); };
+    const int s = n->g.scale;
+    const size_t in_row = (size_t)w * 3, out_row = (size_t)w * s * 3;
+    if (in_stride < in_row || out_stride < out_row) { fail("row stride too small"); return -1; }
+    const size_t in_bytes = in_row * h, out_bytes = out_row * (size_t)h * s;
+    uva_net::PipeSlot* free_slot = nullptr;
+    for (auto& c : n->pipe)
+        if (!c.busy) { free_slot = &c; break; }
+    if (!free_slot) { fail("uva_net_submit_u8: " + std::to_string(uva_net::PIPE_SLOTS) + " frames already in flight, collect one first"); return -1; }
+    uva_net::PipeSlot& ps = *free_slot;
+    if (!n->s_h2d) {
+        if (tryhip(hipStreamCreateWithFlags(&n->s_h2d, hipStreamNonBlocking), "hipStreamCreate") ||
+            tryhip(hipStreamCreateWithFlags(&n->s_d2h, hipStreamNonBlocking), "hipStreamCreate")) return -1;
+    }
+    if (!ps.ev_h2d) {
+        if (tryhip(hipEventCreateWithFlags(&ps.ev_h2d, hipEventDisableTiming), "hipEventCreate") ||
+            tryhip(hipEventCreateWithFlags(&ps.ev_done, hipEventDisableTiming), "hipEventCreate") ||
+            tryhip(hipEventCreateWithFlags(&ps.ev_d2h, hipEventDisableTiming), "hipEventCreate")) return -1;
+    }
+    if (grow_dev(&ps.d_in, &ps.d_in_cap, in_bytes) || grow_dev(&ps.d_out, &ps.d_out_cap, out_bytes)) return -1;
+    // H2D: straight from the caller's buffer when it is pinned (uva_host_alloc / hipHostMalloc /
+    // hipHostRegister), through this slot's pinned staging buffer otherwise
+    const uint8_t* src = in;
+    size_t src_stride = in_stride;
+    if (!is_pinned_host(in)) {
+        if (grow_host(&ps.h_in, &ps.h_in_cap, in_bytes)) return -1;
+        for (int y = 0; y < h; ++y) std::memcpy(ps.h_in + y * in_row, in + y * in_stride, in_row);
+        src = ps.h_in; src_stride = in_row;
+    }
+    if (tryhip(hipMemcpy2DAsync(ps.d_in, in_row, src, src_stride, in_row, h, hipMemcpyHostToDevice, n->s_h2d), "H2D") ||
+        tryhip(hipEventRecord(ps.ev_h2d, n->s_h2d), "hipEventRecord") ||
+        tryhip(hipStreamWaitEvent(n->stream, ps.ev_h2d, 0), "hipStreamWaitEvent")) return -1;
+    if (uva_net_process_u8_device(n, ps.d_in, h, w, in_row, ps.d_out, out_row, tile_size, border)) return -1;
+    if (tryhip(hipEventRecord(ps.ev_done, n->stream), "hipEventRecord") ||
+        tryhip(hipStreamWaitEvent(n->s_d2h, ps.ev_done, 0), "hipStreamWaitEvent")) return -1;
+    uint8_t* dst = out;
+    size_t dst_stride = out_stride;
+    ps.user_out = nullptr;
+    if (!is_pinned_host(out)) {
+        if (grow_host(&ps.h_out, &ps.h_out_cap, out_bytes)) return -1;
+        dst = ps.h_out; dst_stride = out_row;
+        ps.user_out = out; ps.user_out_stride = out_stride; ps.out_row = out_row; ps.out_rows = h * s;
+    }
+    if (tryhip(hipMemcpy2DAsync(dst, dst_stride, ps.d_out, out_row, out_row, (size_t)h * s, hipMemcpyDeviceToHost, n->s_d2h), "D2H") ||
+        tryhip(hipEventRecord(ps.ev_d2h, n->s_d2h), "hipEventRecord")) return -1;
+    ps.busy = true;
+    ps.ticket = n->next_ticket;
+    return n->next_ticket++;
+}
+
+int uva_net_collect_u8(uva_net* n, long long ticket)
+{
+    if (!n || ticket < 0) return fail("bad ticket");
+    uva_net::PipeSlot* slot = nullptr;
+    for (auto& c : n->pipe)
+        if (c.busy && c.ticket == ticket) slot = &c;
+    if (!slot) return fail("uva_net_collect_u8: ticket " + std::to_string(ticket) + " is not in flight");
+    uva_net::PipeSlot& ps = *slot;
+    HIP_TRY(hipSetDevice(n->device));
+    HIP_TRY(hipEventSynchronize(ps.ev_d2h));
+    if (ps.user_out)
+        for (int y = 0; y < ps.out_rows; ++y)
+            std::memcpy(ps.user_out + (size_t)y * ps.user_out_stride, ps.h_out + (size_t)y * ps.out_row, ps.out_row);
+    ps.busy = false;
+    return 0;
 }
 
 int uva_net_process_u8(uva_net* n, const uint8_t* in, int h, int w, size_t in_stride, uint8_t* out,
                        size_t out_stride, int tile_size, int border)
 {
-    if (check_dims(n, h, w)) return 1;
-    if (!in || !out) return fail("null frame pointer");
-    if (ensure_device(n)) return 1;
-    const int s = n->g.scale;
-    const size_t in_row = (size_t)w * 3, out_row = (size_t)w * s * 3;
-    if (in_stride < in_row || out_stride < out_row) return fail("row stride too small");
-    const size_t in_bytes = in_row * h, out_bytes = out_row * (size_t)h * s;
-    if (grow_host(&n->h_in, &n->h_in_cap, in_bytes) || grow_host(&n->h_out, &n->h_out_cap, out_bytes) ||
-        grow_dev(&n->d_in, &n->d_in_cap, in_bytes) || grow_dev(&n->d_out, &n->d_out_cap, out_bytes))
-        return 1;
-    for (int y = 0; y < h; ++y) std::memcpy(n->h_in + y * in_row, in + y * in_stride, in_row);
-    HIP_TRY(hipMemcpyAsync(n->d_in, n->h_in, in_bytes, hipMemcpyHostToDevice, n->stream));
-    if (uva_net_process_u8_device(n, n->d_in, h, w, in_row, n->d_out, out_row, tile_size, border)) return 1;
-    HIP_TRY(hipMemcpyAsync(n->h_out, n->d_out, out_bytes, hipMemcpyDeviceToHost, n->stream));
-    if (uva_net_synchronize(n)) return 1;
-    for (int y = 0; y < h * s; ++y) std::memcpy(out + y * out_stride, n->h_out + y * out_row, out_row);
+    const long long t = uva_net_submit_u8(n, in, h, w, in_stride, out, out_stride, tile_size, border);
+    if (t < 0) return 1;
+    if (uva_net_collect_u8(n, t)) return 1;
+    resolve_events(n);
     return 0;
 }
 
@@ -755,7 +872,7 @@ int uva_net_debug_trunk_stamps(uva_net* n, unsigned long long* out, int max_tile
     HIP_TRY(hipEventCreate(&e1));
     if (ablate == 3) {
         // the u8 tail kernel of the last host-route call instead of a trunk layer
-        if (n->last.f32 || !n->d_out) { (void)hipFree(d); return fail("tail stamps need a previous uva_net_process_u8 call"); }
+        if (n->last.f32 || !n->last.dst) { (void)hipFree(d); return fail("tail stamps need a previous uva_net_process_u8 call"); }
         const int nconv = (int)n->g.convs.size();
         ca.in_act = ws->act[(nconv - 2) & 1];
         ca.out_act = nullptr;
@@ -764,8 +881,8 @@ int uva_net_debug_trunk_stamps(uva_net* n, unsigned long long* out, int max_tile
         ca.slope = nullptr;
         ca.src_u8 = (const uint8_t*)n->last.src;
         ca.src_stride = n->last.src_stride;
-        ca.dst_u8 = n->d_out;
-        ca.dst_stride = (size_t)ws->w * n->g.scale * 3;
+        ca.dst_u8 = (uint8_t*)n->last.dst;
+        ca.dst_stride = n->last.dst_stride;
         int rc3 = launch_conv(n, 1, ca);
         ca.dbg = nullptr;
         HIP_TRY(hipEventRecord(e0, n->stream));

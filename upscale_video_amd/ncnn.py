@@ -58,6 +58,29 @@ def destroy_gpu_instance():
     _lib.load().uva_destroy_gpu_instance()
 
 
+def pinned_empty(shape, dtype=np.uint8):
+    """numpy array in page-locked host memory (include/uva.h uva_host_alloc): frames held in such
+    arrays are copied to / from the GPU without a staging copy by Net.submit_u8 / process_u8."""
+    L = _lib.load()
+    dt = np.dtype(dtype)
+    nbytes = int(np.prod(shape)) * dt.itemsize
+    ptr = L.uva_host_alloc(max(1, nbytes))
+    if not ptr:
+        raise _lib.UvaError(L.uva_last_error().decode(errors="replace"))
+    buf = (ctypes.c_ubyte * max(1, nbytes)).from_address(ptr)
+    arr = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+    import weakref
+    weakref.finalize(buf, L.uva_host_free, ptr)     # freed when the last view of the buffer dies
+    return arr
+
+
+class Ticket:
+    """One frame in flight on the pipelined host route; keeps its buffers alive."""
+
+    def __init__(self, tid, img, out):
+        self.id, self._img, self.out = tid, img, out
+
+
 class Mat:
     """Host f32 planar [c][h][w] image, the subset of ncnn::Mat the reference uses."""
 
@@ -190,6 +213,32 @@ class Net:
         _lib.check(self._L.uva_net_process_u8(self._h, img.ctypes.data, h, w, w * 3, out.ctypes.data,
                                               w * s * 3, int(tile_size), int(border)))
         return out
+
+    def submit_u8(self, img_bgr, out=None, tile_size=0, border=0):
+        """Pipelined process_u8 (include/uva.h uva_net_submit_u8): returns a Ticket at once; up to 3
+        frames may be in flight and their H2D copy, kernels and D2H copy overlap.  `out`: optional
+        preallocated u8 [h*s][w*s][3] array (pinned_empty avoids the staging copy)."""
+        img = np.ascontiguousarray(img_bgr, dtype=np.uint8)
+        if img.ndim != 3 or img.shape[2] != 3:
+            raise ValueError("frame must be u8 [h][w][3]")
+        s = self.scale
+        if s <= 0:
+            raise _lib.UvaError("net has no graph: load_param/load_model failed or were not called")
+        h, w, _ = img.shape
+        if out is None:
+            out = np.empty((h * s, w * s, 3), np.uint8)
+        if out.dtype != np.uint8 or out.shape != (h * s, w * s, 3) or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous u8 [h*s][w*s][3] array")
+        t = self._L.uva_net_submit_u8(self._h, img.ctypes.data, h, w, w * 3, out.ctypes.data, w * s * 3,
+                                      int(tile_size), int(border))
+        if t < 0:
+            raise _lib.UvaError(self._L.uva_last_error().decode(errors="replace"))
+        return Ticket(t, img, out)
+
+    def collect_u8(self, ticket):
+        """Waits for the frame of `ticket` and returns its u8 result array."""
+        _lib.check(self._L.uva_net_collect_u8(self._h, ticket.id))
+        return ticket.out
 
     def process_u8_device(self, d_in, h, w, d_out, tile_size=0, border=0, in_stride=None, out_stride=None):
         """Asynchronous: raw device pointers (ints) of dense u8 HWC frames in this GPU's HBM."""
