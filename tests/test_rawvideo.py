@@ -1,0 +1,95 @@
+"""rawvideo streamer (upscale_video_amd/rawvideo.py): host logic on CPU with a stand-in net, the real
+engine under -m gpu."""
+import io
+
+import numpy as np
+import pytest
+
+from upscale_video_amd import rawvideo
+
+
+class FakeNet:
+    """Stand-in with the Net.submit_u8 / collect_u8 contract: nearest-neighbour upscale + 1, finished
+    only at collect time (so that buffer-reuse mistakes show up)."""
+
+    def __init__(self, scale):
+        self.scale = scale
+        self.live = 0
+
+    def submit_u8(self, img, out=None, tile_size=0, border=0):
+        assert self.live < 3, "more than 3 frames in flight"
+        self.live += 1
+        return (img, out)                      # keeps a VIEW of the input: it must still be intact at collect
+
+    def collect_u8(self, t):
+        img, out = t
+        self.live -= 1
+        out[...] = np.repeat(np.repeat(img, self.scale, 0), self.scale, 1) + 1
+        return out
+
+
+def _frames(n, h, w):
+    rng = np.random.default_rng(7)
+    return [rng.integers(0, 200, (h, w, 3), dtype=np.uint8) for _ in range(n)]
+
+
+@pytest.mark.parametrize("nframes", [0, 1, 2, 3, 4, 11, 23])
+def test_stream_order_and_buffer_lifetimes_two_stages(nframes):
+    h, w = 6, 10
+    frames = _frames(nframes, h, w)
+    fin = io.BytesIO(b"".join(f.tobytes() for f in frames))
+    fout = io.BytesIO()
+    alloc = lambda shape: np.empty(shape, np.uint8)   # noqa: E731
+    n = rawvideo.stream(fin, fout, h, w, [(FakeNet(1), 0), (FakeNet(2), 960)], alloc=alloc)
+    assert n == nframes
+    got = np.frombuffer(fout.getvalue(), np.uint8).reshape(nframes, 2 * h, 2 * w, 3)
+    for i, f in enumerate(frames):
+        want = np.repeat(np.repeat(f + 1, 2, 0), 2, 1) + 1
+        assert np.array_equal(got[i], want), i
+
+
+def test_torn_last_frame_is_an_error():
+    h, w = 4, 4
+    fin = io.BytesIO(_frames(2, h, w)[0].tobytes() + b"\x00" * 10)
+    with pytest.raises(EOFError, match="inside a frame"):
+        rawvideo.stream(fin, io.BytesIO(), h, w, [(FakeNet(2), 0)], alloc=lambda s: np.empty(s, np.uint8))
+
+
+def test_max_frames_and_writer_errors():
+    h, w = 4, 4
+    data = b"".join(f.tobytes() for f in _frames(9, h, w))
+    fout = io.BytesIO()
+    assert rawvideo.stream(io.BytesIO(data), fout, h, w, [(FakeNet(2), 0)], alloc=lambda s: np.empty(s, np.uint8), max_frames=5) == 5
+    assert len(fout.getvalue()) == 5 * 4 * h * w * 3
+
+    class Broken(io.RawIOBase):
+        def write(self, b):
+            raise BrokenPipeError("downstream closed")
+
+    with pytest.raises(BrokenPipeError):
+        rawvideo.stream(io.BytesIO(data), Broken(), h, w, [(FakeNet(2), 0)], alloc=lambda s: np.empty(s, np.uint8))
+
+
+def test_cli_rejects_models_that_are_not_on_the_path(capsys):
+    with pytest.raises(SystemExit):
+        rawvideo.main(["-W", "8", "-H", "8", "-m", "r"])
+    assert "weights missing" in capsys.readouterr().err
+
+
+@pytest.mark.gpu
+def test_stream_equals_per_frame_calls(tmp_path):
+    import torch  # noqa: F401  (its HIP runtime first, see test_gpu_parity.py)
+    from conftest import load_net
+    from upscale_video_amd import ncnn
+    from oracle import uvoracle
+    h, w, n = 72, 112, 7
+    frames = [uvoracle.synthetic_frame(h, w, seed=50 + i) for i in range(n)]
+    src = tmp_path / "in.bgr24"
+    src.write_bytes(b"".join(f.tobytes() for f in frames))
+    dst = tmp_path / "out.bgr24"
+    assert rawvideo.main(["-i", str(src), "-o", str(dst), "-W", str(w), "-H", str(h), "-s", "2", "-m", "a", "--tile", "32"]) == 0
+    got = np.frombuffer(dst.read_bytes(), np.uint8).reshape(n, 2 * h, 2 * w, 3)
+    pre, net = load_net(ncnn, "1x"), load_net(ncnn, "2x")
+    for i, f in enumerate(frames):
+        want = net.process_u8(pre.process_u8(f), tile_size=32, border=10)
+        assert np.array_equal(got[i], want), i

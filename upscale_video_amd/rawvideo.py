@@ -1,0 +1,195 @@
+"""rawvideo.py -- stream bgr24 frames through the MI355X engine.
+
+The reference moves every frame through PNG files on both sides of the net (ffmpeg writes
+`%d.extract.png`, upscale/upscale_processing.py:203-255; workers imread / imwrite, :263,288,487,519;
+ffmpeg re-reads `%d.png`, :604-640) and the PNG codecs, not the GPU, bound its file-to-file rate.
+This module is the same per-frame arithmetic fed by a raw pipe instead, ffmpeg itself untouched:
+
+    ffmpeg -i in.mkv -f rawvideo -pix_fmt bgr24 - \\
+      | python -m upscale_video_amd.rawvideo -W 1920 -H 1080 -s 2 \\
+      | ffmpeg -f rawvideo -pix_fmt bgr24 -s 3840x2160 -r 24 -i - out.mkv
+
+Frames go through Net.submit_u8 / collect_u8 (include/uva.h): page-locked rings on the host, H2D copy,
+kernels and D2H copy of consecutive frames overlapped on three streams.  `-m a` runs the reference's
+anime pass first (1x HurrDeblur, whole frame, re-quantised to u8 exactly like the PNG hop of
+upscale_processing.py:909), then the 2x/4x net with the reference's 960-px tiles.
+
+Flags follow upscale_video.py where they mean the same thing: -s/--scale 1|2|4, -m/--models a,
+-g/--gpu one HIP ordinal.
+"""
+import argparse
+import os
+import sys
+import threading
+import queue
+
+import numpy as np
+
+from . import ncnn
+from .upscale_processing import TILE_BORDER, TILE_SIZE
+
+MODEL_FILES = {  # upscale/upscale_processing.py:880-916
+    1: "1x_HurrDeblur_SubCompact_nf24-nc8_244k_net_g",
+    2: "2x_Compact_Pretrain",
+    4: "4x_Compact_Pretrain",
+}
+PIPE_DEPTH = 3   # include/uva.h: at most 3 frames in flight per net
+
+
+def load_net(stem, gpu, model_path):
+    net = ncnn.Net()
+    net.opt.use_vulkan_compute = True
+    net.set_vulkan_device(gpu)
+    base = os.path.join(model_path, stem)
+    if net.load_param(base + ".param") != 0 or net.load_model(base + ".bin") != 0:
+        raise RuntimeError(getattr(net, "last_error", "cannot load " + base))
+    return net
+
+
+def read_exact(f, view):
+    """Fill `view` from f; returns False on a clean EOF before the first byte, raises on a torn frame."""
+    got = 0
+    n = len(view)
+    while got < n:
+        k = f.readinto(view[got:])
+        if not k:
+            if got == 0:
+                return False
+            raise EOFError("input ended inside a frame (%d of %d bytes)" % (got, n))
+        got += k
+    return True
+
+
+class Stage:
+    """One net with its own ring of page-locked result buffers and up to PIPE_DEPTH frames in flight."""
+
+    def __init__(self, net, h, w, tile_size, alloc):
+        self.net, self.tile = net, tile_size
+        s = net.scale
+        # A result buffer stays in use while its frame is in flight here (<= depth frames) and then
+        # while the consumer holds it -- the next stage reads it as pinned input until that stage's
+        # collect (<= depth frames), or the writer thread (queue of 2 + 1 being written).  Frames stay
+        # in order, so 2*depth + 2 buffers can never wrap onto a live one.
+        self.outs = [alloc((h * s, w * s, 3)) for _ in range(2 * PIPE_DEPTH + 2)]
+        self.n = 0
+        self.inflight = []
+
+    def full(self):
+        return len(self.inflight) >= PIPE_DEPTH
+
+    def submit(self, frame):
+        out = self.outs[self.n % len(self.outs)]
+        self.n += 1
+        self.inflight.append(self.net.submit_u8(frame, out=out, tile_size=self.tile, border=TILE_BORDER if self.tile else 0))
+
+    def collect(self):
+        return self.net.collect_u8(self.inflight.pop(0))
+
+
+def stream(fin, fout, h, w, nets_tiles, alloc=None, max_frames=None):
+    """Reads u8 [h][w][3] frames from fin until EOF, pushes each through the nets in order, writes the
+    results to fout.  nets_tiles: list of (Net, tile_size).  Returns the number of frames written."""
+    alloc = alloc or ncnn.pinned_empty
+    stages = []
+    sh, sw = h, w
+    for net, tile in nets_tiles:
+        stages.append(Stage(net, sh, sw, tile, alloc))
+        sh, sw = sh * net.scale, sw * net.scale
+    ins = [alloc((h, w, 3)) for _ in range(PIPE_DEPTH + 2)]
+
+    # writer thread: the blocking write of frame i overlaps the read of frame i+k and the GPU
+    wq = queue.Queue(maxsize=2)
+    werr = []
+
+    def writer():
+        try:
+            while True:
+                item = wq.get()
+                if item is None:
+                    return
+                fout.write(memoryview(item).cast("B"))
+        except Exception as e:  # noqa: BLE001
+            werr.append(e)
+            while wq.get() is not None:
+                pass
+
+    wt = threading.Thread(target=writer, daemon=True)
+    wt.start()
+    written = 0
+
+    def drain(k, everything):
+        """Advance stage k: move finished frames on to stage k+1 (or the writer)."""
+        nonlocal written
+        st = stages[k]
+        while st.inflight and (everything or st.full()):
+            res = st.collect()
+            if k + 1 < len(stages):
+                if stages[k + 1].full():
+                    drain(k + 1, False)
+                stages[k + 1].submit(res)
+            else:
+                if werr:
+                    raise werr[0]
+                wq.put(res)
+                written += 1
+
+    n_in = 0
+    try:
+        while max_frames is None or n_in < max_frames:
+            buf = ins[n_in % len(ins)]
+            if not read_exact(fin, memoryview(buf).cast("B")):
+                break
+            if stages[0].full():
+                drain(0, False)
+            stages[0].submit(buf)
+            n_in += 1
+        for k in range(len(stages)):
+            drain(k, True)
+    finally:
+        wq.put(None)
+        wt.join()
+    if werr:
+        raise werr[0]
+    fout.flush()
+    return written
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    ap.add_argument("-i", "--input", default="-", help="bgr24 rawvideo file, '-' = stdin")
+    ap.add_argument("-o", "--output", default="-", help="bgr24 rawvideo file, '-' = stdout")
+    ap.add_argument("-W", "--width", type=int, required=True)
+    ap.add_argument("-H", "--height", type=int, required=True)
+    ap.add_argument("-s", "--scale", type=int, default=2, choices=[1, 2, 4])
+    ap.add_argument("-m", "--models", default="", help="'a': 1x HurrDeblur pass first (upscale_video.py -m a)")
+    ap.add_argument("-g", "--gpu", type=int, default=0)
+    ap.add_argument("--tile", type=int, default=TILE_SIZE, help="reference tile size of the final pass (960); 0 = whole frame")
+    ap.add_argument("--frames", type=int, default=None, help="stop after this many frames")
+    ap.add_argument("--model-path", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "models"))
+    a = ap.parse_args(argv)
+    if a.width <= 0 or a.height <= 0:
+        ap.error("frame size must be positive")
+    models = [m for m in a.models.split(",") if m]
+    for m in models:
+        if m != "a":
+            ap.error("only -m a is available on the MI355X path (r: weights missing upstream; n: OpenCV NLM, host only)")
+    nets = []
+    if "a" in models and a.scale != 1:
+        nets.append((load_net(MODEL_FILES[1], a.gpu, a.model_path), 0))          # apply_model: whole frame
+    nets.append((load_net(MODEL_FILES[a.scale], a.gpu, a.model_path), 0 if a.scale == 1 else a.tile))
+    fin = sys.stdin.buffer if a.input == "-" else open(a.input, "rb")
+    fout = sys.stdout.buffer if a.output == "-" else open(a.output, "wb")
+    try:
+        n = stream(fin, fout, a.height, a.width, nets, max_frames=a.frames)
+    finally:
+        if fin is not sys.stdin.buffer:
+            fin.close()
+        if fout is not sys.stdout.buffer:
+            fout.close()
+    print("%d frames" % n, file=sys.stderr)
+    ncnn.destroy_gpu_instance()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
