@@ -220,6 +220,7 @@ int launch_trunk64(uva_net* n, const ConvArgs& a, int ablate = 0)
 {
     if (ablate == 1) return launch_trunk64_t<1>(n, a);
     if (ablate == 2) return launch_trunk64_t<2>(n, a);
+    if (ablate == 4) return launch_trunk64_t<4>(n, a);
     return launch_trunk64_t<0>(n, a);
 }
 
@@ -910,10 +911,13 @@ int uva_net_debug_trunk_stamps(uva_net* n, unsigned long long* out, int max_tile
         if (tiles) *tiles = (ca.tiles_per_xcd + grid3 / 8 - 1) / (grid3 / 8);
         return rc3;
     }
+    // bits 8.. of `ablate`: hundreds of timed repetitions (sustained, power-limited state) instead of 10
+    const int reps = (ablate >> 8) > 0 ? (ablate >> 8) * 100 : 10;
+    ablate &= 0xff;
     int rc = launch_trunk(n, ws, ca, ablate);   // warm
     ca.dbg = nullptr;
     HIP_TRY(hipEventRecord(e0, n->stream));
-    for (int r = 0; r < 10 && !rc; ++r) rc = launch_trunk(n, ws, ca, ablate);
+    for (int r = 0; r < reps && !rc; ++r) rc = launch_trunk(n, ws, ca, ablate);
     HIP_TRY(hipEventRecord(e1, n->stream));
     ca.dbg = d;
     HIP_TRY(hipMemsetAsync(d, 0, bytes, n->stream));
@@ -923,7 +927,7 @@ int uva_net_debug_trunk_stamps(uva_net* n, unsigned long long* out, int max_tile
         HIP_TRY(hipStreamSynchronize(n->stream));
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-        if (kernel_ms) *kernel_ms = ms / 10;
+        if (kernel_ms) *kernel_ms = ms / reps;
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);

@@ -758,7 +758,7 @@ __device__ __forceinline__ void group_barrier()
 
 // ABL (debug ablations, never used by the product path): 0 = the real kernel; 1 = no MFMAs and no
 // LDS reads (memory traffic only); 2 = every tile re-fetches tile 0 and stores to the sink (compute
-// only, memory traffic stays in L2)
+// only, memory traffic stays in L2); 4 = memory traffic and LDS fragment reads, no MFMAs
 template <int NF, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
 {
@@ -953,7 +953,14 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
                         trunk_issue_piece<NF>(la.base, la.pitch, la_lds, st / EVERY, wave, dma_pc[st / EVERY]);
                 }
                 const int R = st & 3, ch = (st >> 2) & 1, dx = st >> 3;
-                if constexpr (ABL == 1) {
+                if constexpr (ABL == 4) {      // fragments are read and consumed, but by one VALU add each
+                    if (st == 0) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) acc[q >> 2][(q >> 1) & 1][q & 1] = zero4;
+                    }
+                    const half8 b0 = bq[(2 * st) % RQ], b1 = bq[(2 * st + 1) % RQ];
+                    acc[st & 1][(st >> 1) & 1][(st >> 2) & 1][st & 3] += (float)b0[st & 7] + (float)b1[(st + 3) & 7] + (float)w[st][0];
+                } else if constexpr (ABL == 1) {
                     if (st == 0) {
 #pragma unroll
                         for (int q = 0; q < 8; ++q) acc[q >> 2][(q >> 1) & 1][q & 1] = zero4;
