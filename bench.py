@@ -148,7 +148,7 @@ def main():
     from upscale_video_amd import build
     build.build_lib()
     from upscale_video_amd import ncnn
-    from oracle import uvoracle
+    from upscale_video_amd.synth import synthetic_frame
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -183,7 +183,7 @@ def main():
 
     # synthetic frames, resident in HBM before the timed region
     n_src = 4
-    frames = [torch.from_numpy(uvoracle.synthetic_frame(h, w, seed=20260928 + 17 * rank + i)).cuda() for i in range(n_src)]
+    frames = [torch.from_numpy(synthetic_frame(h, w, seed=20260928 + 17 * rank + i)).cuda() for i in range(n_src)]
     out = torch.empty((h * s, w * s, 3), dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
 

@@ -178,16 +178,7 @@ def round_f16(x):
     return lib().uvo_round_f16(float(x))
 
 
-def synthetic_frame(h, w, seed=20260928, kind="smooth"):
-    """Seeded synthetic u8 BGR HWC frame."""
-    rng = np.random.default_rng(seed)
-    if kind == "random":
-        return rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
-    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
-    img = np.empty((h, w, 3), np.float64)
-    for c in range(3):
-        img[..., c] = 127 + 100 * np.sin(x / 17 + c) * np.cos(y / 23) + rng.normal(0, 4, (h, w))
-    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+from upscale_video_amd.synth import synthetic_frame  # noqa: E402,F401  (the shared input generator)
 
 
 MODELS_DIR = os.path.join(os.path.dirname(_HERE), "models")

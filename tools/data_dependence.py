@@ -6,9 +6,9 @@ net = ncnn.Net(); net.set_vulkan_device(0)
 b = "models/2x_Compact_Pretrain"
 assert net.load_param(b + ".param") == 0 and net.load_model(b + ".bin") == 0
 h, w = 1080, 1920
-from oracle import uvoracle
+from upscale_video_amd.synth import synthetic_frame
 rng = np.random.default_rng(1)
-kinds = {"zeros": np.zeros((h, w, 3), np.uint8), "smooth": uvoracle.synthetic_frame(h, w),
+kinds = {"zeros": np.zeros((h, w, 3), np.uint8), "smooth": synthetic_frame(h, w),
          "noise": rng.integers(0, 256, (h, w, 3), dtype=np.uint8), "white255": np.full((h, w, 3), 255, np.uint8)}
 out = torch.empty((2 * h, 2 * w, 3), dtype=torch.uint8, device="cuda")
 for rep in range(2):

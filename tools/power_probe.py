@@ -10,9 +10,9 @@ from upscale_video_amd import _lib, ncnn  # noqa: E402
 net = ncnn.Net(); net.set_vulkan_device(0)
 base = os.path.join(ROOT, "models", "2x_Compact_Pretrain")
 assert net.load_param(base + ".param") == 0 and net.load_model(base + ".bin") == 0
-from oracle import uvoracle  # noqa: E402
+from upscale_video_amd.synth import synthetic_frame  # noqa: E402
 kind = sys.argv[1] if len(sys.argv) > 1 else "smooth"
-img = uvoracle.synthetic_frame(1080, 1920) if kind == "smooth" else np.zeros((1080, 1920, 3), np.uint8)
+img = synthetic_frame(1080, 1920) if kind == "smooth" else np.zeros((1080, 1920, 3), np.uint8)
 net.process_u8(img, tile_size=960, border=10)
 
 

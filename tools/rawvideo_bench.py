@@ -3,11 +3,11 @@ frames held in /dev/shm: whole process wall time minus the wall time of a 1-fram
 start, model load, first-use allocations)."""
 import os, subprocess, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import uvoracle
+from upscale_video_amd.synth import synthetic_frame
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1200
 src = "/dev/shm/uva_in.bgr24"
-fr = [uvoracle.synthetic_frame(1080, 1920, seed=i) for i in range(4)]
+fr = [synthetic_frame(1080, 1920, seed=i) for i in range(4)]
 with open(src, "wb") as o:
     for i in range(N):
         o.write(fr[i % 4].tobytes())

@@ -5,13 +5,13 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 from upscale_video_amd import ncnn
-from oracle import uvoracle
+from upscale_video_amd.synth import synthetic_frame
 net = ncnn.Net(); net.set_vulkan_device(0)
 b = "models/2x_Compact_Pretrain"
 assert net.load_param(b + ".param") == 0 and net.load_model(b + ".bin") == 0
 for rep in range(2):
     for (w, h) in [(1920, 1080), (1280, 720), (1600, 900), (960, 540), (2560, 1440), (1920, 1080)]:
-        d = torch.from_numpy(uvoracle.synthetic_frame(h, w)).cuda()
+        d = torch.from_numpy(synthetic_frame(h, w)).cuda()
         out = torch.empty((2 * h, 2 * w, 3), dtype=torch.uint8, device="cuda")
         n = int(400 * (1920 * 1080) / (w * h))
         for i in range(20): net.process_u8_device(d.data_ptr(), h, w, out.data_ptr(), tile_size=0)
