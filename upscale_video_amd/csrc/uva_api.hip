@@ -63,6 +63,7 @@ struct Workspace {
 
 struct DeviceLayer {
     half8* wpk = nullptr;
+    half8* wpk16 = nullptr;   // tail layer of the 64-feature 2x net: pack_tail64 image for tail_kernel
     float* bias = nullptr;
     float* slope = nullptr;
 };
@@ -126,6 +127,7 @@ struct uva_net {
         if (stream) (void)hipStreamSynchronize(stream);
         for (auto& l : layers) {
             if (l.wpk) (void)hipFree(l.wpk);
+            if (l.wpk16) (void)hipFree(l.wpk16);
             if (l.bias) (void)hipFree(l.bias);
             if (l.slope) (void)hipFree(l.slope);
         }
@@ -247,6 +249,33 @@ int launch_conv(uva_net* n, int mode, const ConvArgs& a)
     return fail("no kernel for this trunk width");
 }
 
+// u8 tail of the 64-feature 2x net: ping-pong kernel on 4-row tiles (the other tails: conv3x3_kernel)
+int launch_tail_u8(uva_net* n, const Workspace* ws, ConvArgs ca)
+{
+    if (n->g.nf == 64 && n->g.scale == 2 && n->layers.back().wpk16) {
+        static bool attr_done[16] = {false};
+        const size_t lds = tail_lds_bytes<64>();
+        auto kfn = tail_kernel<64, 2>;
+        if (n->device >= 16 || !attr_done[n->device]) {
+            HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (n->device < 16) attr_done[n->device] = true;
+        }
+        const int grid = std::max(8, (n->ncu / 8) * 8);
+        const int per_launch = 8 * (2 * (grid / 8)) * ((TAIL_SCHED_MAX - TRUNK_LOOKAHEAD) / 2 - 1);
+        ca.sched4 = ws->d_sched4;
+        ca.wpk = n->layers.back().wpk16;
+        for (int base = 0; base < ws->ntiles4; base += per_launch) {
+            ca.tile_base = base;
+            ca.ntiles = std::min(per_launch, ws->ntiles4 - base);
+            ca.tiles_per_xcd = (ca.ntiles + 7) / 8;
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), lds, n->stream, ca);
+            HIP_TRY(hipGetLastError());
+        }
+        return 0;
+    }
+    return launch_conv(n, 1, ca);
+}
+
 // one trunk layer: the 64-feature nets use the split-channel kernel on 4-row tiles
 int launch_trunk(uva_net* n, const Workspace* ws, ConvArgs ca, int ablate = 0)
 {
@@ -314,6 +343,11 @@ int ensure_device(uva_net* n)
         else pack_conv3x3(g.convs[i], g.nf, pk, nullptr, &mf);
         DeviceLayer& dl = n->layers[i];
         if (upload(&dl.wpk, pk.data(), pk.size() * 2, n->stream)) return 1;
+        std::vector<uint16_t> pk16;
+        if (g.nf == 64 && g.scale == 2 && i + 1 == g.convs.size()) {
+            pack_tail64(g.convs[i], pk16);
+            if (upload(&dl.wpk16, pk16.data(), pk16.size() * 2, n->stream)) return 1;
+        }
         std::vector<float> b((size_t)mf * 32, 0.f), s((size_t)mf * 32, 0.f);
         std::copy(g.convs[i].bias.begin(), g.convs[i].bias.end(), b.begin());
         if (upload(&dl.bias, b.data(), b.size() * 4, n->stream)) return 1;
@@ -404,15 +438,19 @@ int get_workspace(uva_net* n, int h, int w, int tile_size, int border, Workspace
     if (n->g.nf == 64) {
         using G4 = Geo<64, 4>;
         sched4.reserve((size_t)tiles4);
-        for (const auto& p : ws.planes)
+        for (size_t pi = 0; pi < ws.planes.size(); ++pi) {
+            const PlaneDesc& p = ws.planes[pi];
+            if (p.nty4 >= 4096 || p.ntx >= 256) return fail("frame too large for the tile schedule encoding");
             for (int ty = 0; ty < p.nty4; ++ty)
                 for (int tx = 0; tx < p.ntx; ++tx) {
                     const unsigned long long off =
                         ((unsigned long long)p.act_off + (unsigned long long)(ty * 4) * p.pitch + (unsigned long long)tx * TW) * G4::PIXB;
+                    if (off >> 40) return fail("activation buffer too large for the tile schedule encoding");
                     const int vy = std::min(4, p.h - ty * 4), vx = std::min(TW, p.w - tx * TW);
-                    sched4.push_back(make_uint4((unsigned)off, (unsigned)(off >> 32), (unsigned)(p.pitch * G4::PIXB),
-                                                (unsigned)((vy << 8) | vx)));
+                    sched4.push_back(make_uint4((unsigned)off, (unsigned)(off >> 32) | ((unsigned)pi << 8), (unsigned)(p.pitch * G4::PIXB),
+                                                (unsigned)(vx | (vy << 6) | (tx << 9) | (ty << 17))));
                 }
+        }
         HIP_TRY(hipMalloc((void**)&ws.d_sched4, sched4.size() * sizeof(uint4)));
         HIP_TRY(hipMemcpyAsync(ws.d_sched4, sched4.data(), sched4.size() * sizeof(uint4), hipMemcpyHostToDevice, n->stream));
     }
@@ -515,7 +553,7 @@ int run_graph(uva_net* n, Workspace* ws, bool f32, const void* src, size_t src_s
         ca.dst_u8 = (uint8_t*)dst;
         ca.dst_stride = dst_stride;
     }
-    if (launch_conv(n, f32 ? 2 : 1, ca)) return 1;
+    if (f32 ? launch_conv(n, 2, ca) : launch_tail_u8(n, ws, ca)) return 1;
     if (prof) {
         HIP_TRY(hipEventRecord(ev.e[3], n->stream));
         n->ev_pending.push_back(ev);
@@ -889,14 +927,14 @@ int uva_net_debug_trunk_stamps(uva_net* n, unsigned long long* out, int max_tile
         ca.src_stride = n->last.src_stride;
         ca.dst_u8 = (uint8_t*)n->last.dst;
         ca.dst_stride = n->last.dst_stride;
-        int rc3 = launch_conv(n, 1, ca);
+        int rc3 = launch_tail_u8(n, ws, ca);
         ca.dbg = nullptr;
         HIP_TRY(hipEventRecord(e0, n->stream));
-        for (int r = 0; r < 10 && !rc3; ++r) rc3 = launch_conv(n, 1, ca);
+        for (int r = 0; r < 10 && !rc3; ++r) rc3 = launch_tail_u8(n, ws, ca);
         HIP_TRY(hipEventRecord(e1, n->stream));
         ca.dbg = d;
         HIP_TRY(hipMemsetAsync(d, 0, bytes, n->stream));
-        if (!rc3) rc3 = launch_conv(n, 1, ca);
+        if (!rc3) rc3 = launch_tail_u8(n, ws, ca);
         if (!rc3) {
             HIP_TRY(hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, n->stream));
             HIP_TRY(hipStreamSynchronize(n->stream));
@@ -908,7 +946,8 @@ int uva_net_debug_trunk_stamps(uva_net* n, unsigned long long* out, int max_tile
         (void)hipEventDestroy(e1);
         (void)hipFree(d);
         const int grid3 = std::max(8, (n->ncu / 8) * 8);
-        if (tiles) *tiles = (ca.tiles_per_xcd + grid3 / 8 - 1) / (grid3 / 8);
+        const bool pingpong_tail = n->g.nf == 64 && n->g.scale == 2;      // tail_kernel: 4-row tiles, 2 groups
+        if (tiles) *tiles = pingpong_tail ? per_block : (ca.tiles_per_xcd + grid3 / 8 - 1) / (grid3 / 8);
         return rc3;
     }
     // bits 8.. of `ablate`: hundreds of timed repetitions (sustained, power-limited state) instead of 10

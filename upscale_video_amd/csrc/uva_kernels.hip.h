@@ -111,8 +111,9 @@ struct ConvArgs {
     _Float16* sink;               // >= 64 pixels of scratch: where lanes outside the image store to
     int tile_base;                // trunk_kernel: first global work tile of this launch (huge frames
                                   // are split so that a workgroup's schedule fits its LDS table)
-    const uint4* sched4;          // trunk_kernel: per 4-row work tile {halo origin byte offset lo, hi, row pitch
-                                  // in bytes, (valid rows << 8) | valid columns}, built by the host per geometry
+    const uint4* sched4;          // trunk_kernel / tail_kernel: per 4-row work tile, built by the host per geometry:
+                                  // x = halo origin byte offset (low 32 bits), y = offset bits 32..39 | plane << 8,
+                                  // z = row pitch in bytes, w = valid columns | valid rows << 6 | tx << 9 | ty << 17
     int reverse;                  // walk the tiles last-to-first: consecutive layers alternate direction so
                                   // that a layer starts on what the previous one wrote last, i.e. on what is
                                   // still in the 256 MB Infinity Cache
@@ -841,12 +842,12 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
     auto read_sched = [&](int k) __attribute__((always_inline)) {
         const uint4 e = sched_lds[k];
         Sched r;
-        const unsigned lo = __builtin_amdgcn_readfirstlane(e.x), hi = __builtin_amdgcn_readfirstlane(e.y);
+        const unsigned lo = __builtin_amdgcn_readfirstlane(e.x), hi = __builtin_amdgcn_readfirstlane(e.y) & 0xffu;
         r.off = ((unsigned long long)hi << 32) | lo;
         r.base = (const char*)a.in_act + r.off;
         r.pitch = __builtin_amdgcn_readfirstlane(e.z);
         const int v = __builtin_amdgcn_readfirstlane(e.w);
-        r.vy = v >> 8; r.vx = v & 255;
+        r.vy = (v >> 6) & 7; r.vx = v & 63;
         return r;
     };
     // prologue: tiles 0 and 2 by group 0, tile 1 by group 1 (all pieces).  Their schedule entries
@@ -856,7 +857,7 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
         bool real;
         const uint4 e = scalar_load16(a.sched4 + __builtin_amdgcn_readfirstlane(sched_tile(k, real)));
         Sched r;
-        const unsigned lo = __builtin_amdgcn_readfirstlane(e.x), hi = __builtin_amdgcn_readfirstlane(e.y);
+        const unsigned lo = __builtin_amdgcn_readfirstlane(e.x), hi = __builtin_amdgcn_readfirstlane(e.y) & 0xffu;
         r.off = ((unsigned long long)hi << 32) | lo;
         r.base = (const char*)a.in_act + r.off;
         r.pitch = __builtin_amdgcn_readfirstlane(e.z);
@@ -1076,6 +1077,290 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
     // nothing of the re-fetched look-ahead tiles may land after the workgroup's LDS is released
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (stamp) a.dbg[6] = __builtin_amdgcn_s_memtime();
+}
+
+// ----------------------------------------------------------------------------------------------
+// tail_kernel<64, 2>: the u8 tail of the 2x net (conv 64 -> 12, PixelShuffle(2), + nearest-upsampled
+// normalised input, *255, cv2 convertTo(CV_8U), core crop) on trunk_kernel's skeleton: 8-wave
+// workgroup, two 4-wave groups in ping-pong, 4x32 work tiles, the same 5-slot LDS ring and tile
+// schedule.  conv3x3_kernel<64,1,2> runs one wave per SIMD, so its k-loop (12 of 32 MFMA rows used)
+// and its long epilogue serialise; here one group's epilogue overlaps the other's k-loop.
+//   wave-in-group = 2*rp + cc: rows 2rp, 2rp+1, columns 16cc .. 16cc+15 of the tile, ALL 12 output
+//   channels as one 16-row block of v_mfma_f32_16x16x32_f16 (72 weight registers).
+// A lane (g = lane>>4, p = lane&15) then holds output channels 4g..4g+3 of pixel p = the 2x2
+// sub-pixels of colour channel g: no cross-lane traffic in the pixel shuffle.  The residual needs
+// 3 source bytes per pixel from the u8 frame: the wave fetches its 2 rows x 48 bytes as 2 x 13
+// aligned dwords with one LDS-DMA instruction at the top of its k-loop phase (ordered and waited for
+// like the ring pieces), instead of per-lane byte loads whose compiler-inserted wait would drain
+// the DMA queue.
+// ----------------------------------------------------------------------------------------------
+constexpr int TAIL_SCHED_MAX = 448;
+constexpr int TAIL_RESID_LDS = 8 * 128;       // per wave: 2 rows x 16 dwords
+template <int NF>
+constexpr int tail_lds_bytes() { return TRUNK_SLOTS * TrunkGeo<NF>::SLOTB + PARAMS_AND_PLANES_LDS + TAIL_SCHED_MAX * 16 + TAIL_RESID_LDS; }
+static_assert(tail_lds_bytes<64>() <= 160 * 1024, "tail kernel LDS budget");
+
+// 4 bytes per active lane from sbase + voff to lds_dst + lane*4
+__device__ __forceinline__ void glds4_s(const void* sbase, unsigned voff, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dword %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_dst));
+}
+
+template <int NF, int R>
+__global__ __launch_bounds__(512, 2) void tail_kernel(ConvArgs a)
+{
+    static_assert(NF == 64 && R == 2, "written for the 2x net's tail (64 -> 12)");
+    using G = Geo<NF, TH4>;
+    using TG = TrunkGeo<NF>;
+    constexpr int KS = 18;                    // k-steps of 32: (tap, input-channel half)
+    constexpr int CPW = TG::CPW;
+    constexpr int SLOTB = TG::SLOTB;
+    constexpr int PFF = 4;                    // B fragments read ahead
+    constexpr int CPW_K = 8;                  // DMA pieces issued in the k-loop phase (the rest in the epilogue phase):
+                                              // all 8 measured slightly better than 5 + 3
+    constexpr int NSTEP = 24;
+    constexpr int ROWB = 16 * R * 3;          // staged bytes per output row of this wave
+    constexpr int STAGEB = 512;               // per wave: 2R rows x ROWB = 384
+    static_assert(2 * R * ROWB <= STAGEB && 4 * STAGEB <= SLOTB, "output staging");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = lds_offset(smem);
+    float* bias_lds = (float*)(smem + TRUNK_SLOTS * SLOTB);
+    PlaneDesc* planes_lds = (PlaneDesc*)(smem + TRUNK_SLOTS * SLOTB + PARAM_LDS);
+    uint4* sched_lds = (uint4*)(smem + TRUNK_SLOTS * SLOTB + PARAMS_AND_PLANES_LDS);
+    char* resid_all = smem + TRUNK_SLOTS * SLOTB + PARAMS_AND_PLANES_LDS + TAIL_SCHED_MAX * 16;
+
+    const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave8 >> 2;
+    const int wave = wave8 & 3;
+    const int lane = threadIdx.x & 63;
+    const int rp = wave >> 1;     // which row pair of the 4-row tile
+    const int cc = wave & 1;      // which 16 columns
+
+    const int g8 = 2 * (gridDim.x >> 3);
+    const int xcd = blockIdx.x & 7;
+    const int slot = blockIdx.x >> 3;
+    const int t_lim = min((xcd + 1) * a.tiles_per_xcd, a.ntiles);
+    const int t0 = xcd * a.tiles_per_xcd + 2 * slot;
+    if (t0 >= t_lim) return;
+    const int niter0 = (t_lim - t0 + g8 - 1) / g8;
+    const int niter1 = t0 + 1 < t_lim ? (t_lim - t0 - 1 + g8 - 1) / g8 : 0;
+    const int niter = grp ? niter1 : niter0;
+
+    const int nsched = 2 * niter0 + TRUNK_LOOKAHEAD;
+    auto sched_tile = [&](int k, bool& real) __attribute__((always_inline)) {
+        int t = t0 + (k & 1) + (k >> 1) * g8;
+        real = t < t_lim;
+        if (!real) t = t0;                                       // past the end: a harmless re-fetch
+        if (a.reverse) t = a.ntiles - 1 - t;
+        return t + a.tile_base;
+    };
+    uint4 sched_e0 = make_uint4(0, 0, 0, 0);
+    bool sched_real0 = false;
+    if ((int)threadIdx.x < nsched) sched_e0 = a.sched4[sched_tile(threadIdx.x, sched_real0)];
+    float prm_b = 0.f;
+    if (threadIdx.x < 16) prm_b = a.bias[threadIdx.x];
+    int plane_words[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        if ((int)threadIdx.x + 512 * j < a.nplanes * 16) plane_words[j] = ((const int*)a.planes)[threadIdx.x + 512 * j];
+    // the layer's weights (12 output channels, zero-padded to 16), resident in registers
+    half8 w[KS];
+#pragma unroll
+    for (int i = 0; i < KS; ++i) w[i] = a.wpk[i * 64 + lane];
+
+    int dma_pc[CPW];
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) dma_pc[i] = trunk_piece_const<NF>(i, wave, lane);
+
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    struct Sched { const char* base; int pitch; int vy, vx, ty, tx, plane; };
+    auto decode = [&](const uint4 e) __attribute__((always_inline)) {
+        Sched r;
+        const unsigned lo = __builtin_amdgcn_readfirstlane(e.x), y = __builtin_amdgcn_readfirstlane(e.y);
+        r.base = (const char*)a.in_act + (((unsigned long long)(y & 0xffu) << 32) | lo);
+        r.plane = (int)(y >> 8);
+        r.pitch = __builtin_amdgcn_readfirstlane(e.z);
+        const unsigned v = __builtin_amdgcn_readfirstlane(e.w);
+        r.vx = v & 63; r.vy = (v >> 6) & 7; r.tx = (v >> 9) & 255; r.ty = v >> 17;
+        return r;
+    };
+    auto read_sched = [&](int k) __attribute__((always_inline)) { return decode(sched_lds[k]); };
+    // prologue: tiles 0 and 2 by group 0, tile 1 by group 1; entries through the scalar cache
+    {
+        bool real;
+        const Sched s0 = decode(scalar_load16(a.sched4 + __builtin_amdgcn_readfirstlane(sched_tile(grp, real))));
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) trunk_issue_piece<NF>(s0.base, s0.pitch, lds0 + grp * SLOTB, i, wave, dma_pc[i]);
+        if (grp == 0) {
+            const Sched s2 = decode(scalar_load16(a.sched4 + __builtin_amdgcn_readfirstlane(sched_tile(2, real))));
+#pragma unroll
+            for (int i = 0; i < CPW; ++i) trunk_issue_piece<NF>(s2.base, s2.pitch, lds0 + 2 * SLOTB, i, wave, dma_pc[i]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int real0 = sched_real0;
+    asm volatile("" : "+v"(real0));
+    if (!real0) sched_e0.w = 0;
+    if ((int)threadIdx.x < nsched) sched_lds[threadIdx.x] = sched_e0;
+    for (int k = threadIdx.x + 512; k < nsched; k += 512) {   // huge frames only
+        bool real;
+        uint4 e = a.sched4[sched_tile(k, real)];
+        if (!real) e.w = 0;
+        sched_lds[k] = e;
+    }
+    if (threadIdx.x < 16) bias_lds[threadIdx.x] = prm_b;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        if ((int)threadIdx.x + 512 * j < a.nplanes * 16) ((int*)planes_lds)[threadIdx.x + 512 * j] = plane_words[j];
+    tile_barrier<0>();
+    if (grp == 1) group_barrier();   // group 1 runs half a period behind group 0
+    int cur = grp;
+    Sched la = read_sched(grp + TRUNK_LOOKAHEAD);
+
+    const unsigned resid_lds = lds0 + (unsigned)(resid_all - smem) + wave8 * 128;
+    const char* const resid_rd = resid_all + wave8 * 128;
+    const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+    for (int it = 0; it < niter0; ++it) {
+        const bool active = it < niter;
+        const int k = 2 * it + grp;
+        if (stamp) a.dbg[8 * it + 0] = __builtin_amdgcn_s_memtime();
+        const Sched own = read_sched(k);
+        const PlaneDesc& pl = planes_lds[own.plane];
+        const int pl_h = __builtin_amdgcn_readfirstlane(pl.h), pl_w = __builtin_amdgcn_readfirstlane(pl.w);
+        const int src_y0 = __builtin_amdgcn_readfirstlane(pl.src_y0), src_x0 = __builtin_amdgcn_readfirstlane(pl.src_x0);
+        const int y_t = own.ty * TH4 + 2 * rp;            // plane-local first row of this wave
+        const int xs = own.tx * TW + 16 * cc;             // plane-local first column of this wave
+        // residual source bytes: rows y_t, y_t+1 (clamped), columns xs .. xs+15 (clamped) of the plane
+        int sh[2];
+        {
+            const int xc = min(xs, pl_w - 1);
+            const int nb = 3 * min(16, pl_w - xc);         // valid bytes of the row segment (>= 3)
+            unsigned voff = 0;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int yc = min(y_t + n, pl_h - 1);
+                const size_t ra = (size_t)(src_y0 + yc) * a.src_stride + (size_t)(src_x0 + xc) * 3;   // byte offset in the frame
+                const size_t abs = (size_t)a.src_u8 + ra;
+                sh[n] = (int)(abs & 3);
+                const int dmax = (int)((((abs + nb - 1) & ~(size_t)3) - (abs & ~(size_t)3)) >> 2);
+                const unsigned vo = (unsigned)(ra - sh[n]) + 4u * (unsigned)min(lane & 15, dmax);
+                if ((lane >> 4) == n) voff = vo;
+            }
+            if (active && lane < 32) glds4_s(a.src_u8, voff, resid_lds);
+        }
+        f32x4 acc[2];
+        const int fill = cur + TRUNK_LOOKAHEAD >= TRUNK_SLOTS ? cur + TRUNK_LOOKAHEAD - TRUNK_SLOTS : cur + TRUNK_LOOKAHEAD;
+        const unsigned la_lds = lds0 + fill * SLOTB;
+        {
+            // ---- k-loop phase: 24 fragment reads, 36 MFMAs, CPW_K DMA pieces of the look-ahead tile ----
+            __builtin_amdgcn_s_setprio(2);
+            const char* buf = smem + cur * SLOTB;
+            const char* bbase = buf + ((2 * rp) * PW + 16 * cc + (lane & 15)) * G::LPIXB + (lane >> 4) * 16;
+            auto read_b = [&](int st) __attribute__((always_inline)) -> half8 {
+                const int Rr = st & 3, ch = (st >> 2) & 1, dx = st >> 3;
+                return *(const half8*)(bbase + (Rr * PW + dx) * G::LPIXB + ch * 64);
+            };
+            constexpr int RQ = PFF + 1;
+            half8 bq[RQ];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int f = 0; f < PFF; ++f) bq[f] = read_b(f);
+#pragma unroll
+            for (int st = 0; st < NSTEP; ++st) {
+                if (st + PFF < NSTEP) bq[(st + PFF) % RQ] = read_b(st + PFF);
+                constexpr int EVERY = NSTEP / CPW_K;
+                if (st % EVERY == 1 && st / EVERY < CPW_K)
+                    trunk_issue_piece<NF>(la.base, la.pitch, la_lds, st / EVERY, wave, dma_pc[st / EVERY]);
+                const int Rr = st & 3, ch = (st >> 2) & 1, dx = st >> 3;
+                const half8 b = bq[st % RQ];
+                if (Rr <= 2)    // output row 0, tap (dy = Rr, dx)
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[((Rr * 3 + dx) * 2) + ch], b, st == 0 ? zero4 : acc[0], 0, 0, 0);
+                if (Rr >= 1)    // output row 1, tap (dy = Rr - 1, dx)
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[(((Rr - 1) * 3 + dx) * 2) + ch], b, st == 1 ? zero4 : acc[1], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+        if (stamp) a.dbg[8 * it + 1] = __builtin_amdgcn_s_memtime();
+        // only the CPW_K pieces of tile k+3 just issued may still be in flight: the residual dwords
+        // (issued before them) and tile k+1 have landed
+        tile_barrier<CPW_K>();
+        if (stamp) a.dbg[8 * it + 2] = __builtin_amdgcn_s_memtime();
+        // ---- epilogue phase ----------------------------------------------------------------------
+        const Sched la_next = read_sched(min(k + 2 + TRUNK_LOOKAHEAD, nsched - 1));
+#pragma unroll
+        for (int i = CPW_K; i < CPW; ++i) trunk_issue_piece<NF>(la.base, la.pitch, la_lds, i, wave, dma_pc[i]);
+        la = la_next;
+        if (active) {
+            const int lane_o = opaque(lane);
+            const int g = lane_o >> 4, p = lane_o & 15;          // colour channel (3: padding rows), pixel
+            uint8_t* const stage = (uint8_t*)(smem + cur * SLOTB + wave * STAGEB);
+            const f32x4 b4 = *(const f32x4*)(bias_lds + 4 * g);
+            const float norm = (float)(1 / 255.0);               // substract_mean_normalize norm_vals (:272, :444)
+            if (g < 3) {
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const float res = (float)*(const uint8_t*)(resid_rd + n * 64 + sh[n] + 3 * p + g) * norm;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = (acc[n][j] + b4[j]) + res;
+                        float q = __builtin_rintf(v * 255.0f);     // v_rndne_f32: ties to even
+                        q = fminf(fmaxf(q, 0.f), 255.f);
+                        stage[(n * R + (j >> 1)) * ROWB + (p * R + (j & 1)) * 3 + g] = (uint8_t)q;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (stamp) a.dbg[8 * it + 4] = __builtin_amdgcn_s_memtime();
+            // copy-out of the plane's core region (process_tile's crop, upscale_processing.py:464-477)
+            const int core_y0 = __builtin_amdgcn_readfirstlane(pl.core_y0), core_y1 = min(__builtin_amdgcn_readfirstlane(pl.core_y1), pl_h);
+            const int core_x0 = __builtin_amdgcn_readfirstlane(pl.core_x0), core_x1 = min(__builtin_amdgcn_readfirstlane(pl.core_x1), pl_w);
+            const int x_lo = max(core_x0, xs) - xs, x_hi = min(core_x1, xs + 16) - xs;
+            const int b_lo = x_lo * R * 3, b_hi = x_hi * R * 3;
+            uint8_t* const dbase = a.dst_u8 + (size_t)(src_y0 + y_t) * R * a.dst_stride + (size_t)(src_x0 + xs) * R * 3;
+            const bool full = b_lo == 0 && b_hi == ROWB && y_t >= core_y0 && y_t + 2 <= core_y1;
+            const size_t align_bits = (size_t)dbase | a.dst_stride;
+            constexpr int Q = ROWB / 16, WORDS = ROWB / 4;
+            if (full && (align_bits & 15) == 0) {
+                if (lane_o < 2 * R * Q) {
+                    const int sr = lane_o / Q, kq = lane_o - sr * Q;
+                    *(uint4*)(dbase + (size_t)sr * a.dst_stride + 16 * kq) = *(const uint4*)(stage + sr * ROWB + 16 * kq);
+                }
+            } else if (b_hi > b_lo) {
+                for (int idx = lane_o; idx < 2 * R * WORDS; idx += 64) {
+                    const int sr = idx / WORDS, kw = idx - sr * WORDS;
+                    const int y = y_t + sr / R;
+                    if (y < core_y0 || y >= core_y1) continue;
+                    uint8_t* drow = dbase + (size_t)sr * a.dst_stride;
+                    const uint8_t* srow = stage + sr * ROWB;
+                    const int b0 = 4 * kw;
+                    if (b0 >= b_lo && b0 + 4 <= b_hi && (((size_t)(drow + b0)) & 3) == 0) {
+                        *(uint32_t*)(drow + b0) = *(const uint32_t*)(srow + b0);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (b0 + e >= b_lo && b0 + e < b_hi) drow[b0 + e] = srow[b0 + e];
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (stamp) a.dbg[8 * it + 3] = __builtin_amdgcn_s_memtime();
+        group_barrier();
+        cur = cur + 2 >= TRUNK_SLOTS ? cur + 2 - TRUNK_SLOTS : cur + 2;
+    }
+    if (grp == 0) group_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // ----------------------------------------------------------------------------------------------

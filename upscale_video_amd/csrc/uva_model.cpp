@@ -263,6 +263,22 @@ void pack_trunk64(const ConvWeights& c, std::vector<uint16_t>& out)
             }
 }
 
+void pack_tail64(const ConvWeights& c, std::vector<uint16_t>& out)
+{
+    const int mb_n = (c.cout + 15) / 16;
+    out.assign((size_t)18 * mb_n * 64 * 8, 0);
+    for (int ks = 0; ks < 18; ++ks)
+        for (int mb = 0; mb < mb_n; ++mb)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int co = 16 * mb + (lane & 15), tap = ks >> 1;
+                if (co >= c.cout) continue;
+                for (int e = 0; e < 8; ++e) {
+                    const int ci = 32 * (ks & 1) + 8 * (lane >> 4) + e;
+                    out[(((size_t)ks * mb_n + mb) * 64 + lane) * 8 + e] = f32_to_f16_bits(c.w[((size_t)co * 64 + ci) * 9 + tap]);
+                }
+            }
+}
+
 void pack_head(const ConvWeights& c, std::vector<uint16_t>& out, int* mf_out)
 {
     const int mf = (c.cout + 31) / 32;

@@ -43,6 +43,9 @@ void pack_conv3x3(const ConvWeights& c, int nf, std::vector<uint16_t>& out, int*
 // lanes][8] fp16, k-step = 2*tap + ch; lane = (octet << 4) | i supplies output channel 16*mb + i and
 // input channels 32*ch + 8*octet .. +7 of that tap.
 void pack_trunk64(const ConvWeights& c, std::vector<uint16_t>& out);
+// tail_kernel<64, R> (v_mfma_f32_16x16x32_f16, cin = 64, cout = 3*R*R padded to a multiple of 16):
+// image [18 k-steps][MB = ceil(cout/16) blocks][64 lanes][8] fp16, lanes and k-steps as pack_trunk64.
+void pack_tail64(const ConvWeights& c, std::vector<uint16_t>& out);
 // Head (cin = 3): K = [tap][4] (3 channels + zero), octet o = 2*ks + half holds taps 2o, 2o+1;
 // image [3][MF][64][8].
 void pack_head(const ConvWeights& c, std::vector<uint16_t>& out, int* mf_out);
