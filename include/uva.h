@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UVA_ABI_VERSION 1
+#define UVA_ABI_VERSION 2   /* 2: + uva_net_submit_u8 / uva_net_collect_u8 / uva_host_alloc / uva_host_free */
 
 typedef struct uva_net uva_net;
 

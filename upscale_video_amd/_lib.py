@@ -6,6 +6,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UVA_LIB_PATH") or os.path.join(_HERE, "libuva.so")   # override: A/B builds
 
 # every symbol include/uva.h declares
+ABI_VERSION = 2   # include/uva.h UVA_ABI_VERSION
+
 SYMBOLS = [
     "uva_get_gpu_count", "uva_get_default_gpu_index", "uva_get_gpu_info", "uva_destroy_gpu_instance",
     "uva_net_create", "uva_net_set_device", "uva_net_load_param", "uva_net_load_model",
@@ -69,6 +71,8 @@ def load():
     L.uva_abi_version.restype = c_i
     for n in SYMBOLS:   # AttributeError here means the .so is stale: rebuild it
         getattr(L, n)
+    if L.uva_abi_version() != ABI_VERSION:
+        raise UvaError("libuva.so has ABI version %d, this package needs %d: rebuild it" % (L.uva_abi_version(), ABI_VERSION))
     _lib = L
     return L
 
