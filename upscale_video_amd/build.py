@@ -30,14 +30,25 @@ def build_lib(force=False, verbose=False):
         return os.environ["UVA_LIB_PATH"]
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function"]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", LIB + ".tmp"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    os.replace(LIB + ".tmp", LIB)
+    # one builder at a time (bench.py runs one process per GPU): the others wait, then find it fresh
+    import fcntl
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not needs_build():
+            return LIB
+        tmp = "%s.tmp.%d" % (LIB, os.getpid())
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-Wall", "-Wno-unused-function"]
+        cmd += [os.path.join(CSRC, s) for s in SOURCES]
+        cmd += ["-o", tmp]
+        if verbose:
+            print(" ".join(cmd))
+        try:
+            subprocess.check_call(cmd)
+            os.replace(tmp, LIB)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
     return LIB
 
 
