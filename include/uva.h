@@ -127,12 +127,15 @@ int uva_net_kernel_stats(uva_net* net, int kind, long long* launches, double* to
  * of workgroup 0 / wave 0: out[8*i + {0,1,2,3,4}] = tile i {start, k-loop done, barrier passed,
  * epilogue done, epilogue staging written} in s_memtime ticks (out holds 8*max_tiles values).
  * *tiles = tiles that workgroup processed.  ablate: 0 real kernel, 1 memory traffic only (no MFMA /
- * LDS reads), 2 compute only (L2-resident input, stores to a sink); *kernel_ms = mean of 10 launches. */
+ * LDS reads), 2 compute only (L2-resident input, stores to a sink), 3 the u8 tail kernel instead, 4 memory
+ * traffic and LDS fragment reads without MFMAs; bits 8.. = hundreds of timed launches instead of 10 (sustained,
+ * power-limited state); *kernel_ms = mean launch time. */
 int uva_net_debug_trunk_stamps(uva_net* net, unsigned long long* out, int max_tiles, int* tiles, int ablate,
                                float* kernel_ms);
 
 /* Test hook (host only, no device needed): the fp16 MFMA A-operand image convolution #conv_idx is
- * repacked into, [k-step][m-frag][lane][8].  *needed receives the element count. */
+ * repacked into, [k-step][m-frag][lane][8].  *needed receives the element count.  conv_idx -1: the
+ * last convolution as tail_kernel reads it (64-feature nets). */
 int uva_net_debug_packed_weights(uva_net* net, int conv_idx, uint16_t* out, size_t out_halfs, size_t* needed);
 
 const char* uva_last_error(void);

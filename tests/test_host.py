@@ -107,6 +107,20 @@ def test_packed_weights_are_a_permutation_of_oihw(uva, oracle_models, key):
         with np.errstate(over="ignore"):
             want = w.astype(np.float16).astype(np.float32)
         assert np.array_equal(got, want), (key, idx)
+    if nf == 64:
+        # tail_kernel's image of the last convolution: [18][MB][64][8], rows beyond cout are zero
+        wt, _, _ = om.conv(net.num_convs - 1)
+        cout = wt.shape[0]
+        mb = (cout + 15) // 16
+        img = net.debug_packed_weights(-1).view(np.float16).astype(np.float32).reshape(18, mb, 64, 8)
+        rec = np.zeros((16 * mb, 64, 9), np.float32)
+        for ks in range(18):
+            for m in range(mb):
+                for lane in range(64):
+                    ci0 = 32 * (ks & 1) + 8 * (lane >> 4)
+                    rec[16 * m + (lane & 15), ci0:ci0 + 8, ks >> 1] = img[ks, m, lane]
+        assert not rec[cout:].any()
+        assert np.array_equal(rec[:cout].reshape(cout, 64, 3, 3), wt.astype(np.float16).astype(np.float32)), key
     # head: K = [tap][4] (3 channels + zero), octet o = 2ks+h holds taps 2o, 2o+1
     w0, _, _ = om.conv(0)
     pk = net.debug_packed_weights(0).view(np.float16).astype(np.float32)

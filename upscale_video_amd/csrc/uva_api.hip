@@ -979,9 +979,11 @@ int uva_net_debug_trunk_stamps(uva_net* n, unsigned long long* out, int max_tile
 int uva_net_debug_packed_weights(uva_net* n, int conv_idx, uint16_t* out, size_t out_halfs, size_t* needed)
 {
     if (!n || !n->g.model_loaded) return fail("no model");
-    if (conv_idx < 0 || conv_idx >= (int)n->g.convs.size()) return fail("conv_idx out of range");
+    if (conv_idx == -1 && n->g.nf != 64) return fail("conv_idx -1 (tail_kernel image) exists for the 64-feature nets only");
+    if (conv_idx < -1 || conv_idx >= (int)n->g.convs.size()) return fail("conv_idx out of range");
     std::vector<uint16_t> pk;
-    if (conv_idx == 0) pack_head(n->g.convs[0], pk, nullptr);
+    if (conv_idx == -1) pack_tail64(n->g.convs.back(), pk);          // tail_kernel's image of the last convolution
+    else if (conv_idx == 0) pack_head(n->g.convs[0], pk, nullptr);
     else if (n->g.nf == 64 && conv_idx + 1 < (int)n->g.convs.size()) pack_trunk64(n->g.convs[conv_idx], pk);
     else pack_conv3x3(n->g.convs[conv_idx], n->g.nf, pk, nullptr, nullptr);
     if (needed) *needed = pk.size();
