@@ -1,5 +1,6 @@
 #!/bin/bash
-# usage: ab_multi.sh "<sed expr for variant 1>" "<sed expr 2>" ... ; A = working tree as is
+# Same-box comparison of several one-line variants of uva_kernels.hip.h (V0 = the working tree as is,
+# V1.. = one sed expression each).  usage: tools/ab_multi.sh "<sed expr 1>" "<sed expr 2>" ...
 cd /root/repo
 HIPCC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-function -Wno-unused-variable"
 F=upscale_video_amd/csrc/uva_kernels.hip.h
