@@ -63,7 +63,7 @@ struct Workspace {
 
 struct DeviceLayer {
     half8* wpk = nullptr;
-    half8* wpk16 = nullptr;   // tail layer of the 64-feature 2x net: pack_tail64 image for tail_kernel
+    half8* wpk16 = nullptr;   // tail layer of the 64-feature 2x / 4x nets: pack_tail64 image for tail_kernel / tail4_kernel
     float* bias = nullptr;
     float* slope = nullptr;
 };
@@ -249,16 +249,17 @@ int launch_conv(uva_net* n, int mode, const ConvArgs& a)
     return fail("no kernel for this trunk width");
 }
 
-// u8 tail of the 64-feature 2x net: ping-pong kernel on 4-row tiles (the other tails: conv3x3_kernel)
+// u8 tails of the 64-feature 2x and 4x nets: ping-pong kernels on 4-row tiles (the other tails: conv3x3_kernel)
 int launch_tail_u8(uva_net* n, const Workspace* ws, ConvArgs ca)
 {
-    if (n->g.nf == 64 && n->g.scale == 2 && n->layers.back().wpk16) {
-        static bool attr_done[16] = {false};
-        const size_t lds = tail_lds_bytes<64>();
-        auto kfn = tail_kernel<64, 2>;
-        if (n->device >= 16 || !attr_done[n->device]) {
+    if (n->g.nf == 64 && (n->g.scale == 2 || n->g.scale == 4) && n->layers.back().wpk16) {
+        static bool attr_done[2][16] = {{false}, {false}};
+        const bool x4 = n->g.scale == 4;
+        const size_t lds = x4 ? tail4_lds_bytes<64>() : tail_lds_bytes<64>();
+        void (*kfn)(ConvArgs) = x4 ? tail4_kernel<64> : tail_kernel<64, 2>;
+        if (n->device >= 16 || !attr_done[x4][n->device]) {
             HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            if (n->device < 16) attr_done[n->device] = true;
+            if (n->device < 16) attr_done[x4][n->device] = true;
         }
         const int grid = std::max(8, (n->ncu / 8) * 8);
         const int per_launch = 8 * (2 * (grid / 8)) * ((TAIL_SCHED_MAX - TRUNK_LOOKAHEAD) / 2 - 1);
@@ -344,7 +345,7 @@ int ensure_device(uva_net* n)
         DeviceLayer& dl = n->layers[i];
         if (upload(&dl.wpk, pk.data(), pk.size() * 2, n->stream)) return 1;
         std::vector<uint16_t> pk16;
-        if (g.nf == 64 && g.scale == 2 && i + 1 == g.convs.size()) {
+        if (g.nf == 64 && (g.scale == 2 || g.scale == 4) && i + 1 == g.convs.size()) {
             pack_tail64(g.convs[i], pk16);
             if (upload(&dl.wpk16, pk16.data(), pk16.size() * 2, n->stream)) return 1;
         }
@@ -946,7 +947,7 @@ int uva_net_debug_trunk_stamps(uva_net* n, unsigned long long* out, int max_tile
         (void)hipEventDestroy(e1);
         (void)hipFree(d);
         const int grid3 = std::max(8, (n->ncu / 8) * 8);
-        const bool pingpong_tail = n->g.nf == 64 && n->g.scale == 2;      // tail_kernel: 4-row tiles, 2 groups
+        const bool pingpong_tail = n->g.nf == 64 && (n->g.scale == 2 || n->g.scale == 4);   // 4-row tiles, 2 groups
         if (tiles) *tiles = pingpong_tail ? per_block : (ca.tiles_per_xcd + grid3 / 8 - 1) / (grid3 / 8);
         return rc3;
     }

@@ -1364,6 +1364,252 @@ __global__ __launch_bounds__(512, 2) void tail_kernel(ConvArgs a)
 }
 
 // ----------------------------------------------------------------------------------------------
+// tail4_kernel<64>: the u8 tail of the 4x net (conv 64 -> 48, PixelShuffle(4), + nearest-upsampled
+// normalised input, *255, cv2 convertTo(CV_8U), core crop), again two 4-wave groups in ping-pong on
+// 4x32 tiles.  48 output channels = three 16-row blocks, one per colour channel: with the 2x tail's
+// pixel split (wave = 2 rows x 16 columns) the weights would be 216 registers per wave, too many for
+// two waves per SIMD, so they live in LDS (54 KB, an A fragment is one linear ds_read_b128 per lane)
+// and the ring shrinks to 3 slots:
+//   * tile k sits in slot k % 3; the group that has just finished k-loop k refills that very slot
+//     with tile k+3 (the other group's next-but-one) at the END of its epilogue phase, after its
+//     output stores, and issues nothing but the residual dwords during its k-loop -- so "everything
+//     has landed" (vmcnt(0)) at the end of the next k-loop is a cheap wait and proves tile k+3 in
+//     time (1.x phases of latency hiding);
+//   * a lane (g, p) holds, over the three blocks, sub-row g and sub-columns 0..3 of all three colour
+//     channels of pixel p: 12 contiguous output bytes, stored straight from registers.
+// ----------------------------------------------------------------------------------------------
+constexpr int TAIL4_SLOTS = 3;
+constexpr int TAIL4_MB = 3;                                  // 16-channel blocks = colour channels
+constexpr int TAIL4_W_LDS = 18 * TAIL4_MB * 1024;            // weights: [k-step][block][lane][8] fp16
+template <int NF>
+constexpr int tail4_lds_bytes()
+{
+    return TAIL4_SLOTS * TrunkGeo<NF>::SLOTB + TAIL4_W_LDS + PARAMS_AND_PLANES_LDS + TAIL_SCHED_MAX * 16 + TAIL_RESID_LDS;
+}
+static_assert(tail4_lds_bytes<64>() <= 160 * 1024, "tail4 kernel LDS budget");
+
+template <int NF>
+__global__ __launch_bounds__(512, 2) void tail4_kernel(ConvArgs a)
+{
+    static_assert(NF == 64, "written for the 4x net's tail (64 -> 48)");
+    using G = Geo<NF, TH4>;
+    using TG = TrunkGeo<NF>;
+    constexpr int R = 4, MB = TAIL4_MB;
+    constexpr int CPW = TG::CPW;
+    constexpr int SLOTB = TG::SLOTB;
+    constexpr int PFF = 3;                    // B fragments read ahead
+    constexpr int NSTEP = 24;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = lds_offset(smem);
+    char* w_lds = smem + TAIL4_SLOTS * SLOTB;
+    char* const after_w = w_lds + TAIL4_W_LDS;
+    float* bias_lds = (float*)after_w;
+    PlaneDesc* planes_lds = (PlaneDesc*)(after_w + PARAM_LDS);
+    uint4* sched_lds = (uint4*)(after_w + PARAMS_AND_PLANES_LDS);
+    char* resid_all = after_w + PARAMS_AND_PLANES_LDS + TAIL_SCHED_MAX * 16;
+
+    const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave8 >> 2;
+    const int wave = wave8 & 3;
+    const int lane = threadIdx.x & 63;
+    const int rp = wave >> 1;     // which row pair of the 4-row tile
+    const int cc = wave & 1;      // which 16 columns
+
+    const int g8 = 2 * (gridDim.x >> 3);
+    const int xcd = blockIdx.x & 7;
+    const int slot = blockIdx.x >> 3;
+    const int t_lim = min((xcd + 1) * a.tiles_per_xcd, a.ntiles);
+    const int t0 = xcd * a.tiles_per_xcd + 2 * slot;
+    if (t0 >= t_lim) return;
+    const int niter0 = (t_lim - t0 + g8 - 1) / g8;
+    const int niter1 = t0 + 1 < t_lim ? (t_lim - t0 - 1 + g8 - 1) / g8 : 0;
+    const int niter = grp ? niter1 : niter0;
+
+    const int nsched = 2 * niter0 + TRUNK_LOOKAHEAD;
+    auto sched_tile = [&](int k, bool& real) __attribute__((always_inline)) {
+        int t = t0 + (k & 1) + (k >> 1) * g8;
+        real = t < t_lim;
+        if (!real) t = t0;                                       // past the end: a harmless re-fetch
+        if (a.reverse) t = a.ntiles - 1 - t;
+        return t + a.tile_base;
+    };
+    int dma_pc[CPW];
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) dma_pc[i] = trunk_piece_const<NF>(i, wave, lane);
+
+    struct Sched { const char* base; int pitch; int vy, vx, ty, tx, plane; };
+    auto decode = [&](const uint4 e) __attribute__((always_inline)) {
+        Sched r;
+        const unsigned lo = __builtin_amdgcn_readfirstlane(e.x), y = __builtin_amdgcn_readfirstlane(e.y);
+        r.base = (const char*)a.in_act + (((unsigned long long)(y & 0xffu) << 32) | lo);
+        r.plane = (int)(y >> 8);
+        r.pitch = __builtin_amdgcn_readfirstlane(e.z);
+        const unsigned v = __builtin_amdgcn_readfirstlane(e.w);
+        r.vx = v & 63; r.vy = (v >> 6) & 7; r.tx = (v >> 9) & 255; r.ty = v >> 17;
+        return r;
+    };
+    auto read_sched = [&](int k) __attribute__((always_inline)) { return decode(sched_lds[k]); };
+    // prologue: the first three tiles' DMA (entries through the scalar cache), then tables and weights
+    {
+        bool real;
+        const Sched s0 = decode(scalar_load16(a.sched4 + __builtin_amdgcn_readfirstlane(sched_tile(grp, real))));
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) trunk_issue_piece<NF>(s0.base, s0.pitch, lds0 + grp * SLOTB, i, wave, dma_pc[i]);
+        if (grp == 0) {
+            const Sched s2 = decode(scalar_load16(a.sched4 + __builtin_amdgcn_readfirstlane(sched_tile(2, real))));
+#pragma unroll
+            for (int i = 0; i < CPW; ++i) trunk_issue_piece<NF>(s2.base, s2.pitch, lds0 + 2 * SLOTB, i, wave, dma_pc[i]);
+        }
+    }
+    for (int k = threadIdx.x; k < nsched; k += 512) {
+        bool real;
+        uint4 e = a.sched4[sched_tile(k, real)];
+        if (!real) e.w = 0;
+        sched_lds[k] = e;
+    }
+    if (threadIdx.x < 48) bias_lds[threadIdx.x] = a.bias[threadIdx.x];
+    for (int i = threadIdx.x; i < a.nplanes * 16; i += 512) ((int*)planes_lds)[i] = ((const int*)a.planes)[i];
+    for (int i = threadIdx.x; i < TAIL4_W_LDS / 16; i += 512) ((uint4*)w_lds)[i] = ((const uint4*)a.wpk)[i];
+    tile_barrier<0>();
+    if (grp == 1) group_barrier();   // group 1 runs half a period behind group 0
+    int cur = grp;                   // ring slot of this group's current tile: (2*it + grp) % 3
+
+    const unsigned resid_lds = lds0 + (unsigned)(resid_all - smem) + wave8 * 128;
+    const char* const resid_rd = resid_all + wave8 * 128;
+    const char* const wrd = w_lds + lane * 16;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < niter0; ++it) {
+        const bool active = it < niter;
+        const int k = 2 * it + grp;
+        const Sched own = read_sched(k);
+        const PlaneDesc& pl = planes_lds[own.plane];
+        const int pl_h = __builtin_amdgcn_readfirstlane(pl.h), pl_w = __builtin_amdgcn_readfirstlane(pl.w);
+        const int src_y0 = __builtin_amdgcn_readfirstlane(pl.src_y0), src_x0 = __builtin_amdgcn_readfirstlane(pl.src_x0);
+        const int y_t = own.ty * TH4 + 2 * rp;            // plane-local first row of this wave
+        const int xs = own.tx * TW + 16 * cc;             // plane-local first column of this wave
+        // residual source bytes: rows y_t, y_t+1 (clamped), columns xs .. xs+15 (clamped), 2 x 13 dwords
+        int sh[2];
+        {
+            const int xc = min(xs, pl_w - 1);
+            const int nb = 3 * min(16, pl_w - xc);
+            unsigned voff = 0;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int yc = min(y_t + n, pl_h - 1);
+                const size_t ra = (size_t)(src_y0 + yc) * a.src_stride + (size_t)(src_x0 + xc) * 3;
+                const size_t abs = (size_t)a.src_u8 + ra;
+                sh[n] = (int)(abs & 3);
+                const int dmax = (int)((((abs + nb - 1) & ~(size_t)3) - (abs & ~(size_t)3)) >> 2);
+                const unsigned vo = (unsigned)(ra - sh[n]) + 4u * (unsigned)min(lane & 15, dmax);
+                if ((lane >> 4) == n) voff = vo;
+            }
+            if (active && lane < 32) glds4_s(a.src_u8, voff, resid_lds);
+        }
+        f32x4 acc[2][MB];
+        {
+            // ---- k-loop phase: per (dx, ch) column of taps, halo rows Rr = 0..3: the fragment of row Rr
+            // meets the weights of tap row dy = Rr (output row 0) and of dy = Rr - 1 (output row 1, the
+            // A fragments kept from the previous step): 24 B reads + 54 A reads per 108 MFMAs -------
+            __builtin_amdgcn_s_setprio(2);
+            const char* buf = smem + cur * SLOTB;
+            const char* bbase = buf + ((2 * rp) * PW + 16 * cc + (lane & 15)) * G::LPIXB + (lane >> 4) * 16;
+            auto read_b = [&](int st) __attribute__((always_inline)) -> half8 {
+                const int Rr = st & 3, ch = (st >> 2) & 1, dx = st >> 3;
+                return *(const half8*)(bbase + (Rr * PW + dx) * G::LPIXB + ch * 64);
+            };
+            auto read_a = [&](int st, int m) __attribute__((always_inline)) -> half8 {   // weights of tap (dy = Rr, dx), half ch
+                const int Rr = st & 3, ch = (st >> 2) & 1, dx = st >> 3;
+                return *(const half8*)(wrd + ((((Rr * 3 + dx) * 2 + ch) * MB + m) * 1024));
+            };
+            constexpr int RQ = PFF + 1;
+            half8 bq[RQ];
+            half8 a_cur[MB], a_prev[MB], a_next[MB];
+#pragma unroll
+            for (int f = 0; f < PFF; ++f) bq[f] = read_b(f);
+#pragma unroll
+            for (int m = 0; m < MB; ++m) { a_next[m] = read_a(0, m); a_cur[m] = a_next[m]; }
+#pragma unroll
+            for (int st = 0; st < NSTEP; ++st) {
+                const int Rr = st & 3;
+                if (st + PFF < NSTEP) bq[(st + PFF) % RQ] = read_b(st + PFF);
+#pragma unroll
+                for (int m = 0; m < MB; ++m) { a_prev[m] = a_cur[m]; a_cur[m] = a_next[m]; }
+                if (st + 1 < NSTEP && ((st + 1) & 3) <= 2) {
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) a_next[m] = read_a(st + 1, m);
+                }
+                const half8 b = bq[st % RQ];
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    if (Rr <= 2)    // output row 0, tap (dy = Rr, dx)
+                        acc[0][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur[m], b, st == 0 ? zero4 : acc[0][m], 0, 0, 0);
+                    if (Rr >= 1)    // output row 1, tap (dy = Rr - 1, dx): the previous step's weights
+                        acc[1][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_prev[m], b, st == 1 ? zero4 : acc[1][m], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+        // nothing was issued to the memory pipe during the k-loop except the residual dwords at its
+        // top: waiting for everything is cheap, and proves tile k+1 (refilled one full phase ago by the
+        // other group) for that group's k-loop, which starts now
+        tile_barrier<0>();
+        // ---- epilogue phase ----------------------------------------------------------------------
+        const Sched la = read_sched(min(k + TRUNK_LOOKAHEAD, nsched - 1));   // tile k+3 goes into the slot just consumed
+        if (active) {
+            const int lane_o = opaque(lane);
+            const int g = lane_o >> 4, p = lane_o & 15;          // sub-row of the 4x4 output block, pixel
+            const float norm = (float)(1 / 255.0);
+            const int core_y0 = __builtin_amdgcn_readfirstlane(pl.core_y0), core_y1 = min(__builtin_amdgcn_readfirstlane(pl.core_y1), pl_h);
+            const int core_x0 = __builtin_amdgcn_readfirstlane(pl.core_x0), core_x1 = min(__builtin_amdgcn_readfirstlane(pl.core_x1), pl_w);
+            const bool col_ok = xs + p >= core_x0 && xs + p < core_x1;
+            const bool aligned = (((size_t)a.dst_u8 | a.dst_stride) & 3) == 0;
+            f32x4 b4[MB];
+#pragma unroll
+            for (int m = 0; m < MB; ++m) b4[m] = *(const f32x4*)(bias_lds + 16 * m + 4 * g);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int y = y_t + n;
+                unsigned q[MB][4];
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    const float res = (float)*(const uint8_t*)(resid_rd + n * 64 + sh[n] + 3 * p + m) * norm;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = (acc[n][m][j] + b4[m][j]) + res;
+                        float r = __builtin_rintf(v * 255.0f);     // v_rndne_f32: ties to even
+                        r = fminf(fmaxf(r, 0.f), 255.f);
+                        q[m][j] = (unsigned)r;
+                    }
+                }
+                if (y >= core_y0 && y < core_y1 && col_ok) {
+                    // output row 4y + g, pixels 4(x) .. 4(x)+3, BGR each: 12 contiguous bytes
+                    uint8_t* d = a.dst_u8 + ((size_t)(src_y0 + y) * R + g) * a.dst_stride + (size_t)(src_x0 + xs + p) * R * 3;
+                    const unsigned d0 = q[0][0] | (q[1][0] << 8) | (q[2][0] << 16) | (q[0][1] << 24);
+                    const unsigned d1 = q[1][1] | (q[2][1] << 8) | (q[0][2] << 16) | (q[1][2] << 24);
+                    const unsigned d2 = q[2][2] | (q[0][3] << 8) | (q[1][3] << 16) | (q[2][3] << 24);
+                    if (aligned) {
+                        ((unsigned*)d)[0] = d0; ((unsigned*)d)[1] = d1; ((unsigned*)d)[2] = d2;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            d[e] = (uint8_t)(d0 >> (8 * e)); d[4 + e] = (uint8_t)(d1 >> (8 * e)); d[8 + e] = (uint8_t)(d2 >> (8 * e));
+                        }
+                    }
+                }
+            }
+        }
+        // refill the slot this group has just consumed with tile k+3, behind the stores in the queue
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) trunk_issue_piece<NF>(la.base, la.pitch, lds0 + cur * SLOTB, i, wave, dma_pc[i]);
+        group_barrier();
+        cur = cur + 2 >= TAIL4_SLOTS ? cur + 2 - TAIL4_SLOTS : cur + 2;
+    }
+    if (grp == 0) group_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ----------------------------------------------------------------------------------------------
 // head_kernel<NF, SRC>: from_pixels(PIXEL_BGR) + substract_mean_normalize + Conv_0 (3 -> NF) +
 // PReLU_1, fp16 NHWC out.  SRC 0: u8 HWC source; the integer pixel values go through the MFMA
 // exactly (0..255 are exact in fp16) and the 1/255 normalisation is applied to the fp32
