@@ -15,5 +15,5 @@ for e in "$@"; do
 done
 touch upscale_video_amd/libuva.so
 N=$((i-1))
-/usr/local/graft/bin/gpurun --timeout 600 -- "P='import json,sys; d=json.loads(sys.stdin.read()); print(d[\"value\"], d[\"config\"][\"kernel_ms_per_frame\"])'; for r in 1 2; do for v in \$(seq 0 $N); do echo -n \"V\$v: \"; UVA_LIB_PATH=\$PWD/upscale_video_amd/libuva_V\$v.so python bench.py --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c \"\$P\"; done; done" 2>&1 | grep -E "^V[0-9]"
+/usr/local/graft/bin/gpurun --timeout 600 -- "P='import json,sys; d=json.loads(sys.stdin.read()); print(d[\"value\"], d[\"config\"][\"kernel_ms_per_frame\"])'; for r in 1 2; do for v in \$(seq 0 $N); do echo -n \"V\$v: \"; UVA_LIB_PATH=\$PWD/upscale_video_amd/libuva_V\$v.so python bench.py --workload ${WORKLOAD:-2x_compact_1080p} --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c \"\$P\"; done; done" 2>&1 | grep -E "^V[0-9]"
 rm -f upscale_video_amd/libuva_V*.so
