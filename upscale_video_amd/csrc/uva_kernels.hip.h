@@ -738,8 +738,15 @@ template <int NF>
 __device__ __forceinline__ void trunk_issue_piece(const char* tile_base, int pitch_bytes, unsigned lds_slot, int i,
                                                   int wave, int pc)
 {
+    if (4 * i + wave >= TrunkGeo<NF>::PIECES) return;     // 29 pieces, 4 waves x 8: waves 1-3 have no 8th piece
     const unsigned off = (unsigned)(pc >> 16) * (unsigned)pitch_bytes + (unsigned)(pc & 0xffff);
     glds16_s(tile_base, off, lds_slot + trunk_piece_index<NF>(i, wave) * 1024);
+}
+// how many of its pieces 0 .. n-1 a wave really issues
+template <int NF>
+__device__ __forceinline__ int trunk_pieces_issued(int n, int wave)
+{
+    return (n == TrunkGeo<NF>::CPW && 4 * (n - 1) + wave >= TrunkGeo<NF>::PIECES) ? n - 1 : n;
 }
 
 // 16 bytes through the scalar cache: the address must be wave-uniform.  The constant address space
@@ -1290,9 +1297,10 @@ __global__ __launch_bounds__(512, 2) void tail_kernel(ConvArgs a)
             __builtin_amdgcn_s_setprio(0);
         }
         if (stamp) a.dbg[8 * it + 1] = __builtin_amdgcn_s_memtime();
-        // only the CPW_K pieces of tile k+3 just issued may still be in flight: the residual dwords
-        // (issued before them) and tile k+1 have landed
-        tile_barrier<CPW_K>();
+        // only the pieces of tile k+3 just issued (CPW_K, one fewer for waves without an 8th piece) may
+        // still be in flight: the residual dwords (issued before them) and tile k+1 have landed
+        if (trunk_pieces_issued<NF>(CPW_K, wave) == CPW_K) tile_barrier<CPW_K>();
+        else tile_barrier<CPW_K - 1>();
         if (stamp) a.dbg[8 * it + 2] = __builtin_amdgcn_s_memtime();
         // ---- epilogue phase ----------------------------------------------------------------------
         const Sched la_next = read_sched(min(k + 2 + TRUNK_LOOKAHEAD, nsched - 1));
