@@ -14,14 +14,22 @@
 //   frame I/O   : u8 HWC BGR exactly as cv2.imread / cv2.imwrite hold it, or f32 planar CHW
 //                 exactly as ncnn::Mat holds it.
 //
-// Kernel structure (conv3x3_kernel): one persistent 4-wave workgroup per CU.  Every wave keeps the
-// layer's whole weight matrix (Cout x 9*Cin, fp16) in its 512-entry VGPR/AGPR file for the
-// lifetime of the kernel, so the MFMA A operand never touches LDS or L2 again.  Work tiles are
-// 8 rows x 32 columns of output pixels; the 10 x 34 pixel input halo tile is streamed
-// HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip), double buffered so the
-// DMA of tile t+1 runs under the MFMAs of tile t.  v_mfma_f32_32x32x16_f16: A = weights
-// (rows = output channels), B = 32 consecutive pixels of one image row (cols), K = 16 input
-// channels of one tap, fp32 accumulate.  Each B fragment read from LDS feeds Cout/32 MFMAs.
+// Kernels in this file (DESIGN.md section 5 has the measurements behind each choice):
+//   head_kernel<NF,SRC>     u8 / f32 frame -> Conv_0 (3 -> NF) + PReLU -> fp16 NHWC planes
+//   trunk_kernel<64>        one trunk layer 64 -> 64 + PReLU: 8-wave workgroup per CU, two 4-wave groups
+//                           in ping-pong (k-loop of one over the epilogue of the other), weights
+//                           stationary in registers, 4x32 tiles streamed through a 5-slot LDS ring by
+//                           LDS-DMA, v_mfma_f32_16x16x32_f16 (the kernel is power-bound and this shape
+//                           is the cheapest per flop), host-built tile schedule
+//   tail_kernel<64,2>       u8 tail of the 2x net on the same skeleton (residual bytes by LDS-DMA)
+//   tail4_kernel<64>        u8 tail of the 4x net: weights in LDS, 3-slot ring, stores from registers
+//   conv3x3_kernel<NF,M,R>  everything else (24-feature nets, f32-route tails): one persistent 4-wave
+//                           workgroup per CU (two for NF = 24), one wave per SIMD, every wave keeps the
+//                           layer's whole weight matrix in its 512-entry register file, 8x32 tiles,
+//                           10x34 halo tiles streamed HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4,
+//                           no VGPR round trip) into a ring, v_mfma_f32_32x32x16_f16: A = weights (rows =
+//                           output channels), B = 32 consecutive pixels of one image row, K = 16 input
+//                           channels of one tap, fp32 accumulate.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
