@@ -794,15 +794,12 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
     const unsigned lds0 = lds_offset(smem);
     float* bias_lds = (float*)(smem + TRUNK_SLOTS * SLOTB);
     float* prm_lds = bias_lds + 64;                  // slopes [0,64), med3 selectors [64,128)
-    PlaneDesc* planes_lds = (PlaneDesc*)(smem + TRUNK_SLOTS * SLOTB + PARAM_LDS);
     uint4* sched_lds = (uint4*)(smem + TRUNK_SLOTS * SLOTB + PARAMS_AND_PLANES_LDS);
 
     const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int grp = wave8 >> 2;   // ping-pong group
     const int wave = wave8 & 3;   // wave within the group
     const int lane = threadIdx.x & 63;
-    const int half = lane >> 5;
-    const int px = lane & 31;
     const int mh = wave & 1;      // which 32 output channels
     const int rp = wave >> 1;     // which row pair of the 4-row tile
 
