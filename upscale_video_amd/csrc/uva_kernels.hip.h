@@ -1031,55 +1031,50 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
             // 32 pixels x 32 channels through the ring slot it has just finished reading and stores
             // 64 contiguous bytes per pixel.
             const int lane_o = opaque(lane);
-            char* const stage = smem + cur * SLOTB + wave * TG::STAGE_WAVE;
-            // per-channel parameters of this lane's 16 channels, fetched up front (one LDS latency,
-            // not eight): bias, slope, med3 selector
+            const int cg = lane_o >> 4, p = lane_o & 15;
+            // per-channel parameters of this lane's 8 channels (4 in each 16-channel block), fetched up
+            // front (one LDS latency, not eight): bias, slope, med3 selector
             f32x4 b4[2], s4[2], i4[2];
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                const int cl = 32 * mh + 16 * m + 4 * (lane_o >> 4);
+                const int cl = 32 * mh + 16 * m + 4 * cg;
                 b4[m] = *(const f32x4*)(bias_lds + cl);
                 s4[m] = *(const f32x4*)(prm_lds + cl);
                 i4[m] = *(const f32x4*)(prm_lds + 64 + cl);
             }
+            // Output pixel (row 2*rp + n, column 16*c + p) of the tile sits one row and one column inside
+            // the halo origin.  After the lane exchange below, lane (p, cg) holds 8 consecutive channels
+            // starting at {0, 16, 8, 24}[cg] of this wave's 32.
+            char* const obase = (char*)a.out_act + own.off + ((size_t)(2 * rp + 1) * own.pitch + G::PIXB) + 64 * mh +
+                                (size_t)p * G::PIXB + 32 * (cg & 1) + 8 * (cg & 2);
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < 2; ++c) {
+                    unsigned o[2][2];
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
-                        const int cl = 16 * m + 4 * (lane_o >> 4);     // channel within this wave's 32
                         f32x4 v;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float xv = acc[n][c][m][j] + b4[m][j];
                             v[j] = __builtin_amdgcn_fmed3f(xv, xv * s4[m][j], i4[m][j]);
                         }
-                        const half2v lo = __builtin_convertvector(f32x2{v[0], v[1]}, half2v);
-                        const half2v hi = __builtin_convertvector(f32x2{v[2], v[3]}, half2v);
-                        uint2 o;
-                        o.x = __builtin_bit_cast(unsigned, lo);
-                        o.y = __builtin_bit_cast(unsigned, hi);
-                        *(uint2*)(stage + (n * 32 + 16 * c + (lane_o & 15)) * TG::STAGE_PX + cl * 2) = o;
+                        o[m][0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, half2v));
+                        o[m][1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, half2v));
                     }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    // v_permlane16_swap_b32: lanes 16-31 / 48-63 of the first operand trade places with
+                    // lanes 0-15 / 32-47 of the second.  Before: block m = 0 and m = 1 hold channels
+                    // 4cg..4cg+3 and 16+4cg..; after: even cg lanes hold 8 consecutive channels of block 0
+                    // (their own 4 and their neighbour's), odd cg lanes 8 consecutive channels of block 1.
+                    const auto x = __builtin_amdgcn_permlane16_swap(o[0][0], o[1][0], false, false);
+                    const auto y = __builtin_amdgcn_permlane16_swap(o[0][1], o[1][1], false, false);
+                    const uint4 val = make_uint4(x[0], y[0], x[1], y[1]);
+                    const bool ok = ABL != 2 && 2 * rp + n < own.vy && 16 * c + p < own.vx;
+                    char* dst = ok ? obase + ((size_t)n * own.pitch + (size_t)(16 * c) * G::PIXB) : sink;
+                    *(uint4*)dst = val;
+                }
             if (stamp) a.dbg[8 * it + 4] = __builtin_amdgcn_s_memtime();
-            // 256 sixteen-byte chunks: chunk q = pixel q/4 (row q/128, column (q/4)%32), quarter q%4.
-            // Output pixel (row 2*rp + n, column xl) of the tile sits one row and one column inside
-            // the halo origin.
-            char* const obase = (char*)a.out_act + own.off + ((size_t)(2 * rp + 1) * own.pitch + G::PIXB) + 64 * mh;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int q = c * 64 + lane_o;
-                const int pix = q >> 2, quarter = q & 3;
-                const int n = pix >> 5, xl = pix & 31;
-                const uint4 val = *(const uint4*)(stage + pix * TG::STAGE_PX + quarter * 16);
-                const bool ok = ABL != 2 && 2 * rp + n < own.vy && xl < own.vx;
-                char* dst = ok ? obase + ((size_t)n * own.pitch + xl * G::PIXB) + quarter * 16 : sink;
-                *(uint4*)dst = val;
-            }
         }
         if (stamp) a.dbg[8 * it + 3] = __builtin_amdgcn_s_memtime();
         group_barrier();
