@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define UVA_ABI_VERSION 2   /* 2: + uva_net_submit_u8 / uva_net_collect_u8 / uva_host_alloc / uva_host_free */
+#define UVA_ABI_VERSION 3   /* 2: + uva_net_submit_u8 / uva_net_collect_u8 / uva_host_alloc / uva_host_free;
+                               3: + uva_get_gpu_pci_bus_id, uva_debug_trunk2_schedule */
 
 typedef struct uva_net uva_net;
 
@@ -38,6 +39,10 @@ int uva_get_default_gpu_index(void);
 /* ncnn.get_gpu_info(i).type() / .device_name()   test_gpus.py:59-66
  * *type: 0 discrete, 1 integrated, 2 virtual, 3 cpu (ncnn's enumeration). */
 int uva_get_gpu_info(int index, int* type, char* name, size_t name_len);
+/* PCI address "dddd:bb:dd.f" of HIP device `index` (ncnn's GpuInfo has no counterpart; the worker layer
+ * uses it to find the GPU's NUMA node in sysfs and to place a worker's feeder threads and page-locked
+ * buffers next to the GPU it was given by its position in the -g list, upscale/upscale_processing.py:59). */
+int uva_get_gpu_pci_bus_id(int index, char* out, size_t out_len);
 /* ncnn.destroy_gpu_instance()     upscale/upscale_processing.py:292, :458
  * Frees every cached device allocation of every live net (nets stay loadable). */
 void uva_destroy_gpu_instance(void);
@@ -123,6 +128,7 @@ int uva_net_debug_read_activation(uva_net* net, int conv_idx, float* out_chw, in
 int uva_net_set_profiling(uva_net* net, int enable);
 int uva_net_kernel_stats(uva_net* net, int kind, long long* launches, double* total_ms);
 
+#ifdef UVA_INSTRUMENT   /* instrumented builds only (python -m upscale_video_amd.build --instrument) */
 /* Debug: replays one trunk-layer launch on the last call's workspace with in-kernel cycle stamps
  * of workgroup 0 / wave 0: out[8*i + {0,1,2,3,4}] = tile i {start, k-loop done, barrier passed,
  * epilogue done, epilogue staging written} in s_memtime ticks (out holds 8*max_tiles values).
@@ -132,11 +138,21 @@ int uva_net_kernel_stats(uva_net* net, int kind, long long* launches, double* to
  * power-limited state); *kernel_ms = mean launch time. */
 int uva_net_debug_trunk_stamps(uva_net* net, unsigned long long* out, int max_tiles, int* tiles, int ablate,
                                float* kernel_ms);
+#endif
 
 /* Test hook (host only, no device needed): the fp16 MFMA A-operand image convolution #conv_idx is
  * repacked into, [k-step][m-frag][lane][8].  *needed receives the element count.  conv_idx -1: the
  * last convolution as tail_kernel reads it (64-feature nets). */
 int uva_net_debug_packed_weights(uva_net* net, int conv_idx, uint16_t* out, size_t out_halfs, size_t* needed);
+
+/* Test hook (host only): the step lists trunk2_kernel (two fused trunk layers per launch) would walk for an
+ * h x w frame cut into reference tiles (tile_size, border; <= 0: one plane) on `grid` workgroups.  Every
+ * workgroup has `*stride` 32-byte entries of 8 words (csrc/uva_kernels.hip.h Trunk2Step), nsteps[b] of them
+ * real.  plane_hw receives h, w, activation pitch and array offset (pixels) of up to max_planes planes.
+ * Returns non-zero if steps_words (capacity in 32-bit words) is too small; *needed_words says how many. */
+int uva_debug_trunk2_schedule(int h, int w, int tile_size, int border, int grid, uint32_t* steps_words,
+                              size_t capacity_words, size_t* needed_words, int* nsteps, int* stride,
+                              long long* plane_info, int max_planes, int* nplanes, long long* guard_bytes);
 
 const char* uva_last_error(void);
 int uva_abi_version(void);

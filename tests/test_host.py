@@ -16,13 +16,19 @@ def test_library_exports_every_declared_symbol(uva):
     from upscale_video_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "uva.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)   # prototypes only, not the comments
+    instr = re.findall(r"#ifdef UVA_INSTRUMENT(.*?)#endif", hdr, flags=re.S)
+    hdr = re.sub(r"#ifdef UVA_INSTRUMENT.*?#endif", "", hdr, flags=re.S)
     declared = sorted(set(re.findall(r"\b(uva_[a-z0-9_]+)\s*\(", hdr)))
     assert len(declared) >= 20
     assert sorted(_lib.SYMBOLS) == declared
+    # the instrumentation entry points are declared for -DUVA_INSTRUMENT builds only and are NOT in the product library
+    instr_declared = sorted(set(re.findall(r"\b(uva_[a-z0-9_]+)\s*\(", "".join(instr))))
+    assert instr_declared == sorted(_lib.INSTRUMENT_SYMBOLS)
+    assert not any(hasattr(ctypes.CDLL(_lib.LIB_PATH), n) for n in instr_declared)
     L = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert _lib.load().uva_abi_version() == 2
+    assert _lib.load().uva_abi_version() == 3
 
 
 @pytest.mark.parametrize("key,facts", [("2x", (2, 64, 18)), ("4x", (4, 64, 18)), ("1x", (1, 24, 10))])

@@ -43,11 +43,48 @@ def test_tile_window_matches_reference_logic(h, w, ts):
             assert up.tile_window(ts, y, x, h, w) == _reference_window(ts, y, x, h, w)
 
 
-def test_init_worker_rejects_out_of_range_and_cpu(monkeypatch):
+def test_init_worker_records_failures_instead_of_exiting(monkeypatch, tmp_path):
+    """A Pool respawns a worker that dies in its initializer, forever: a worker that cannot
+    be set up stays alive and every task it gets comes back as the reference's error items."""
+    for gpus in ([], [-1]):
+        up.init_worker(gpus, 0, "models", "x_Compact_Pretrain", 2, "input", "output")
+        assert up.net is None and up.init_error
+        items = up.upscale_image(str(tmp_path / "1.extract.png"), str(tmp_path / "1.png"), 2, 1, 1, 1)
+        assert items[0] == ["error", "Upscale failed"] and items[1][0] == "error"
+        items = up.apply_model(str(tmp_path / "1.extract.png"), str(tmp_path / "1.anime.png"), True)
+        assert items[0] == ["error", "Model processing failed"]
+        with pytest.raises(SystemExit):
+            up.logging_callback(items)
+    up.init_worker([0], 0, str(tmp_path), "x_missing_model", 2, "input", "output")
+    assert up.net is None and "x_missing_model" in up.init_error
+
+
+@pytest.mark.parametrize("persistent", [True, False])
+def test_frame_queue_with_unusable_gpu_list_returns(monkeypatch, tmp_path, persistent):
+    """process_model / upscale_frames with -g -1 end with the reference's exit, they do not hang."""
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(up, "PERSISTENT_WORKERS", persistent)
+    _imageio.imwrite("1.extract.png", np.zeros((8, 8, 3), np.uint8))
     with pytest.raises(SystemExit):
-        up.init_worker([], 0, "models", "x_Compact_Pretrain", 2, "input", "output")
+        up.process_model(1, "models", "x_HurrDeblur_SubCompact_nf24-nc8_244k_net_g", 1, "input", "output",
+                         "extract", "anime", [-1], 0)
     with pytest.raises(SystemExit):
-        up.init_worker([-1], 0, "models", "x_Compact_Pretrain", 2, "input", "output")
+        up.upscale_frames(1, 1, 1, "extract", 2, [], 0, "models", "x_Compact_Pretrain", "input", "output")
+    assert __import__("os").path.exists("1.extract.png")
+
+
+def test_reference_shaped_pool_reports_a_failed_worker_and_returns(monkeypatch, tmp_path):
+    """PERSISTENT_WORKERS = False (fresh spawn Pool + init_worker, reference :565-577): a model that
+    cannot be loaded makes every frame an error item; the run ends with SystemExit from the main
+    thread after the pool has been joined, and the inputs are still there for the next run."""
+    import os
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(up, "PERSISTENT_WORKERS", False)
+    for n in (1, 2, 3):
+        _imageio.imwrite("%d.extract.png" % n, np.zeros((8, 8, 3), np.uint8))
+    with pytest.raises(SystemExit):
+        up.upscale_frames(1, 1, 3, "extract", 2, [0, 0], 0, str(tmp_path), "x_no_such_model", "input", "output")
+    assert all(os.path.exists("%d.extract.png" % n) for n in (1, 2, 3))
 
 
 def test_imageio_roundtrip_is_bgr(tmp_path):

@@ -6,17 +6,19 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UVA_LIB_PATH") or os.path.join(_HERE, "libuva.so")   # override: A/B builds
 
 # every symbol include/uva.h declares
-ABI_VERSION = 2   # include/uva.h UVA_ABI_VERSION
+ABI_VERSION = 3   # include/uva.h UVA_ABI_VERSION
 
 SYMBOLS = [
-    "uva_get_gpu_count", "uva_get_default_gpu_index", "uva_get_gpu_info", "uva_destroy_gpu_instance",
+    "uva_get_gpu_count", "uva_get_default_gpu_index", "uva_get_gpu_info", "uva_get_gpu_pci_bus_id",
+    "uva_debug_trunk2_schedule", "uva_destroy_gpu_instance",
     "uva_net_create", "uva_net_set_device", "uva_net_load_param", "uva_net_load_model",
     "uva_net_destroy", "uva_net_scale", "uva_net_num_features", "uva_net_num_convs",
     "uva_net_extract_f32", "uva_net_process_u8", "uva_net_process_u8_device", "uva_net_synchronize",
     "uva_net_wait_for", "uva_net_submit_u8", "uva_net_collect_u8", "uva_host_alloc", "uva_host_free",
     "uva_net_debug_read_activation", "uva_net_set_profiling", "uva_net_kernel_stats",
-    "uva_net_debug_packed_weights", "uva_net_debug_trunk_stamps", "uva_last_error", "uva_abi_version",
+    "uva_net_debug_packed_weights", "uva_last_error", "uva_abi_version",
 ]
+INSTRUMENT_SYMBOLS = ["uva_net_debug_trunk_stamps"]     # only in a -DUVA_INSTRUMENT build (build.py --instrument)
 
 _lib = None
 
@@ -41,6 +43,13 @@ def load():
     L.uva_get_default_gpu_index.restype = c_i
     L.uva_get_gpu_info.restype = c_i
     L.uva_get_gpu_info.argtypes = [c_i, ctypes.POINTER(c_i), ctypes.c_char_p, c_sz]
+    if not hasattr(L, "uva_get_gpu_pci_bus_id"):     # an older A/B build (UVA_LIB_PATH)
+        _lib = L
+        return L
+    L.uva_get_gpu_pci_bus_id.argtypes = [c_i, ctypes.c_char_p, c_sz]
+    L.uva_debug_trunk2_schedule.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_sz, ctypes.POINTER(c_sz), c_p,
+                                            ctypes.POINTER(c_i), c_p, c_i, ctypes.POINTER(c_i),
+                                            ctypes.POINTER(ctypes.c_longlong)]
     L.uva_destroy_gpu_instance.restype = None
     L.uva_net_create.restype = c_p
     L.uva_net_destroy.argtypes = [c_p]
@@ -66,12 +75,15 @@ def load():
     L.uva_net_kernel_stats.argtypes = [c_p, c_i, ctypes.POINTER(ctypes.c_longlong),
                                        ctypes.POINTER(ctypes.c_double)]
     L.uva_net_debug_packed_weights.argtypes = [c_p, c_i, c_p, c_sz, ctypes.POINTER(c_sz)]
-    L.uva_net_debug_trunk_stamps.argtypes = [c_p, c_p, c_i, ctypes.POINTER(c_i), c_i, ctypes.POINTER(ctypes.c_float)]
+    if hasattr(L, "uva_net_debug_trunk_stamps"):
+        L.uva_net_debug_trunk_stamps.argtypes = [c_p, c_p, c_i, ctypes.POINTER(c_i), c_i, ctypes.POINTER(ctypes.c_float)]
     L.uva_last_error.restype = ctypes.c_char_p
     L.uva_abi_version.restype = c_i
+    ab_build = bool(os.environ.get("UVA_LIB_PATH"))   # an older build under comparison may lack newer entry points
     for n in SYMBOLS:   # AttributeError here means the .so is stale: rebuild it
-        getattr(L, n)
-    if L.uva_abi_version() != ABI_VERSION:
+        if not ab_build:
+            getattr(L, n)
+    if L.uva_abi_version() != ABI_VERSION and not ab_build:
         raise UvaError("libuva.so has ABI version %d, this package needs %d: rebuild it" % (L.uva_abi_version(), ABI_VERSION))
     _lib = L
     return L

@@ -24,6 +24,18 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
+def build_instrumented(verbose=False):
+    """libuva_instr.so: the same sources with -DUVA_INSTRUMENT (in-kernel cycle stamps, the trunk kernel's
+    ablation variants, uva_net_debug_trunk_stamps).  Select it with UVA_LIB_PATH; tools/ only."""
+    out = os.path.join(_HERE, "libuva_instr.so")
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DUVA_INSTRUMENT",
+           "-Wall", "-Wno-unused-function"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 def build_lib(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU).  Returns the .so path."""
     if os.environ.get("UVA_LIB_PATH"):      # an A/B build selected by the caller: leave it alone
@@ -53,4 +65,8 @@ def build_lib(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build_lib(force=True, verbose=True))
+    import sys
+    if "--instrument" in sys.argv:
+        print(build_instrumented(verbose=True))
+    else:
+        print(build_lib(force=True, verbose=True))

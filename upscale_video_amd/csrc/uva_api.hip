@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <list>
 #include <memory>
@@ -48,15 +49,29 @@ struct Workspace {
     int ntiles = 0;     // 8-row work tiles (head, tail, 24-feature trunk)
     int ntiles4 = 0;    // 4-row work tiles (64-feature trunk kernel)
     size_t act_pixels = 0;
+    // Activation buffers: act_base[i] is the allocation, act[i] = act_base[i] + guard the planes.  The guard
+    // (zeroed, never written) on both ends keeps trunk2_kernel's halo reads of rows -2 / h+4 and columns
+    // -2 / pitch+1 -- which only ever feed pixels it masks to zero -- inside the allocation.
+    size_t guard_bytes = 0;
+    char* act_base[2] = {nullptr, nullptr};
     _Float16* act[2] = {nullptr, nullptr};
+    // trunk2_kernel (fused layer pair): per-workgroup step lists
+    Trunk2Step* d_steps2 = nullptr;
+    int* d_nsteps2 = nullptr;
+    int max_steps2 = 0, grid2 = 0;
     void release()
     {
         if (d_planes) (void)hipFree(d_planes);
         if (d_sched4) (void)hipFree(d_sched4);
+        if (d_steps2) (void)hipFree(d_steps2);
+        if (d_nsteps2) (void)hipFree(d_nsteps2);
         d_sched4 = nullptr;
-        if (act[0]) (void)hipFree(act[0]);
-        if (act[1]) (void)hipFree(act[1]);
+        d_steps2 = nullptr;
+        d_nsteps2 = nullptr;
+        if (act_base[0]) (void)hipFree(act_base[0]);
+        if (act_base[1]) (void)hipFree(act_base[1]);
         d_planes = nullptr;
+        act_base[0] = act_base[1] = nullptr;
         act[0] = act[1] = nullptr;
     }
 };
@@ -95,6 +110,8 @@ struct uva_net {
     float *d_fin = nullptr, *d_fout = nullptr;
     size_t d_fin_cap = 0, d_fout_cap = 0;
     _Float16* d_sink = nullptr;   // where out-of-image lanes of the trunk kernel store to
+    int last_act_buf = 0;         // which ping-pong buffer the last run_graph() left its last trunk activation in
+    bool fuse_pairs = true;       // 64-feature nets: trunk layers run two per launch (trunk2_kernel); UVA_TRUNK_FUSION=0 turns it off
     LastCall last;
     // pipelined host route (uva_net_submit_u8 / uva_net_collect_u8): H2D, kernels and D2H of
     // consecutive frames overlap on three streams; PIPE_SLOTS frames may be in flight
@@ -220,9 +237,12 @@ int launch_trunk64_t(uva_net* n, const ConvArgs& a)
 
 int launch_trunk64(uva_net* n, const ConvArgs& a, int ablate = 0)
 {
+#ifdef UVA_INSTRUMENT
     if (ablate == 1) return launch_trunk64_t<1>(n, a);
     if (ablate == 2) return launch_trunk64_t<2>(n, a);
     if (ablate == 4) return launch_trunk64_t<4>(n, a);
+#endif
+    (void)ablate;
     return launch_trunk64_t<0>(n, a);
 }
 
@@ -298,6 +318,108 @@ int launch_trunk(uva_net* n, const Workspace* ws, ConvArgs ca, int ablate = 0)
     return launch_conv(n, 0, ca);
 }
 
+// Step lists of trunk2_kernel for one frame geometry: every plane is cut into 30-column strips, a strip
+// is a column of 4-row steps walked top to bottom, and the sequence (plane, strip, step) is dealt out to
+// the workgroups in contiguous ranges of (nearly) equal length.  A range that ends inside a strip ends a
+// SEGMENT there: k producer steps yield 4k - 2 output rows (the consumer needs one intermediate row below
+// its last output row), the next segment starts on the following row and recomputes two intermediate rows.
+// Consecutive ranges go to the workgroups of one XCD (block b runs on XCD b % 8).
+int build_trunk2_schedule(const std::vector<PlaneDesc>& planes, int grid, size_t guard_bytes, std::vector<Trunk2Step>& steps,
+                          std::vector<int>& nsteps, int* max_steps)
+{
+    constexpr int PIXB = 128;
+    struct Seg { int plane, x0, ya, rows, k; };
+    long long total = 0;
+    for (const auto& p : planes) total += (long long)((p.w + T2_SW - 1) / T2_SW) * ((p.h + 2 + 3) / 4);
+    std::vector<std::vector<Seg>> per_wg;
+    int L = (int)std::max<long long>(4, (total + grid - 1) / grid);
+    for (;; ++L) {
+        per_wg.assign(1, {});
+        int cap = L;
+        bool ok = true;
+        auto next_wg = [&]() { per_wg.emplace_back(); cap = L; };
+        for (size_t pi = 0; pi < planes.size() && ok; ++pi) {
+            const PlaneDesc& p = planes[pi];
+            for (int x0 = 0; x0 < p.w; x0 += T2_SW) {
+                int y = 0;
+                while (y < p.h) {
+                    const int need = (p.h - y + 2 + 3) / 4;
+                    if (need <= cap) {
+                        per_wg.back().push_back({(int)pi, x0, y, p.h - y, need});
+                        cap -= need;
+                        y = p.h;
+                    } else if (cap < 2) {
+                        next_wg();
+                        continue;
+                    } else {
+                        per_wg.back().push_back({(int)pi, x0, y, 4 * cap - 2, cap});
+                        y += 4 * cap - 2;
+                        cap = 0;
+                    }
+                    if (cap == 0) next_wg();
+                }
+            }
+        }
+        while (!per_wg.empty() && per_wg.back().empty()) per_wg.pop_back();
+        if ((int)per_wg.size() <= grid) break;
+    }
+    *max_steps = L;
+    const int stride = L + T2_PAD_STEPS;
+    steps.assign((size_t)grid * stride, Trunk2Step{make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)});
+    nsteps.assign(grid, 0);
+    const int per_xcd = grid / 8;
+    for (size_t c = 0; c < per_wg.size(); ++c) {
+        const int b = (int)(c % per_xcd) * 8 + (int)(c / per_xcd);
+        Trunk2Step* out = steps.data() + (size_t)b * stride;
+        int g = 0;
+        for (const Seg& sg : per_wg[c]) {
+            const PlaneDesc& p = planes[sg.plane];
+            const int nb = (sg.rows + 3) / 4;
+            for (int j = 0; j < sg.k; ++j, ++g) {
+                const int yA = sg.ya - 1 + 4 * j;                        // first intermediate row of the block
+                // halo origin = input pixel (yA - 1, x0 - 2) = array position (yA, x0 - 1)
+                const long long ao = (long long)guard_bytes +
+                                     ((long long)p.act_off + (long long)yA * p.pitch + (sg.x0 - 1)) * PIXB;
+                if (ao < 0 || (ao >> 40)) return fail("activation buffer too large for the step encoding");
+                unsigned rmask = 0;
+                for (int r = 0; r < 4; ++r)
+                    if (yA + r >= 0 && yA + r < p.h) rmask |= 1u << r;
+                const unsigned c_lo = sg.x0 == 0 ? 1 : 0, c_hi = (unsigned)std::min(32, p.w - sg.x0 + 1);
+                out[g].a = make_uint4((unsigned)ao, (unsigned)(ao >> 32) | (rmask << 8) | (c_lo << 12) | (c_hi << 18) | (1u << 24),
+                                      (unsigned)(p.pitch * PIXB), (unsigned)sg.plane);
+                if (j < nb) {
+                    const int yo = sg.ya + 4 * j;
+                    const long long bo = (long long)guard_bytes +
+                                         ((long long)p.act_off + (long long)(yo + 1) * p.pitch + (sg.x0 + 1)) * PIXB;
+                    const unsigned vy = (unsigned)std::min(4, sg.ya + sg.rows - yo), vx = (unsigned)std::min(T2_SW, p.w - sg.x0);
+                    out[g].b = make_uint4((unsigned)bo, (unsigned)(bo >> 32) | (vy << 8) | (vx << 11) | (1u << 24),
+                                          (unsigned)(p.pitch * PIXB), (unsigned)sg.plane);
+                }
+            }
+        }
+        nsteps[b] = g;
+        for (int k = 0; k < T2_PAD_STEPS; ++k) {      // harmless re-fetches of the last tile, nothing active
+            out[g + k].a = out[g - 1].a;
+            out[g + k].a.y &= 0xffu;
+        }
+    }
+    return 0;
+}
+
+int launch_trunk2(uva_net* n, const Workspace* ws, const Trunk2Args& a)
+{
+    static bool attr_done[16] = {false};
+    const size_t lds = trunk2_lds_bytes<64>();
+    auto kfn = trunk2_kernel<64>;
+    if (n->device >= 16 || !attr_done[n->device]) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (n->device < 16) attr_done[n->device] = true;
+    }
+    hipLaunchKernelGGL(kfn, dim3(ws->grid2), dim3(512), lds, n->stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_head(uva_net* n, bool f32, const HeadArgs& a)
 {
     const dim3 grid(a.ntiles), block(256);
@@ -331,6 +453,7 @@ int ensure_device(uva_net* n)
         return fail(std::string("libuva is built for gfx950 (MI355X) only; device is ") + prop.gcnArchName);
     n->ncu = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking));
+    if (const char* e = std::getenv("UVA_TRUNK_FUSION")) n->fuse_pairs = std::atoi(e) != 0;
     n->dev_ready = true;
     HIP_TRY(hipMalloc((void**)&n->d_sink, 64 * 128 + 256));
     // weights: head, trunk..., tail
@@ -392,6 +515,28 @@ int build_planes(int h, int w, int tile_size, int border, std::vector<PlaneDesc>
     return 0;
 }
 
+// Work-tile counts, activation pitch and array offset of every plane (see PlaneDesc).
+void layout_planes(std::vector<PlaneDesc>& planes, size_t* pixels, int* ntiles, int* ntiles4)
+{
+    size_t pix = 0;
+    int tiles = 0, tiles4 = 0;
+    for (auto& p : planes) {
+        p.nty = (p.h + TH - 1) / TH;
+        p.ntx = (p.w + TW - 1) / TW;
+        p.pitch = p.ntx * TW + 2;
+        p.tile_begin = tiles;
+        p.nty4 = (p.h + 3) / 4;
+        p.tile_begin4 = tiles4;
+        p.act_off = (long long)pix;
+        tiles += p.nty * p.ntx;
+        tiles4 += p.nty4 * p.ntx;
+        pix += (size_t)(p.nty * TH + 2) * p.pitch;
+    }
+    if (pixels) *pixels = pix;
+    if (ntiles) *ntiles = tiles;
+    if (ntiles4) *ntiles4 = tiles4;
+}
+
 int get_workspace(uva_net* n, int h, int w, int tile_size, int border, Workspace** out)
 {
     if (tile_size <= 0) { tile_size = 0; border = 0; }
@@ -406,18 +551,7 @@ int get_workspace(uva_net* n, int h, int w, int tile_size, int border, Workspace
     if (build_planes(h, w, tile_size, border, ws.planes)) return 1;
     size_t pix = 0;
     int tiles = 0, tiles4 = 0;
-    for (auto& p : ws.planes) {
-        p.nty = (p.h + TH - 1) / TH;
-        p.ntx = (p.w + TW - 1) / TW;
-        p.pitch = p.ntx * TW + 2;
-        p.tile_begin = tiles;
-        p.nty4 = (p.h + 3) / 4;
-        p.tile_begin4 = tiles4;
-        p.act_off = (long long)pix;
-        tiles += p.nty * p.ntx;
-        tiles4 += p.nty4 * p.ntx;
-        pix += (size_t)(p.nty * TH + 2) * p.pitch;
-    }
+    layout_planes(ws.planes, &pix, &tiles, &tiles4);
     ws.ntiles = tiles;
     ws.ntiles4 = tiles4;
     ws.act_pixels = pix;
@@ -427,10 +561,14 @@ int get_workspace(uva_net* n, int h, int w, int tile_size, int border, Workspace
         n->wss.back().release();
         n->wss.pop_back();
     }
-    const size_t bytes = pix * (size_t)n->g.nf * 2;
+    int max_pitch = 0;
+    for (auto& p : ws.planes) max_pitch = std::max(max_pitch, p.pitch);
+    ws.guard_bytes = (size_t)8 * max_pitch * n->g.nf * 2;
+    const size_t bytes = pix * (size_t)n->g.nf * 2 + 2 * ws.guard_bytes;
     for (int i = 0; i < 2; ++i) {
-        HIP_TRY(hipMalloc((void**)&ws.act[i], bytes));
-        HIP_TRY(hipMemsetAsync(ws.act[i], 0, bytes, n->stream));   // the zero border lives here forever
+        HIP_TRY(hipMalloc((void**)&ws.act_base[i], bytes));
+        HIP_TRY(hipMemsetAsync(ws.act_base[i], 0, bytes, n->stream));   // the zero border lives here forever
+        ws.act[i] = (_Float16*)(ws.act_base[i] + ws.guard_bytes);
     }
     HIP_TRY(hipMalloc((void**)&ws.d_planes, ws.planes.size() * sizeof(PlaneDesc)));
     HIP_TRY(hipMemcpyAsync(ws.d_planes, ws.planes.data(), ws.planes.size() * sizeof(PlaneDesc),
@@ -454,6 +592,16 @@ int get_workspace(uva_net* n, int h, int w, int tile_size, int border, Workspace
         }
         HIP_TRY(hipMalloc((void**)&ws.d_sched4, sched4.size() * sizeof(uint4)));
         HIP_TRY(hipMemcpyAsync(ws.d_sched4, sched4.data(), sched4.size() * sizeof(uint4), hipMemcpyHostToDevice, n->stream));
+    }
+    std::vector<Trunk2Step> steps2;
+    std::vector<int> nsteps2;
+    if (n->g.nf == 64) {
+        ws.grid2 = std::max(8, (n->ncu / 8) * 8);
+        if (build_trunk2_schedule(ws.planes, ws.grid2, ws.guard_bytes, steps2, nsteps2, &ws.max_steps2)) return 1;
+        HIP_TRY(hipMalloc((void**)&ws.d_steps2, steps2.size() * sizeof(Trunk2Step)));
+        HIP_TRY(hipMalloc((void**)&ws.d_nsteps2, nsteps2.size() * sizeof(int)));
+        HIP_TRY(hipMemcpyAsync(ws.d_steps2, steps2.data(), steps2.size() * sizeof(Trunk2Step), hipMemcpyHostToDevice, n->stream));
+        HIP_TRY(hipMemcpyAsync(ws.d_nsteps2, nsteps2.data(), nsteps2.size() * sizeof(int), hipMemcpyHostToDevice, n->stream));
     }
     HIP_TRY(hipStreamSynchronize(n->stream));
     n->wss.push_front(ws);
@@ -525,21 +673,47 @@ int run_graph(uva_net* n, Workspace* ws, bool f32, const void* src, size_t src_s
     ca.ntiles = ws->ntiles;
     ca.tiles_per_xcd = (ws->ntiles + 7) / 8;
     ca.sink = n->d_sink;
+    // ping-pong: every launch (one trunk layer, or a fused pair of them) reads act[cur] and writes act[cur ^ 1]
+    int cur = 0;
+    n->last_act_buf = 0;
     for (int i = 1; i < nconv - 1; ++i) {
         if (stop_after >= 0 && i > stop_after) return 0;
-        ca.in_act = ws->act[(i - 1) & 1];
-        ca.out_act = ws->act[i & 1];
+        // two trunk layers per launch where a pair is wanted in full (a debug tap on layer i itself runs it alone)
+        if (n->fuse_pairs && ws->d_steps2 && i + 1 < nconv - 1 && (stop_after < 0 || i + 1 <= stop_after)) {
+            Trunk2Args ta;
+            std::memset(&ta, 0, sizeof ta);
+            ta.in_act = ws->act_base[cur];
+            ta.out_act = ws->act_base[cur ^ 1];
+            for (int k = 0; k < 2; ++k) {
+                ta.wpk[k] = n->layers[i + k].wpk;
+                ta.bias[k] = n->layers[i + k].bias;
+                ta.slope[k] = n->layers[i + k].slope;
+            }
+            ta.steps = ws->d_steps2;
+            ta.nsteps = ws->d_nsteps2;
+            ta.max_steps = ws->max_steps2;
+            ta.sink = n->d_sink;
+            if (launch_trunk2(n, ws, ta)) return 1;
+            ++i;
+            cur ^= 1;
+            n->last_act_buf = cur;
+            continue;
+        }
+        ca.in_act = ws->act[cur];
+        ca.out_act = ws->act[cur ^ 1];
         ca.wpk = n->layers[i].wpk;
         ca.bias = n->layers[i].bias;
         ca.slope = n->layers[i].slope;
         ca.reverse = i & 1;   // layer 1 walks backwards over what the head wrote last, layer 2 forwards, ...
         if (launch_trunk(n, ws, ca)) return 1;
+        cur ^= 1;
+        n->last_act_buf = cur;
     }
     if (stop_after >= 0) return 0;
     if (prof) HIP_TRY(hipEventRecord(ev.e[2], n->stream));
     ca.ntiles = ws->ntiles;
     ca.tiles_per_xcd = (ws->ntiles + 7) / 8;
-    ca.in_act = ws->act[(nconv - 2) & 1];
+    ca.in_act = ws->act[cur];
     ca.reverse = (nconv - 1) & 1;
     ca.out_act = nullptr;
     ca.wpk = n->layers[nconv - 1].wpk;
@@ -614,6 +788,15 @@ int uva_get_gpu_info(int index, int* type, char* name, size_t name_len)
     HIP_TRY(hipGetDeviceProperties(&prop, index));
     if (type) *type = prop.integrated ? 1 : 0;
     if (name && name_len) std::snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    return 0;
+}
+
+int uva_get_gpu_pci_bus_id(int index, char* out, size_t out_len)
+{
+    if (!out || out_len < 13) return fail("buffer too small for a PCI address");
+    const int count = uva_get_gpu_count();
+    if (index < 0 || index >= count) return fail("no such HIP device");
+    HIP_TRY(hipDeviceGetPCIBusId(out, (int)out_len, index));
     return 0;
 }
 
@@ -853,7 +1036,7 @@ int uva_net_debug_read_activation(uva_net* n, int conv_idx, float* out_chw, int 
     const int nf = n->g.nf;
     const size_t rows = (size_t)p.nty * TH + 2;
     std::vector<uint16_t> hbuf(rows * p.pitch * nf);
-    HIP_TRY(hipMemcpyAsync(hbuf.data(), ws->act[conv_idx & 1], hbuf.size() * 2, hipMemcpyDeviceToHost, n->stream));
+    HIP_TRY(hipMemcpyAsync(hbuf.data(), ws->act[n->last_act_buf], hbuf.size() * 2, hipMemcpyDeviceToHost, n->stream));
     HIP_TRY(hipStreamSynchronize(n->stream));
     for (int c = 0; c < nf; ++c)
         for (int y = 0; y < h; ++y)
@@ -880,6 +1063,7 @@ int uva_net_kernel_stats(uva_net* n, int kind, long long* launches, double* tota
     return 0;
 }
 
+#ifdef UVA_INSTRUMENT
 // debug: one trunk-layer launch on the last call's workspace with in-kernel s_memtime stamps
 // (block 0, wave 0): out[8*i + {0,1,2,3,4}] = tile i {start, k-loop done, barrier passed, epilogue done,
 // epilogue staging written}
@@ -919,7 +1103,7 @@ int uva_net_debug_trunk_stamps(uva_net* n, unsigned long long* out, int max_tile
         // the u8 tail kernel of the last host-route call instead of a trunk layer
         if (n->last.f32 || !n->last.dst) { (void)hipFree(d); return fail("tail stamps need a previous uva_net_process_u8 call"); }
         const int nconv = (int)n->g.convs.size();
-        ca.in_act = ws->act[(nconv - 2) & 1];
+        ca.in_act = ws->act[n->last_act_buf];
         ca.out_act = nullptr;
         ca.wpk = n->layers[nconv - 1].wpk;
         ca.bias = n->layers[nconv - 1].bias;
@@ -976,6 +1160,8 @@ int uva_net_debug_trunk_stamps(uva_net* n, unsigned long long* out, int max_tile
     return rc;
 }
 
+#endif  // UVA_INSTRUMENT
+
 // test hook: the packed MFMA weight image of convolution #conv_idx (host side, no device needed)
 int uva_net_debug_packed_weights(uva_net* n, int conv_idx, uint16_t* out, size_t out_halfs, size_t* needed)
 {
@@ -989,6 +1175,38 @@ int uva_net_debug_packed_weights(uva_net* n, int conv_idx, uint16_t* out, size_t
     else pack_conv3x3(n->g.convs[conv_idx], n->g.nf, pk, nullptr, nullptr);
     if (needed) *needed = pk.size();
     if (out && out_halfs >= pk.size()) std::memcpy(out, pk.data(), pk.size() * 2);
+    return 0;
+}
+
+int uva_debug_trunk2_schedule(int h, int w, int tile_size, int border, int grid, uint32_t* steps_words,
+                              size_t capacity_words, size_t* needed_words, int* nsteps, int* stride,
+                              long long* plane_info, int max_planes, int* nplanes, long long* guard_bytes)
+{
+    if (h <= 0 || w <= 0 || grid < 8 || grid % 8) return fail("bad argument");
+    std::vector<PlaneDesc> planes;
+    if (tile_size <= 0) { tile_size = 0; border = 0; }
+    if (build_planes(h, w, tile_size, border, planes)) return 1;
+    size_t pix = 0;
+    int max_pitch = 0;
+    layout_planes(planes, &pix, nullptr, nullptr);
+    for (auto& p : planes) max_pitch = std::max(max_pitch, p.pitch);
+    const size_t guard = (size_t)8 * max_pitch * 128;
+    std::vector<Trunk2Step> steps;
+    std::vector<int> ns;
+    int max_steps = 0;
+    if (build_trunk2_schedule(planes, grid, guard, steps, ns, &max_steps)) return 1;
+    if (needed_words) *needed_words = steps.size() * 8;
+    if (stride) *stride = max_steps + T2_PAD_STEPS;
+    if (nplanes) *nplanes = (int)planes.size();
+    if (guard_bytes) *guard_bytes = (long long)guard;
+    if (plane_info)
+        for (int i = 0; i < (int)planes.size() && i < max_planes; ++i) {
+            plane_info[4 * i + 0] = planes[i].h; plane_info[4 * i + 1] = planes[i].w;
+            plane_info[4 * i + 2] = planes[i].pitch; plane_info[4 * i + 3] = planes[i].act_off;
+        }
+    if (!steps_words || capacity_words < steps.size() * 8) return fail("steps buffer too small");
+    std::memcpy(steps_words, steps.data(), steps.size() * sizeof(Trunk2Step));
+    if (nsteps) std::copy(ns.begin(), ns.end(), nsteps);
     return 0;
 }
 

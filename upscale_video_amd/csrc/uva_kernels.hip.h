@@ -36,6 +36,17 @@
 
 #include <utility>
 
+// In-kernel cycle stamps (s_memtime of workgroup 0 / wave 0 per phase) and the trunk kernel's ablation
+// variants exist only in an instrumented build (-DUVA_INSTRUMENT: tools/trunk_anatomy.py, power_probe.py);
+// the product library compiles them out.
+#ifdef UVA_INSTRUMENT
+#define UVA_STAMP_ON(a) ((a).dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
+#define UVA_MEMTIME() __builtin_amdgcn_s_memtime()
+#else
+#define UVA_STAMP_ON(a) false
+#define UVA_MEMTIME() 0ull
+#endif
+
 namespace uva {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -469,7 +480,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a)
     constexpr int PF = (MODE == 0) ? 3 : (R == 4 ? 1 : 2);
     int cur = 0;            // ring slot of the tile being computed
 
-    const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+    const bool stamp = UVA_STAMP_ON(a);
     for (int it = 0; it < niter; ++it) {
         if (stamp) a.dbg[8 * it + 0] = __builtin_amdgcn_s_memtime();
         const TileId id = ids[0];
@@ -789,7 +800,7 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
                                // the wave's MFMA issue for ~60-150 cycles); the other CPW - CPW_K are
                                // issued by the same wave at the start of its (shorter) epilogue phase
 
-    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_entry = UVA_MEMTIME();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = lds_offset(smem);
     float* bias_lds = (float*)(smem + TRUNK_SLOTS * SLOTB);
@@ -842,7 +853,7 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
     int dma_pc[CPW];
 #pragma unroll
     for (int i = 0; i < CPW; ++i) dma_pc[i] = trunk_piece_const<NF>(i, wave, lane);
-    const unsigned long long t_sched = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_sched = UVA_MEMTIME();
 
     // accumulator chains start from C = 0 (an inline constant, no registers); the bias is added in
     // the epilogue, which has VALU slots to spare, rather than held in 16 more registers
@@ -886,7 +897,7 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
             for (int i = 0; i < CPW; ++i) trunk_issue_piece<NF>(s2.base, s2.pitch, lds0 + 2 * SLOTB, i, wave, dma_pc[i]);
         }
     }
-    const unsigned long long t_dma = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_dma = UVA_MEMTIME();
     // everything requested so far has landed -> publish the schedule table, then the workgroup barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int real0 = sched_real0;
@@ -915,7 +926,7 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
     int cur = grp;                   // ring slot of this group's current tile: (2*it + grp) % 5
     Sched la = read_sched(grp + TRUNK_LOOKAHEAD);   // look-ahead tile of the first k-loop
 
-    const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+    const bool stamp = UVA_STAMP_ON(a);
     if (stamp) { a.dbg[5] = t_entry; a.dbg[7] = t_sched; a.dbg[15] = t_dma; }
     for (int it = 0; it < niter0; ++it) {
         const bool active = it < niter;
@@ -1087,6 +1098,298 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
 }
 
 // ----------------------------------------------------------------------------------------------
+// trunk2_kernel<64>: TWO consecutive trunk layers (64 -> 64 -> 64, each + bias + PReLU) in one launch;
+// the activations between them never leave the CU.
+//
+// trunk_kernel is bound by the package power cap, and a third of a launch's energy is spent on the
+// 2 x 128 B per pixel that cross the Infinity Fabric.  Here the same 8-wave workgroup
+// runs its two 4-wave groups as a producer / consumer pair instead of as twins:
+//   group A (waves 0-3) holds the weights of layer i and computes it on 4-row x 32-column blocks of
+//            the INTERMEDIATE image, written as fp16 into a 12-row ring in LDS (same 144-byte pixel
+//            stride as a halo tile, so the consumer's B-fragment reads are the producer's reads);
+//   group B (waves 4-7) holds the weights of layer i+1 and computes 4 rows x 30 columns of its output
+//            from 6 rows x 32 columns of that ring, 2.5 steps behind A, and stores them to HBM.
+// The workgroup walks DOWN a 30-column strip of a plane, so the only recomputed intermediate pixels
+// are the 2 strip-edge columns (32 computed per 30 used: +6.7 % MFMA work on layer i, none on layer
+// i+1) and 2 rows per strip segment; a 2-D tile pair of the same LDS footprint would recompute
+// +59 % (6x34 per 4x32).  Ping-pong as in trunk_kernel: A's k-loop runs beside B's epilogue (stores),
+// B's k-loop beside A's epilogue (LDS writes + ALL LDS-DMA issue for A's input tile three steps
+// ahead), so neither k-loop contains anything but MFMAs and their fragment reads.
+//
+// Step g of a workgroup (host-built list, Trunk2Step):
+//   A: intermediate rows yA .. yA+3, columns x0-1 .. x0+30 (block g % 3 of the ring) from the 6 x 34
+//      input halo tile at (yA-1, x0-2) in ring slot g % 3; pixels outside the plane are written as
+//      ZERO (they are layer i+1's zero padding, not layer i's output there);
+//   B: output rows yA+1 .. yA+4 (= the rows whose 3x3 windows are complete once block g+1 exists),
+//      columns x0 .. x0+29, from ring blocks g % 3 and (g+1) % 3; executed in iteration g+2.
+// ----------------------------------------------------------------------------------------------
+constexpr int T2_SW = 30;                       // output columns per strip
+constexpr int T2_SLOTS = 3;                     // input halo-tile ring (A only: one tile per period)
+constexpr int T2_RING_ROWS = 12;                // intermediate ring: 3 blocks of 4 rows
+constexpr int T2_PAD_STEPS = 3;                 // dummy entries behind a workgroup's last step (DMA look-ahead)
+
+struct Trunk2Step {                             // 32 bytes
+    // A half: x = input halo origin byte offset (low 32), y = offset bits 32..39 | row mask << 8 (bit r:
+    // intermediate row r of the block is inside the plane) | c_lo << 12 | c_hi << 18 (intermediate columns
+    // [c_lo, c_hi) of the block are inside the plane) | active << 24, z = row pitch in bytes
+    uint4 a;
+    // B half: x = output origin byte offset (low 32), y = offset bits 32..39 | valid rows << 8 |
+    // valid columns << 11 | active << 24, z = row pitch in bytes
+    uint4 b;
+};
+static_assert(sizeof(Trunk2Step) == 32, "Trunk2Step layout");
+
+struct Trunk2Args {
+    const char* in_act;           // activation buffer INCLUDING its leading guard (offsets are from here)
+    char* out_act;
+    const half8* wpk[2];          // pack_trunk64 images of layer i and i+1
+    const float* bias[2];
+    const float* slope[2];
+    const Trunk2Step* steps;      // [gridDim.x][max_steps + T2_PAD_STEPS]
+    const int* nsteps;            // [gridDim.x]
+    int max_steps;
+    _Float16* sink;
+};
+
+template <int NF>
+constexpr int trunk2_lds_bytes()
+{
+    return T2_SLOTS * TrunkGeo<NF>::SLOTB + T2_RING_ROWS * PW * Geo<NF, TH4>::LPIXB + 2 * PARAM_LDS;
+}
+static_assert(trunk2_lds_bytes<64>() <= 160 * 1024, "trunk2 kernel LDS budget");
+
+template <int KEEP>
+__device__ __forceinline__ void dma_barrier()
+{
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(KEEP) : "memory");
+}
+
+template <int NF>
+__global__ __launch_bounds__(512, 2) void trunk2_kernel(Trunk2Args a)
+{
+    static_assert(NF == 64, "written for 64 features");
+    using G = Geo<NF, TH4>;
+    using TG = TrunkGeo<NF>;
+    constexpr int KS = G::KS;
+    constexpr int CPW = TG::CPW;
+    constexpr int SLOTB = TG::SLOTB;
+    constexpr int PFF = 6;
+    constexpr int ROWB = PW * G::LPIXB;            // one ring / halo-tile row in LDS
+    constexpr int BLOCKB = 4 * ROWB;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = lds_offset(smem);
+    char* const ring = smem + T2_SLOTS * SLOTB;
+    float* const prm_all = (float*)(ring + T2_RING_ROWS * ROWB);   // per layer: bias[64], slope[64], med3 selector[64]
+
+    const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave8 >> 2;   // 0: producer (layer i), 1: consumer (layer i+1)
+    const int wave = wave8 & 3;
+    const int lane = threadIdx.x & 63;
+    const int mh = wave & 1;      // which 32 output channels
+    const int rp = wave >> 1;     // which row pair of the 4-row block
+
+    const int nsteps = __builtin_amdgcn_readfirstlane(a.nsteps[blockIdx.x]);
+    if (nsteps <= 0) return;
+    const Trunk2Step* const steps = a.steps + (size_t)blockIdx.x * (a.max_steps + T2_PAD_STEPS);
+    auto load_a = [&](int g) __attribute__((always_inline)) { return scalar_load16(&steps[g].a); };
+    auto load_b = [&](int g) __attribute__((always_inline)) { return scalar_load16(&steps[g].b); };
+
+    // this wave's half of its layer's weights, resident in registers for the whole kernel
+    half8 w[KS];
+    {
+        const half8* wp = grp ? a.wpk[1] : a.wpk[0];
+#pragma unroll
+        for (int i = 0; i < KS; ++i) w[i] = wp[((i >> 1) * 4 + 2 * mh + (i & 1)) * 64 + lane];
+    }
+    float prm_b = 0.f, prm_s = 0.f;
+    if (lane < 64 && wave == 0) {
+        prm_b = (grp ? a.bias[1] : a.bias[0])[lane];
+        prm_s = (grp ? a.slope[1] : a.slope[0])[lane];
+    }
+    int dma_pc[CPW];
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) dma_pc[i] = trunk_piece_const<NF>(i, wave, lane);
+
+    auto issue_tile = [&](const uint4 e, int slot) __attribute__((always_inline)) {
+        const unsigned lo = __builtin_amdgcn_readfirstlane(e.x), hi = __builtin_amdgcn_readfirstlane(e.y) & 0xffu;
+        const char* base = a.in_act + (((unsigned long long)hi << 32) | lo);
+        const int pitch = __builtin_amdgcn_readfirstlane(e.z);
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) trunk_issue_piece<NF>(base, pitch, lds0 + slot * SLOTB, i, wave, dma_pc[i]);
+    };
+    if (grp == 0) {
+        // prologue: the first three input tiles (entries behind the last step are valid dummies)
+#pragma unroll
+        for (int g = 0; g < T2_SLOTS; ++g) issue_tile(load_a(g), g);
+    }
+    if (wave == 0) {
+        float* prm = prm_all + grp * (PARAM_LDS / 4);
+        prm[lane] = prm_b;
+        prm[64 + lane] = prm_s;
+        prm[128 + lane] = prm_s <= 1.f ? __builtin_inff() : -__builtin_inff();
+    }
+    tile_barrier<0>();                 // weights, parameters and the first tiles have landed
+    if (grp == 1) group_barrier();     // the consumer runs half a period behind the producer
+
+    const float* const bias_lds = prm_all + grp * (PARAM_LDS / 4);
+    const float* const prm_lds = bias_lds + 64;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    char* const sink = (char*)a.sink + lane * G::PIXB;
+
+    // entries this group needs in its next epilogue phase, fetched one iteration ahead through the
+    // scalar cache: A: masks of step it, input tile of step it + 3;  B: output tile of step it - 2
+    uint4 e_own = grp ? make_uint4(0, 0, 0, 0) : load_a(0);
+    uint4 e_dma = grp ? make_uint4(0, 0, 0, 0) : load_a(T2_SLOTS);
+
+    const int niter = nsteps + 2;
+    int blk = 0;                       // it % 3: A's input slot and ring block; B reads blocks blk+1, blk+2 (mod 3)
+    for (int it = 0; it < niter; ++it) {
+        const bool work = grp ? it >= 2 : it < nsteps;
+        f32x4 acc[2][2][2];            // [output row n][column half c][16-channel block m]
+        if (work) {
+            // ---- k-loop phase: MFMAs and their fragment reads, nothing else (see trunk_kernel) ----------
+            __builtin_amdgcn_s_setprio(2);
+            // A: halo tile in slot blk.  B: 6 ring rows starting at block (it - 2) % 3 = (blk + 1) % 3; the ring
+            // wraps behind row 11, which only the second row pair (rows 2..5 of the window) can cross.
+            const int bblk = blk + 1 >= 3 ? blk - 2 : blk + 1;
+            const char* const win = grp ? ring + bblk * BLOCKB : smem + blk * SLOTB;
+            const char* const bbase_lo = win + ((2 * rp) * PW + (lane & 15)) * G::LPIXB + (lane >> 4) * 16;
+            const char* const bbase_hi = bbase_lo - ((grp && rp && bblk == 2) ? T2_RING_ROWS * ROWB : 0);
+            auto read_b = [&](int f) __attribute__((always_inline)) -> half8 {
+                const int st = f >> 1, c = f & 1;
+                const int R = st & 3, ch = (st >> 2) & 1, dx = st >> 3;
+                return *(const half8*)((R < 2 ? bbase_lo : bbase_hi) + (R * PW + dx + 16 * c) * G::LPIXB + ch * 64);
+            };
+            constexpr int NSTEP = 24, NFRAG = 48;
+            constexpr int RQ = PFF + 2;
+            half8 bq[RQ];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int f = 0; f < PFF; ++f) bq[f] = read_b(f);
+#pragma unroll
+            for (int st = 0; st < NSTEP; ++st) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    if (2 * st + c + PFF < NFRAG) bq[(2 * st + c + PFF) % RQ] = read_b(2 * st + c + PFF);
+                const int R = st & 3, ch = (st >> 2) & 1, dx = st >> 3;
+                const half8 b0 = bq[(2 * st) % RQ], b1 = bq[(2 * st + 1) % RQ];
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    if (n == 0 ? R > 2 : R < 1) continue;       // output row n, tap (dy = R - n, dx)
+                    const bool first = st == n;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const half8 wv = w[(((R - n) * 3 + dx) * 2 + ch) * 2 + m];
+                        acc[n][0][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, b0, first ? zero4 : acc[n][0][m], 0, 0, 0);
+                        acc[n][1][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, b1, first ? zero4 : acc[n][1][m], 0, 0, 0);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, PFF, 0);
+#pragma unroll
+            for (int st = 0; st < NSTEP; ++st) {
+                const int R = st & 3;
+                const bool light = R == 0 || R == 3;
+                const bool rd = 2 * st + PFF < NFRAG;
+                if (light) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); else __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                if (rd) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (light) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); else __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                if (rd) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+        group_barrier();               // roles swap: every wave is done reading slot / blocks of this phase
+        // ---- epilogue phase ---------------------------------------------------------------------------
+        const int lane_o = opaque(lane);
+        const int cg = lane_o >> 4, p = lane_o & 15;
+        f32x4 b4[2], s4[2], i4[2];
+        if (work) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int cl = 32 * mh + 16 * m + 4 * cg;
+                b4[m] = *(const f32x4*)(bias_lds + cl);
+                s4[m] = *(const f32x4*)(prm_lds + cl);
+                i4[m] = *(const f32x4*)(prm_lds + 64 + cl);
+            }
+        }
+        if (grp == 0) {
+            // input tile of step it + 3 -> the slot this k-loop has just released; the pieces issued one and
+            // two epilogues ago (steps it + 2, it + 1) are older, so "at most two tiles' pieces outstanding"
+            // at the closing barrier proves step it + 1's tile
+            issue_tile(e_dma, blk);
+            if (work) {
+                const unsigned ey = __builtin_amdgcn_readfirstlane(e_own.y);
+                const int rmask = (ey >> 8) & 15, c_lo = (ey >> 12) & 63, c_hi = (ey >> 18) & 63;
+                char* const wbase = ring + blk * BLOCKB + ((2 * rp) * PW + p) * G::LPIXB + (32 * mh + 4 * cg) * 2;
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const bool inside = ((rmask >> (2 * rp + n)) & 1) && 16 * c + p >= c_lo && 16 * c + p < c_hi;
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            f32x4 v;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float xv = acc[n][c][m][j] + b4[m][j];
+                                v[j] = __builtin_amdgcn_fmed3f(xv, xv * s4[m][j], i4[m][j]);
+                            }
+                            uint2 o;
+                            o.x = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, half2v));
+                            o.y = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, half2v));
+                            if (!inside) o = make_uint2(0, 0);   // layer i+1's zero padding
+                            *(uint2*)(wbase + (n * PW + 16 * c) * G::LPIXB + 32 * m) = o;
+                        }
+                    }
+            }
+            e_own = load_a(min(it + 1, nsteps - 1));
+            e_dma = load_a(it + 1 + T2_SLOTS <= nsteps + T2_PAD_STEPS - 1 ? it + 1 + T2_SLOTS : nsteps + T2_PAD_STEPS - 1);
+            if (wave == 0) dma_barrier<2 * CPW>(); else dma_barrier<2 * (CPW - 1)>();
+        } else {
+            if (work) {
+                const unsigned lo = __builtin_amdgcn_readfirstlane(e_own.x), ey = __builtin_amdgcn_readfirstlane(e_own.y);
+                const size_t off = ((unsigned long long)(ey & 0xffu) << 32) | lo;
+                const int pitch = __builtin_amdgcn_readfirstlane(e_own.z);
+                const int vy = (ey >> 8) & 7, vx = (ey >> 11) & 31;
+                char* const obase = a.out_act + off + 64 * mh + (size_t)p * G::PIXB + 32 * (cg & 1) + 8 * (cg & 2) +
+                                    (size_t)(2 * rp) * pitch;
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        unsigned o[2][2];
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            f32x4 v;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float xv = acc[n][c][m][j] + b4[m][j];
+                                v[j] = __builtin_amdgcn_fmed3f(xv, xv * s4[m][j], i4[m][j]);
+                            }
+                            o[m][0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, half2v));
+                            o[m][1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, half2v));
+                        }
+                        // lane exchange: see trunk_kernel's epilogue
+                        const auto x = __builtin_amdgcn_permlane16_swap(o[0][0], o[1][0], false, false);
+                        const auto y = __builtin_amdgcn_permlane16_swap(o[0][1], o[1][1], false, false);
+                        const uint4 val = make_uint4(x[0], y[0], x[1], y[1]);
+                        const bool ok = 2 * rp + n < vy && 16 * c + p < vx;
+                        char* dst = ok ? obase + ((size_t)n * pitch + (size_t)(16 * c) * G::PIXB) : sink;
+                        *(uint4*)dst = val;
+                    }
+            }
+            e_own = load_b(max(it - 1, 0));      // step (it + 1) - 2
+            group_barrier();
+        }
+        blk = blk + 1 == 3 ? 0 : blk + 1;
+    }
+    if (grp == 0) group_barrier();
+    // nothing of the dummy look-ahead tiles may land after the workgroup's LDS is released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ----------------------------------------------------------------------------------------------
 // tail_kernel<64, 2>: the u8 tail of the 2x net (conv 64 -> 12, PixelShuffle(2), + nearest-upsampled
 // normalised input, *255, cv2 convertTo(CV_8U), core crop) on trunk_kernel's skeleton: 8-wave
 // workgroup, two 4-wave groups in ping-pong, 4x32 work tiles, the same 5-slot LDS ring and tile
@@ -1235,7 +1538,7 @@ __global__ __launch_bounds__(512, 2) void tail_kernel(ConvArgs a)
 
     const unsigned resid_lds = lds0 + (unsigned)(resid_all - smem) + wave8 * 128;
     const char* const resid_rd = resid_all + wave8 * 128;
-    const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+    const bool stamp = UVA_STAMP_ON(a);
     for (int it = 0; it < niter0; ++it) {
         const bool active = it < niter;
         const int k = 2 * it + grp;

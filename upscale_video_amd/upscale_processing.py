@@ -14,8 +14,14 @@ import these instead of its own.  Differences, all behind the same signatures:
     (Net.process_u8): normalise, every tile, *255 and the cv2 u8 conversion happen on the GPU and
     only u8 crosses PCIe.  The tile-by-tile float route of the reference is kept
     (FUSED_DEVICE_PATH = False) and is what the parity tests compare the fused route against;
-  * PNG I/O goes through cv2 when present, Pillow otherwise (_imageio.py).
+  * PNG I/O goes through cv2 when present, Pillow otherwise (_imageio.py);
+  * process_model / upscale_frames keep their signatures but, with PERSISTENT_WORKERS (default), hand
+    the batch to a FramePool (frame_pool.py): the worker processes, their nets and workspaces survive
+    from batch to batch instead of being rebuilt per call (reference :565-577, :923-948), and PNG
+    decode / encode run beside the GPU instead of around it.  PERSISTENT_WORKERS = False is the
+    reference-shaped route (a fresh spawn Pool + init_worker per call, `workers_used` offsets).
 """
+import atexit
 import logging
 import math
 import multiprocessing
@@ -30,6 +36,8 @@ from ._imageio import imread, imwrite
 net = None
 model_input_name = "input"
 model_output_name = "output"
+init_error = None      # why this worker has no net (init_worker never exits: a Pool respawns a dead worker forever)
+PERSISTENT_WORKERS = True
 
 TILE_SIZE = 960        # upscale_processing.py:489
 TILE_BORDER = 10       # upscale_processing.py:409-427
@@ -73,24 +81,32 @@ def init_worker(gpus, workers_used, model_path, model_file, scale, model_input, 
     """Pool initializer: position of this worker in the pool picks its entry of the -g list
     (duplicates allowed: '0,0,1' = two workers on GPU 0), then the net is built and loaded from
     models/<scale><model_file>.param|.bin  (reference :54-73)."""
-    global net, model_input_name, model_output_name
+    global net, model_input_name, model_output_name, init_error
 
+    # A Pool replaces a worker that dies in its initializer, and the replacement (a higher pool
+    # identity) dies the same way: pool.join() would never return.  So a worker that cannot be set up
+    # stays alive without a net and every task it receives comes back as error items -- which is how
+    # the reference reports a failed frame (:289-293) and what makes logging_callback end the run.
+    net, init_error = None, None
     gpu = _worker_slot(workers_used)
-    if gpu > len(gpus) - 1:
-        logging.error("Unable to assign GPU to new worker.")
-        sys.exit("Error - Exiting")
-    if gpus[gpu] < 0:
-        logging.error("GPU index %d: this build has no CPU path." % gpus[gpu])
-        sys.exit("Error - Exiting")
-
-    net = ncnn.Net()
-    net.opt.use_vulkan_compute = True
-    net.set_vulkan_device(gpus[gpu])
-
-    base = os.path.join(model_path, str(scale) + model_file)
-    if net.load_param(base + ".param") or net.load_model(base + ".bin"):
-        logging.error("Unable to load model %s: %s" % (base, getattr(net, "last_error", "")))
-        sys.exit("Error - Exiting")
+    if gpu > len(gpus) - 1 or gpu < 0:
+        init_error = "Unable to assign GPU to new worker."
+    elif gpus[gpu] < 0:
+        init_error = "GPU index %d: this build has no CPU path." % gpus[gpu]
+    if init_error is None:
+        try:
+            candidate = ncnn.Net()
+            candidate.opt.use_vulkan_compute = True
+            candidate.set_vulkan_device(gpus[gpu])
+            base = os.path.join(model_path, str(scale) + model_file)
+            if candidate.load_param(base + ".param") or candidate.load_model(base + ".bin"):
+                init_error = "Unable to load model %s: %s" % (base, getattr(candidate, "last_error", ""))
+            else:
+                net = candidate
+        except Exception as e:  # noqa: BLE001 - libuva.so missing, no HIP device, ...
+            init_error = "%s: %s" % (type(e).__name__, e)
+    if init_error is not None:
+        logging.error(init_error)
     model_input_name = model_input
     model_output_name = model_output
 
@@ -110,6 +126,8 @@ def _run_net(tile_bgr):
 def apply_model(input_file, output_file, remove):
     """1x whole-frame pass (the '-m a' HurrDeblur stage): PNG -> net -> PNG  (reference :258-299)."""
     logging_items = []
+    if net is None:
+        return [["error", "Model processing failed"], ["error", init_error or "worker has no net: init_worker was not run"]]
     img = imread(input_file)
     try:
         if img is None:
@@ -140,19 +158,111 @@ def _pool(gpus, workers_used, model_path, model_file, scale, model_input, model_
     )
 
 
+class _Collector:
+    """apply_async callback for the reference-shaped route.  The reference calls sys.exit from the
+    callback (:47-51), i.e. inside the pool's result-handler thread, which ends that thread and not the
+    program; here the failure is remembered and the main thread exits once the pool has been joined."""
+
+    def __init__(self):
+        self.failed = None
+
+    def __call__(self, log_list):
+        if self.failed is not None:
+            return
+        try:
+            logging_callback(log_list)
+        except SystemExit as e:
+            self.failed = e
+
+    def finish(self):
+        if self.failed is not None:
+            raise self.failed
+
+
+def _check_gpus(gpus):
+    """Parent-side validation before any worker exists (the reference would only find out inside a worker)."""
+    if not gpus:
+        logging.error("No GPUs given.")
+        sys.exit("Error - Exiting")
+    for g in gpus:
+        if g < 0:
+            logging.error("GPU index %d: this build has no CPU path." % g)
+            sys.exit("Error - Exiting")
+
+
+_frame_pools = {}
+NET_FACTORY = None     # "module:function" override of frame_pool.load_reference_net (tests)
+
+
+def get_frame_pool(gpus):
+    """The persistent FramePool of this `-g` list, created on first use and kept until shutdown_workers()."""
+    from . import frame_pool
+    key = tuple(gpus)
+    pool = _frame_pools.get(key)
+    if pool is None or pool.closed or not all(p.is_alive() for p in pool.procs):
+        if pool is not None:
+            pool.close(timeout=1.0)
+        kw = {"net_factory": NET_FACTORY} if NET_FACTORY else {}
+        pool = frame_pool.FramePool(list(gpus), **kw)
+        _frame_pools[key] = pool
+    return pool
+
+
+def shutdown_workers():
+    """Ends every persistent worker (also registered with atexit)."""
+    for pool in list(_frame_pools.values()):
+        pool.close()
+    _frame_pools.clear()
+
+
+atexit.register(shutdown_workers)
+
+
+def _run_persistent(gpus, tasks):
+    from . import frame_pool
+    pool = get_frame_pool(gpus)
+    try:
+        pool.run(tasks, callback=logging_callback)
+    except frame_pool.WorkerDied as e:
+        _frame_pools.pop(tuple(gpus), None)
+        logging.error(e)
+        sys.exit("Error - Exiting")
+    except BaseException:
+        # an error item (SystemExit from logging_callback), a dead worker or Ctrl-C: frames not yet
+        # started keep their inputs, so a rerun picks up exactly what is missing
+        pool.abort()
+        _frame_pools.pop(tuple(gpus), None)
+        raise
+
+
 def process_model(frames_count, model_path, model_file, scale, model_input, model_output, input_file_tag,
                   output_file_tag, gpus, workers_used, remove=True):
     """Frame work queue for a 1x model: one spawned worker per -g entry, one task per existing
     '<n>.<input_tag>.png'  (reference :302-347).  No collective: frames are independent."""
     frames = range(1, frames_count + 1) if isinstance(frames_count, int) else frames_count
+    _check_gpus(gpus)
+    if PERSISTENT_WORKERS:
+        tasks = []
+        for frame in frames:
+            src = "%s.%s.png" % (frame, input_file_tag)
+            dst = "%s.%s.png" % (frame, output_file_tag)
+            if os.path.exists(src):
+                tasks.append(dict(src=src, dst=dst, model_path=model_path, model_file=model_file, scale=scale,
+                                  tile_size=0, border=0, remove=remove,
+                                  log_ok=[["info", "Processed Model: " + dst]],
+                                  log_error=lambda e: [["error", "Model processing failed"], ["error", e]]))
+        _run_persistent(gpus, tasks)
+        return
     pool = _pool(gpus, workers_used, model_path, model_file, scale, model_input, model_output)
+    collect = _Collector()
     for frame in frames:
         src = "%s.%s.png" % (frame, input_file_tag)
         dst = "%s.%s.png" % (frame, output_file_tag)
         if os.path.exists(src):
-            pool.apply_async(apply_model, args=(src, dst, remove), callback=logging_callback)
+            pool.apply_async(apply_model, args=(src, dst, remove), callback=collect)
     pool.close()
     pool.join()
+    collect.finish()
 
 
 def tile_window(tile_size, y, x, height, width, border=TILE_BORDER):
@@ -189,6 +299,8 @@ def process_tile(img, tile_size, scale, y, x, height, width, output, logging_ite
 def upscale_image(input_file_name, output_file_name, scale, frame_batch, frame, end_frame, remove=True):
     """2x/4x of one frame with the reference's 960-px tiling  (reference :480-542)."""
     logging_items = []
+    if net is None:
+        return [["error", "Upscale failed"], ["error", init_error or "worker has no net: init_worker was not run"]]
     img = imread(input_file_name)
     if img is None:
         logging_items.append(["error", "Upscale failed"])
@@ -224,14 +336,17 @@ def upscale_image(input_file_name, output_file_name, scale, frame_batch, frame, 
     if remove:
         os.remove(input_file_name)
 
+    logging_items.append(_progress_item(frame_batch, frame, end_frame, output_file_name))
+    return logging_items
+
+
+def _progress_item(frame_batch, frame, end_frame, output_file_name):
+    """the reference's per-frame progress line (:524-540)"""
     if frame_batch:
         if isinstance(frame_batch, int):
-            logging_items.append(["info", "Upscaling Batch: %s : Upscaled %s/%s" % (frame_batch, frame, end_frame)])
-        else:
-            logging_items.append(["info", "Upscaled " + str(output_file_name)])
-    else:
-        logging_items.append(["info", "Upscaled %s/%s" % (frame, end_frame)])
-    return logging_items
+            return ["info", "Upscaling Batch: %s : Upscaled %s/%s" % (frame_batch, frame, end_frame)]
+        return ["info", "Upscaled " + str(output_file_name)]
+    return ["info", "Upscaled %s/%s" % (frame, end_frame)]
 
 
 def upscale_frames(frame_batch, start_frame, end_frame, input_file_tag, scale, gpus, workers_used, model_path,
@@ -241,7 +356,23 @@ def upscale_frames(frame_batch, start_frame, end_frame, input_file_tag, scale, g
         frames = frame_batch
     else:
         frames = range(start_frame, end_frame + 1)
+    _check_gpus(gpus)
+    if PERSISTENT_WORKERS:
+        tasks = []
+        for frame in frames:
+            src = "%s.%s.png" % (frame, input_file_tag)
+            dst = "%s.png" % frame
+            if os.path.exists(src):
+                # the tile lines of upscale_image (:508) cannot be known before the PNG is decoded in the
+                # worker; the frame's progress line is what the orchestrator's log shows at info level
+                tasks.append(dict(src=src, dst=dst, model_path=model_path, model_file=model_file, scale=scale,
+                                  tile_size=TILE_SIZE, border=TILE_BORDER, remove=remove,
+                                  log_ok=[_progress_item(frame_batch, frame, end_frame, dst)],
+                                  log_error=lambda e: [["error", "Upscale failed"], ["error", e]]))
+        _run_persistent(gpus, tasks)
+        return
     pool = _pool(gpus, workers_used, model_path, model_file, scale, model_input, model_output)
+    collect = _Collector()
     for frame in frames:
         src = "%s.%s.png" % (frame, input_file_tag)
         dst = "%s.png" % frame
@@ -249,7 +380,8 @@ def upscale_frames(frame_batch, start_frame, end_frame, input_file_tag, scale, g
             pool.apply_async(
                 upscale_image,
                 args=(src, dst, scale, frame_batch, frame, end_frame, remove),
-                callback=logging_callback,
+                callback=collect,
             )
     pool.close()
     pool.join()
+    collect.finish()
