@@ -10,6 +10,14 @@ HBM (upscale_image arithmetic: head/trunk/tail kernels over all reference tiles,
 N > 1: one process per GPU, frames sharded across ranks as independent units, no data-path
 collective (RCCL is used only for the timing barrier / max-reduce); scaling = weak.
 
+`value` is the device-resident rate (route "K": frames and results in HBM when the timed region
+starts).  The PCIe-inclusive rate of the pipelined host route (route "E": page-locked host frames in,
+page-locked host results out, H2D / kernels / D2H of consecutive frames overlapped) is measured on
+EVERY rank in a second barrier-bracketed region and reported as config.host_route_fps_pcie_inclusive
+(sum of frames over ranks / max wall over ranks): it is what shows the host-side limits of multi-GPU
+scaling (feeder cores, pinned bandwidth, PCIe, NUMA), never `value`.  Every rank pins itself to the
+CPUs of its GPU's NUMA node before it allocates its page-locked buffers.
+
 One JSON line on rank 0 with the driver's keys plus
   roofline     : dominant kernel (trunk conv3x3 64->64) vs the dense fp16 MFMA peak, from HIP
                  events recorded on the engine's own stream inside the timed region
@@ -67,6 +75,11 @@ def timed_region(run_steps, sync, barrier, max_over_ranks):
     return max_over_ranks(time.perf_counter() - t0)
 
 
+def whole_job_rate(units_per_rank, world, max_elapsed):
+    """Aggregate over the job: every rank processed units_per_rank units, the slowest rank's wall time counts."""
+    return units_per_rank * world / max_elapsed
+
+
 def cpu_baseline(model_key, h, w, tile, min_seconds=10.0):
     """CPU oracle on a bounded sample of the same workload: crops of 1/16, 1/4, 1/1 of the frame
     are run in turn until one pass takes >= min_seconds (about 10-30 s of CPU work on the box's
@@ -94,19 +107,36 @@ def cpu_baseline(model_key, h, w, tile, min_seconds=10.0):
     }
 
 
-def pmc_traffic(args, nf):
-    """HBM bytes per trunk launch from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE collected in
-    separate runs of this command on the same build, FETCH_SIZE doubled per MI355X_MICROARCH.md's
-    gfx950 correction); bench.py cannot run the profiler on itself, so the committed summary of the
-    matching workload is reported, or null when there is none."""
+def pmc_traffic(args, nf, kernel):
+    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE
+    collected in separate runs of this command on the same build, FETCH_SIZE doubled per
+    MI355X_MICROARCH.md's gfx950 correction).  bench.py cannot run the profiler on itself, so the
+    committed summary of the matching workload AND kernel is replayed (-> (bytes, file name)), or
+    (None, None) when there is none."""
     import glob
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_trunk_pmc.json")))   # latest round/letter last
-    if args.workload != "2x_compact_1080p" or args.tile != 960 or nf != 64 or not paths:
-        return None
-    try:
-        return int(json.load(open(paths[-1]))["hbm_bytes_per_launch"])
-    except Exception:  # noqa: BLE001
-        return None
+    if args.workload != "2x_compact_1080p" or args.tile != 960 or nf != 64:
+        return None, None
+    for path in reversed(paths):
+        try:
+            d = json.load(open(path))
+            if d.get("kernel", "trunk_kernel").startswith(kernel):
+                return int(d["hbm_bytes_per_launch"]), "profiles/" + os.path.basename(path)
+        except Exception:  # noqa: BLE001
+            pass
+    return None, None
+
+
+def pin_to_gpu_numa_node(gpu):
+    """CPUs of the NUMA node the GPU hangs off (sysfs via the engine's PCI bus id); None if unknown."""
+    from upscale_video_amd import frame_pool
+    cpus = frame_pool.gpu_cpu_affinity(gpu)
+    if cpus:
+        try:
+            os.sched_setaffinity(0, cpus)
+        except OSError:
+            return None
+    return cpus
 
 
 def parity_probe(net, model_key, tile):
@@ -174,6 +204,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    numa_cpus = pin_to_gpu_numa_node(local_rank)     # before any page-locked allocation of this rank
     key, stem, h, w = WORKLOADS[args.workload]
     net = ncnn.Net()
     net.set_vulkan_device(local_rank)
@@ -223,16 +254,44 @@ def main():
     net.set_profiling(False)
 
     total_frames = args.steps * world
-    fps = total_frames / elapsed
+    fps = whole_job_rate(args.steps, world, elapsed)
+
+    # (E) pipelined host route, PCIe inclusive, on every rank at once: frames in page-locked host memory,
+    # submit/collect with 3 frames in flight (SURVEY.md 8d "host-to-host with stream overlap")
+    depth, n_host = 3, max(30, min(args.steps, 120))
+    host_in = frames[0].cpu().numpy()
+    pin_in = [ncnn.pinned_empty((h, w, 3)) for _ in range(depth)]
+    pin_out = [ncnn.pinned_empty((h * s, w * s, 3)) for _ in range(depth)]
+    for b in pin_in:
+        b[...] = host_in
+
+    def host_pipeline(n_frames):
+        inflight = []
+        for i in range(n_frames):
+            if len(inflight) == depth:
+                net.collect_u8(inflight.pop(0))
+            inflight.append(net.submit_u8(pin_in[i % depth], out=pin_out[i % depth], tile_size=args.tile, border=10))
+        while inflight:
+            net.collect_u8(inflight.pop(0))
+
+    host_fps = None
+    if pre is None:
+        host_pipeline(6)
+        host_elapsed = timed_region(lambda: host_pipeline(n_host), sync, barrier, max_over_ranks)
+        host_fps = whole_job_rate(n_host, world, host_elapsed)
 
     if rank == 0:
         nf, nconv = net.num_features, net.num_convs
-        trunk_flops_per_launch = 2 * 9 * nf * nf * h * w        # algorithmic: un-tiled frame
+        layers_per_launch = (nconv - 2) * args.steps / max(1, n_launch)       # 2 with trunk2_kernel (fused pairs)
+        fused = layers_per_launch > 1.5
+        kernel = "trunk2_kernel" if fused else ("trunk_kernel" if nf == 64 else "conv3x3_kernel")
+        trunk_flops_per_launch = layers_per_launch * 2 * 9 * nf * nf * h * w        # algorithmic: un-tiled frame
         avg_ms = trunk_ms / max(1, n_launch)
         achieved = trunk_flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         frame_flops = conv_flops_per_px(nf, nconv, s) * h * w
         if pre is not None:
             frame_flops += conv_flops_per_px(pre.num_features, pre.num_convs, 1) * h * w
+        traffic, traffic_source = pmc_traffic(args, nf, kernel)
         result = {
             "metric": "frames/sec 1080p->2x Compact (SRVGGNetCompact per-frame SR hot path)" if args.workload == "2x_compact_1080p"
                       else "frames/sec " + args.workload,
@@ -243,51 +302,38 @@ def main():
                 "workload": f"{w}x{h} synthetic u8 BGR frames, {stem}, upscale_image arithmetic "
                             f"({'reference 960-px tiles, 10-px border' if args.tile > 0 else 'whole frame'}), "
                             f"frames and results resident in HBM",
+                "route": "K (device-resident frames and results; host_route_* fields are PCIe inclusive and never `value`)",
                 "frames_per_rank": args.steps, "tile_size": args.tile, "parallelism": f"frame-sharded x{world}, no collective",
                 "frame_tflop": round(frame_flops / 1e12, 4),
                 "whole_path_tflops": round(frame_flops * fps / world / 1e12, 1),
                 "kernel_ms_per_frame": {"head": round(head_ms / args.steps, 4), "trunk": round(trunk_ms / args.steps, 4),
                                         "tail": round(tail_ms / args.steps, 4)},
+                "numa_cpus_rank0": (len(numa_cpus) if numa_cpus else None),
             },
             "roofline": {
-                "kernel": (f"trunk_kernel<{nf}>" if nf == 64 else f"conv3x3_kernel<{nf},0,1>") + f" (trunk {nf}->{nf} + PReLU)",
+                "kernel": (f"{kernel}<{nf}>" if nf == 64 else f"conv3x3_kernel<{nf},0,1>") +
+                          (f" ({int(round(layers_per_launch))} trunk layers {nf}->{nf} + PReLU per launch)"),
                 "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": pmc_traffic(args, nf),
+                "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "flops_per_launch": trunk_flops_per_launch, "avg_launch_ms": round(avg_ms, 4), "launches": n_launch,
+                "layers_per_launch": round(layers_per_launch, 2),
                 "peak_sustained_at_power_cap": MFMA_F16_SUSTAINED_AT_POWER_CAP_TFLOPS,
                 "frac_of_sustained": round(achieved / MFMA_F16_SUSTAINED_AT_POWER_CAP_TFLOPS, 4) if nf == 64 else None,
             },
         }
+        if host_fps is not None:
+            result["config"]["host_route_fps_pcie_inclusive"] = round(host_fps, 2)
+            result["config"]["host_route_frames_per_rank"] = n_host
         if world == 1:
-            # informational, never `value`: the host-pointer routes of the C ABI, PCIe inclusive.
-            #  (E) frames in page-locked host memory, pipelined submit/collect: H2D, kernels and D2H of
-            #      consecutive frames overlap (SURVEY.md 8d "host-to-host with stream overlap")
-            #  sync: pageable numpy in/out, one synchronous call per frame (what one reference worker does)
-            host_in = frames[0].cpu().numpy()
+            # informational: pageable numpy in/out, one synchronous call per frame (what one reference worker does)
             net.process_u8(host_in, tile_size=args.tile, border=10)
             t0 = time.perf_counter()
             for _ in range(5):
                 net.process_u8(host_in, tile_size=args.tile, border=10)
             result["config"]["host_route_sync_pageable_fps"] = round(5 / (time.perf_counter() - t0), 2)
-            depth, n_host = 3, 60
-            pin_in = [ncnn.pinned_empty((h, w, 3)) for _ in range(depth)]
-            pin_out = [ncnn.pinned_empty((h * s, w * s, 3)) for _ in range(depth)]
-            for b in pin_in:
-                b[...] = host_in
-            def host_pipeline(n_frames):
-                inflight = []
-                for i in range(n_frames):
-                    if len(inflight) == depth:
-                        net.collect_u8(inflight.pop(0))
-                    inflight.append(net.submit_u8(pin_in[i % depth], out=pin_out[i % depth], tile_size=args.tile, border=10))
-                while inflight:
-                    net.collect_u8(inflight.pop(0))
-            host_pipeline(6)
-            t0 = time.perf_counter()
-            host_pipeline(n_host)
-            result["config"]["host_route_fps_pcie_inclusive"] = round(n_host / (time.perf_counter() - t0), 2)
-            ref_out = net.process_u8(host_in, tile_size=args.tile, border=10)
-            assert np.array_equal(pin_out[(n_host - 1) % depth], ref_out), "pipelined host route differs from the synchronous one"
+            if pre is None:
+                ref_out = net.process_u8(host_in, tile_size=args.tile, border=10)
+                assert np.array_equal(pin_out[(n_host - 1) % depth], ref_out), "pipelined host route differs from the synchronous one"
             result["parity"] = parity_probe(net, key, args.tile) if pre is None else chain_parity_probe(pre, net)
             if not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(key, h, w, args.tile)

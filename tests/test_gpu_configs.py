@@ -1,0 +1,160 @@
+"""GPU tests (-m gpu) of the BASELINE.json configurations that the small-frame parity tests do not reach:
+config 5's frame (3840x2160, 2x Compact, 12 reference tiles), the device limits of the tile schedule, the
+test_gpus.py harness, and an opportunistic comparison with the real ncnn / cv2 when
+the box happens to have them (it normally does not: the reference pins neither, README.md:29)."""
+import logging
+import os
+
+import numpy as np
+import pytest
+
+try:
+    import torch  # noqa: F401  (its HIP runtime first, see test_gpu_parity.py)
+except Exception:  # noqa: BLE001
+    torch = None
+
+from conftest import ROOT, load_net, psnr_u8
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def net2x(uva):
+    assert uva.get_gpu_count() > 0
+    return load_net(uva, "2x")
+
+
+def test_config5_frame_2160p_reference_tiling(net2x, oracle_models, oracle):
+    """3840x2160 in, 2x Compact, 960/10 tiling = 12 planes of up to 980x980 (tile grid
+    upscale_processing.py:499-516):
+      (a) away from the seams the tiled result equals the whole-frame result, which is checked against the
+          oracle by locality windows (18-px receptive radius);
+      (b) ON the seams the fused route equals the reference-shaped float route (process_tile: cut core +
+          border, extract, *255, paste core) run on the two tiles either side of a seam;
+      (c) the tiled and the whole-frame results differ only within the receptive radius of a seam."""
+    from upscale_video_amd import upscale_processing as up
+    net, om = net2x, oracle_models["2x"]
+    h, w, s, rad = 2160, 3840, 2, net2x.num_convs
+    img = oracle.synthetic_frame(h, w, seed=5)
+    tiled = net.process_u8(img, tile_size=960, border=10)
+    assert tiled.shape == (h * s, w * s, 3)
+    assert np.array_equal(tiled, net.process_u8(img, tile_size=960, border=10))
+    whole = net.process_u8(img, tile_size=0)
+    win = 24
+    for (y0, x0) in [(0, 0), (h - win, w - win), (400, 1400), (1500, 2500), (2000, 3700), (1000, 100)]:
+        cy0, cx0 = max(0, y0 - rad), max(0, x0 - rad)
+        cy1, cx1 = min(h, y0 + win + rad), min(w, x0 + win + rad)
+        want = om.apply_model(np.ascontiguousarray(img[cy0:cy1, cx0:cx1]))[
+            (y0 - cy0) * s:(y0 - cy0 + win) * s, (x0 - cx0) * s:(x0 - cx0 + win) * s]
+        for name, res in (("whole", whole), ("tiled", tiled)):
+            got = res[y0 * s:(y0 + win) * s, x0 * s:(x0 + win) * s]
+            d = np.abs(got.astype(int) - want.astype(int))
+            assert d.max() <= 2 and psnr_u8(got, want) >= 50, (name, (y0, x0), d.max(), psnr_u8(got, want))
+    # (c)
+    d = np.abs(tiled.astype(np.int16) - whole.astype(np.int16))
+    assert d.max() <= 2
+    ys, xs = np.nonzero(d.max(axis=2))
+    near = np.zeros(len(ys), bool)
+    for k in (1, 2, 3):
+        near |= np.abs(xs - 960 * k * s) <= (rad + 2) * s
+    for k in (1, 2):
+        near |= np.abs(ys - 960 * k * s) <= (rad + 2) * s
+    assert near.all()
+    # (b) tiles (1, 1) and (1, 2): interior tiles with a border on every side, sharing the x = 1920 seam
+    up.net = net
+    for (ty, tx) in [(1, 1), (1, 2)]:
+        canvas = np.zeros((h * s, w * s, 3))
+        items = []
+        assert up.process_tile(img, 960, s, ty, tx, h, w, canvas, items) == 0, items
+        (y0, y1, x0, x1), _ = up.tile_window(960, ty, tx, h, w)
+        floaty = np.clip(np.rint(canvas[y0 * s:y1 * s, x0 * s:x1 * s]), 0, 255).astype(np.uint8)
+        got = tiled[y0 * s:y1 * s, x0 * s:x1 * s]
+        dd = np.abs(got.astype(np.int16) - floaty.astype(np.int16))
+        # the float route rounds x/255 to fp16 at the head, the u8 route feeds exact integers
+        assert dd.max() <= 1 and (dd > 0).mean() <= 5e-2, ((ty, tx), int(dd.max()), float((dd > 0).mean()))
+
+
+def test_schedule_limits_fail_with_messages(net2x, uva, oracle):
+    """The encodings of the tile schedules have limits (uva_api.hip: 64 planes per frame, 255 tile columns
+    and 4095 4-row tile rows per plane): beyond them the call fails with a message, it does not compute."""
+    from upscale_video_amd import _lib
+    img = oracle.synthetic_frame(90, 90)
+    with pytest.raises(_lib.UvaError, match="more than 64 tiles"):
+        net2x.process_u8(img, tile_size=10, border=2)                 # 9 x 9 = 81 planes
+    ok = net2x.process_u8(img, tile_size=12, border=2)                # 8 x 8 = 64 planes: the most there can be
+    assert ok.shape == (180, 180, 3)
+    wide = np.zeros((2, 8200, 3), np.uint8)                           # 257 tile columns in one plane
+    with pytest.raises(_lib.UvaError, match="too large for the tile schedule"):
+        net2x.process_u8(wide, tile_size=0)
+    assert net2x.process_u8(np.zeros((2, 8100, 3), np.uint8), tile_size=0).shape == (4, 16200, 3)
+    tall = np.zeros((16400, 2, 3), np.uint8)                          # 4100 4-row tile rows in one plane
+    with pytest.raises(_lib.UvaError, match="too large for the tile schedule"):
+        net2x.process_u8(tall, tile_size=0)
+    # the net is still usable afterwards
+    assert np.array_equal(net2x.process_u8(img, tile_size=12, border=2), ok)
+
+
+def test_harness_test_gpus_two_workers(caplog, tmp_path, monkeypatch):
+    """test_gpus.py (counterpart of the reference's only benchmark harness, test_gpus.py:15-127) run the
+    way BASELINE config 5 names it, here with `-g 0,0 -s 2 -r 4` on one GPU: the device listing, one
+    "Testing GPU" and one "seconds to upscale" line per run, the total, and frames/s.  The transcript is
+    kept under gpurun_out/ when that directory exists (copied to profiles/ by hand)."""
+    import test_gpus
+    monkeypatch.chdir(tmp_path)
+    with caplog.at_level(logging.INFO):
+        test_gpus.run_tests("0,0", 2, 4)
+    text = "\n".join(r.getMessage() for r in caplog.records)
+    assert "GPU count: " in text and "Default GPU: 0" in text and "gfx950" in text
+    assert text.count("Testing GPU: 0") == 4
+    assert text.count("seconds to upscale sample.png") == 4
+    assert text.count("Upscaled 1/1") == 4
+    assert "seconds total to run tests." in text and "frames/s" in text
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "test_gpus_harness.txt"), "w") as f:
+            f.write(text + "\n")
+
+
+def test_opportunistic_pin_against_real_ncnn_and_cv2(uva, oracle, oracle_models):
+    """The oracle is pinned only by an independent restatement: the reference's
+    arithmetic lives in the un-pinned ncnn_vulkan / opencv-python wheels, which this image does not have.
+    If a box ever has them, compare: ncnn on the CPU (use_vulkan_compute = False) against the oracle's f32
+    output on a golden input, and cv2.imwrite's float -> u8 conversion against the oracle's."""
+    found = {}
+    for mod in ("ncnn", "ncnn_vulkan", "cv2"):
+        try:
+            found[mod] = __import__(mod)
+        except Exception as e:  # noqa: BLE001
+            found[mod] = None
+            print("import %s: %s: %s" % (mod, type(e).__name__, e))
+    real = found["ncnn"] or (getattr(found["ncnn_vulkan"], "ncnn", None) if found["ncnn_vulkan"] else None)
+    if real is None and found["cv2"] is None:
+        pytest.skip("neither ncnn / ncnn_vulkan nor cv2 is importable on this box: the oracle stays pinned by "
+                    "oracle/independent_check.py only (parity unpinned, DESIGN.md section 2)")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "independent_torch.npz"))
+    if found["cv2"] is not None:
+        cv2 = found["cv2"]
+        f = (np.arange(0, 4096, dtype=np.float64).reshape(64, 64, 1) / 8.0 - 20.0).repeat(3, axis=2)   # .5 ties included
+        path = "/tmp/uva_cv2_roundtrip.png"
+        assert cv2.imwrite(path, f)
+        from upscale_video_amd import _imageio
+        assert np.array_equal(cv2.imread(path), _imageio.to_u8(f))
+    if real is not None:
+        from conftest import model_paths
+        for key in ("2x", "1x"):
+            net = real.Net()
+            net.opt.use_vulkan_compute = False
+            p, b = model_paths(key)
+            net.load_param(p)
+            net.load_model(b)
+            tag = [k[:-3] for k in g.files if k.startswith(key) and k.endswith("_in")][0]
+            img = g[tag + "_in"]
+            mat = real.Mat.from_pixels(img, real.Mat.PixelType.PIXEL_BGR, img.shape[1], img.shape[0])
+            mat.substract_mean_normalize([], [1 / 255.0] * 3)
+            ex = net.create_extractor()
+            ex.input("input", mat)
+            ret, out = ex.extract("output")
+            assert ret == 0
+            got = np.array(out)
+            want = oracle_models[key].forward(oracle.from_pixels_normalize(img))
+            assert np.abs(got - want).max() <= 2e-3, (key, float(np.abs(got - want).max()))

@@ -36,6 +36,10 @@ def _worker(rank, world, port, n_frames, q):
         return float(t.item())
 
     elapsed = bench.timed_region(run, lambda: None, dist.barrier, max_over_ranks)
+    # second region, as bench.py runs the PCIe-inclusive host route on every rank: the same protocol, its
+    # own barriers, the fast rank of the first region is the slow one here
+    host = bench.timed_region(lambda: time.sleep(0.3 if rank == 0 else 0.05), lambda: None, dist.barrier, max_over_ranks)
+    assert host >= 0.3 and abs(bench.whole_job_rate(10, world, host) - 10 * world / host) < 1e-9
     checksum = float(sum(int(v.astype(np.int64).sum()) for v in outs.values()))
     t = torch.tensor([checksum, float(len(mine))], dtype=torch.float64)
     dist.all_reduce(t)               # test bookkeeping only, not part of the data path

@@ -90,6 +90,12 @@ def test_stream_equals_per_frame_calls(tmp_path):
     assert rawvideo.main(["-i", str(src), "-o", str(dst), "-W", str(w), "-H", str(h), "-s", "2", "-m", "a", "--tile", "32"]) == 0
     got = np.frombuffer(dst.read_bytes(), np.uint8).reshape(n, 2 * h, 2 * w, 3)
     pre, net = load_net(ncnn, "1x"), load_net(ncnn, "2x")
+    o1, o2 = uvoracle.load_model("1x"), uvoracle.load_model("2x")
     for i, f in enumerate(frames):
-        want = net.process_u8(pre.process_u8(f), tile_size=32, border=10)
-        assert np.array_equal(got[i], want), i
+        # against the CPU oracle's chain (apply_model -> u8 -> upscale_image with the same 32/10 tiling) ...
+        want = o2.upscale_image(o1.apply_model(f), tile_size=32, border=10)
+        d = np.abs(got[i].astype(int) - want.astype(int))
+        mse = float((d.astype(np.float64) ** 2).mean())
+        assert d.max() <= 3 and (mse == 0 or 10 * np.log10(255.0 ** 2 / mse) >= 48), (i, int(d.max()))
+        # ... and, bit for bit, against the synchronous per-frame calls of the same engine
+        assert np.array_equal(got[i], net.process_u8(pre.process_u8(f), tile_size=32, border=10)), i

@@ -4,7 +4,8 @@ are in KB; gfx950 counts 64 B per 128-B request on wide coalesced reads -> FETCH
 import csv, glob, json, os, statistics, sys
 
 out_dir, tag = sys.argv[1], sys.argv[2]
-KERNEL = "trunk_kernel<64, 0>"
+KERNEL = sys.argv[3] if len(sys.argv) > 3 else "trunk2_kernel<64>"
+LAYERS = 2 if KERNEL.startswith("trunk2") else 1
 
 
 def per_launch(sub):
@@ -28,10 +29,12 @@ fetch = per_launch("pmc_fetch").get("FETCH_SIZE")
 write = per_launch("pmc_write").get("WRITE_SIZE")
 sq = per_launch("pmc_sq")
 h, w, nf = 1080, 1920, 64
-algo = 2 * h * w * nf * 2          # read + write one fp16 NHWC activation image (un-tiled frame)
+algo = 2 * h * w * nf * 2          # read + write one fp16 NHWC activation image (un-tiled frame): a fused pair
+                                   # of layers moves as many compulsory bytes as a single layer
 res = {
     "build": tag, "kernel": "uva::" + KERNEL,
     "workload": "1920x1080 2x Compact, reference tiling 960/10, one launch (median of the full-size launches)",
+    "trunk_layers_per_launch": LAYERS,
     "FETCH_SIZE_KB_raw": fetch, "WRITE_SIZE_KB_raw": write,
     "correction": "FETCH_SIZE doubled (gfx950 rocprofv3 counts 64 B per 128-B request for wide coalesced reads, "
                   "MI355X_MICROARCH.md section HBM); WRITE_SIZE uncalibrated, taken as is",

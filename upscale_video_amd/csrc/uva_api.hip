@@ -53,6 +53,7 @@ struct Workspace {
     // (zeroed, never written) on both ends keeps trunk2_kernel's halo reads of rows -2 / h+4 and columns
     // -2 / pitch+1 -- which only ever feed pixels it masks to zero -- inside the allocation.
     size_t guard_bytes = 0;
+    size_t alloc_bytes = 0;      // device bytes of the two activation buffers (the cache's LRU budget)
     char* act_base[2] = {nullptr, nullptr};
     _Float16* act[2] = {nullptr, nullptr};
     // trunk2_kernel (fused layer pair): per-workgroup step lists
@@ -102,6 +103,7 @@ struct uva_net {
     int device = 0;
     Graph g;
     bool dev_ready = false;
+    bool dev_partial = false;     // some device state exists (ensure_device started); free_device() must run
     int ncu = 256;
     hipStream_t stream = nullptr;
     std::vector<DeviceLayer> layers;
@@ -110,6 +112,7 @@ struct uva_net {
     float *d_fin = nullptr, *d_fout = nullptr;
     size_t d_fin_cap = 0, d_fout_cap = 0;
     _Float16* d_sink = nullptr;   // where out-of-image lanes of the trunk kernel store to
+    bool attr_set[16] = {false};  // hipFuncAttributeMaxDynamicSharedMemorySize done for kernel slot k on this net's device
     int last_act_buf = 0;         // which ping-pong buffer the last run_graph() left its last trunk activation in
     bool fuse_pairs = true;       // 64-feature nets: trunk layers run two per launch (trunk2_kernel); UVA_TRUNK_FUSION=0 turns it off
     LastCall last;
@@ -139,7 +142,9 @@ struct uva_net {
 
     void free_device()
     {
-        if (!dev_ready) return;
+        if (!dev_ready && !dev_partial) return;
+        dev_partial = false;
+        std::memset(attr_set, 0, sizeof attr_set);
         (void)hipSetDevice(device);
         if (stream) (void)hipStreamSynchronize(stream);
         for (auto& l : layers) {
@@ -198,14 +203,12 @@ int upload(T** dst, const void* src, size_t bytes, hipStream_t st)
 template <int NF, int MODE, int R>
 int launch_conv_t(uva_net* n, const ConvArgs& a)
 {
-    static bool attr_done[16] = {false};   // per device ordinal
     const size_t lds = conv_lds_bytes<NF>(MODE == 0 ? 0 : R);
     auto kfn = conv3x3_kernel<NF, MODE, R>;
-    if (n->device < 16 && !attr_done[n->device]) {
+    // a net runs at most one trunk (MODE 0) and the u8 / f32 tails (MODE 1 / 2) of its own graph: slots 0-2
+    if (!n->attr_set[MODE]) {
         HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done[n->device] = true;
-    } else if (n->device >= 16) {
-        HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        n->attr_set[MODE] = true;
     }
     // 24-feature nets: 160 VGPRs and ~52 KB of LDS per workgroup leave room for two persistent
     // workgroups per CU, whose k-loops and epilogues then overlap (the 64-feature tails fill the
@@ -222,12 +225,12 @@ int launch_conv_t(uva_net* n, const ConvArgs& a)
 template <int ABL>
 int launch_trunk64_t(uva_net* n, const ConvArgs& a)
 {
-    static bool attr_done[16] = {false};
     const size_t lds = trunk_lds_bytes<64>();
     auto kfn = trunk_kernel<64, ABL>;
-    if (n->device >= 16 || !attr_done[n->device]) {
+    constexpr int SLOT = 3 + (ABL == 0 ? 0 : ABL == 1 ? 1 : ABL == 2 ? 2 : 3);   // slots 3-6
+    if (!n->attr_set[SLOT]) {
         HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (n->device < 16) attr_done[n->device] = true;
+        n->attr_set[SLOT] = true;
     }
     const int grid = std::max(8, (n->ncu / 8) * 8);
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), lds, n->stream, a);
@@ -273,13 +276,12 @@ int launch_conv(uva_net* n, int mode, const ConvArgs& a)
 int launch_tail_u8(uva_net* n, const Workspace* ws, ConvArgs ca)
 {
     if (n->g.nf == 64 && (n->g.scale == 2 || n->g.scale == 4) && n->layers.back().wpk16) {
-        static bool attr_done[2][16] = {{false}, {false}};
         const bool x4 = n->g.scale == 4;
         const size_t lds = x4 ? tail4_lds_bytes<64>() : tail_lds_bytes<64>();
         void (*kfn)(ConvArgs) = x4 ? tail4_kernel<64> : tail_kernel<64, 2>;
-        if (n->device >= 16 || !attr_done[x4][n->device]) {
+        if (!n->attr_set[7]) {
             HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            if (n->device < 16) attr_done[x4][n->device] = true;
+            n->attr_set[7] = true;
         }
         const int grid = std::max(8, (n->ncu / 8) * 8);
         const int per_launch = 8 * (2 * (grid / 8)) * ((TAIL_SCHED_MAX - TRUNK_LOOKAHEAD) / 2 - 1);
@@ -408,12 +410,11 @@ int build_trunk2_schedule(const std::vector<PlaneDesc>& planes, int grid, size_t
 
 int launch_trunk2(uva_net* n, const Workspace* ws, const Trunk2Args& a)
 {
-    static bool attr_done[16] = {false};
     const size_t lds = trunk2_lds_bytes<64>();
     auto kfn = trunk2_kernel<64>;
-    if (n->device >= 16 || !attr_done[n->device]) {
+    if (!n->attr_set[8]) {
         HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (n->device < 16) attr_done[n->device] = true;
+        n->attr_set[8] = true;
     }
     hipLaunchKernelGGL(kfn, dim3(ws->grid2), dim3(512), lds, n->stream, a);
     HIP_TRY(hipGetLastError());
@@ -452,9 +453,15 @@ int ensure_device(uva_net* n)
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(std::string("libuva is built for gfx950 (MI355X) only; device is ") + prop.gcnArchName);
     n->ncu = prop.multiProcessorCount;
+    // dev_ready is set only once every upload below has succeeded; any failure on the way releases what
+    // was allocated (free_device works on partial state), so a later call starts from scratch
+    n->dev_partial = true;
+    struct Undo {
+        uva_net* n;
+        ~Undo() { if (!n->dev_ready) n->free_device(); }
+    } undo{n};
     HIP_TRY(hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking));
     if (const char* e = std::getenv("UVA_TRUNK_FUSION")) n->fuse_pairs = std::atoi(e) != 0;
-    n->dev_ready = true;
     HIP_TRY(hipMalloc((void**)&n->d_sink, 64 * 128 + 256));
     // weights: head, trunk..., tail
     const Graph& g = n->g;
@@ -481,6 +488,7 @@ int ensure_device(uva_net* n)
         }
         HIP_TRY(hipStreamSynchronize(n->stream));   // pk / b / s go out of scope
     }
+    n->dev_ready = true;
     return 0;
 }
 
@@ -555,25 +563,13 @@ int get_workspace(uva_net* n, int h, int w, int tile_size, int border, Workspace
     ws.ntiles = tiles;
     ws.ntiles4 = tiles4;
     ws.act_pixels = pix;
-    if (n->wss.size() >= 6) {   // LRU: keep a handful of geometries resident
-        HIP_TRY(hipStreamSynchronize(n->stream));
-        if (n->last.ws == &n->wss.back()) n->last = LastCall();
-        n->wss.back().release();
-        n->wss.pop_back();
-    }
+    // everything that can be refused is checked BEFORE anything is allocated
+    std::vector<uint4> sched4;
+    std::vector<Trunk2Step> steps2;
+    std::vector<int> nsteps2;
     int max_pitch = 0;
     for (auto& p : ws.planes) max_pitch = std::max(max_pitch, p.pitch);
     ws.guard_bytes = (size_t)8 * max_pitch * n->g.nf * 2;
-    const size_t bytes = pix * (size_t)n->g.nf * 2 + 2 * ws.guard_bytes;
-    for (int i = 0; i < 2; ++i) {
-        HIP_TRY(hipMalloc((void**)&ws.act_base[i], bytes));
-        HIP_TRY(hipMemsetAsync(ws.act_base[i], 0, bytes, n->stream));   // the zero border lives here forever
-        ws.act[i] = (_Float16*)(ws.act_base[i] + ws.guard_bytes);
-    }
-    HIP_TRY(hipMalloc((void**)&ws.d_planes, ws.planes.size() * sizeof(PlaneDesc)));
-    HIP_TRY(hipMemcpyAsync(ws.d_planes, ws.planes.data(), ws.planes.size() * sizeof(PlaneDesc),
-                           hipMemcpyHostToDevice, n->stream));
-    std::vector<uint4> sched4;
     if (n->g.nf == 64) {
         using G4 = Geo<64, 4>;
         sched4.reserve((size_t)tiles4);
@@ -590,25 +586,55 @@ int get_workspace(uva_net* n, int h, int w, int tile_size, int border, Workspace
                                                 (unsigned)(vx | (vy << 6) | (tx << 9) | (ty << 17))));
                 }
         }
-        HIP_TRY(hipMalloc((void**)&ws.d_sched4, sched4.size() * sizeof(uint4)));
-        HIP_TRY(hipMemcpyAsync(ws.d_sched4, sched4.data(), sched4.size() * sizeof(uint4), hipMemcpyHostToDevice, n->stream));
-    }
-    std::vector<Trunk2Step> steps2;
-    std::vector<int> nsteps2;
-    if (n->g.nf == 64) {
         ws.grid2 = std::max(8, (n->ncu / 8) * 8);
         if (build_trunk2_schedule(ws.planes, ws.grid2, ws.guard_bytes, steps2, nsteps2, &ws.max_steps2)) return 1;
+    }
+    const size_t bytes = pix * (size_t)n->g.nf * 2 + 2 * ws.guard_bytes;
+    // LRU over the cached geometries, by bytes (the fused route keeps one workspace per frame size, the
+    // float / Extractor route one per distinct tile shape -- 9 for a 4000x2200 frame): plenty fit 288 GB
+    constexpr size_t CACHE_BYTES = (size_t)96 << 30;
+    constexpr size_t CACHE_ENTRIES = 32;
+    auto cached_bytes = [&]() {
+        size_t t = 0;
+        for (auto& w2 : n->wss) t += w2.alloc_bytes;
+        return t;
+    };
+    while (!n->wss.empty() && (n->wss.size() >= CACHE_ENTRIES || cached_bytes() + 2 * bytes > CACHE_BYTES)) {
+        HIP_TRY(hipStreamSynchronize(n->stream));
+        if (n->last.ws == &n->wss.back()) n->last = LastCall();
+        n->wss.back().release();
+        n->wss.pop_back();
+    }
+    // from here on a failure releases what this workspace already holds
+    struct Guard {
+        Workspace* w;
+        ~Guard() { if (w) w->release(); }
+    } guard{&ws};
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipMalloc((void**)&ws.act_base[i], bytes));
+        HIP_TRY(hipMemsetAsync(ws.act_base[i], 0, bytes, n->stream));   // the zero border lives here forever
+        ws.act[i] = (_Float16*)(ws.act_base[i] + ws.guard_bytes);
+    }
+    ws.alloc_bytes = 2 * bytes;
+    HIP_TRY(hipMalloc((void**)&ws.d_planes, ws.planes.size() * sizeof(PlaneDesc)));
+    HIP_TRY(hipMemcpyAsync(ws.d_planes, ws.planes.data(), ws.planes.size() * sizeof(PlaneDesc),
+                           hipMemcpyHostToDevice, n->stream));
+    if (n->g.nf == 64) {
+        HIP_TRY(hipMalloc((void**)&ws.d_sched4, sched4.size() * sizeof(uint4)));
+        HIP_TRY(hipMemcpyAsync(ws.d_sched4, sched4.data(), sched4.size() * sizeof(uint4), hipMemcpyHostToDevice, n->stream));
         HIP_TRY(hipMalloc((void**)&ws.d_steps2, steps2.size() * sizeof(Trunk2Step)));
         HIP_TRY(hipMalloc((void**)&ws.d_nsteps2, nsteps2.size() * sizeof(int)));
         HIP_TRY(hipMemcpyAsync(ws.d_steps2, steps2.data(), steps2.size() * sizeof(Trunk2Step), hipMemcpyHostToDevice, n->stream));
         HIP_TRY(hipMemcpyAsync(ws.d_nsteps2, nsteps2.data(), nsteps2.size() * sizeof(int), hipMemcpyHostToDevice, n->stream));
     }
     HIP_TRY(hipStreamSynchronize(n->stream));
+    guard.w = nullptr;
     n->wss.push_front(ws);
     *out = &n->wss.front();
     return 0;
 }
 
+// -> nullptr (with the error recorded) if the runtime cannot create another event
 hipEvent_t take_event(uva_net* n)
 {
     if (!n->ev_free.empty()) {
@@ -617,13 +643,24 @@ hipEvent_t take_event(uva_net* n)
         return e;
     }
     hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
+    const hipError_t rc = hipEventCreate(&e);
+    if (rc != hipSuccess) {
+        fail(std::string("hipEventCreate: ") + hipGetErrorString(rc));
+        return nullptr;
+    }
     return e;
 }
 
+// Frames whose last event has completed are added to the statistics and their events recycled; frames still
+// in flight (pipelined submits) stay pending for the next call.
 void resolve_events(uva_net* n)
 {
+    std::vector<uva_net::EvSet> keep;
     for (auto& s : n->ev_pending) {
+        if (hipEventQuery(s.e[3]) == hipErrorNotReady) {
+            keep.push_back(s);
+            continue;
+        }
         float ms[3] = {0, 0, 0};
         bool ok = true;
         for (int k = 0; k < 3; ++k) ok &= hipEventElapsedTime(&ms[k], s.e[k], s.e[k + 1]) == hipSuccess;
@@ -634,7 +671,7 @@ void resolve_events(uva_net* n)
         }
         for (auto e : s.e) n->ev_free.push_back(e);
     }
-    n->ev_pending.clear();
+    n->ev_pending.swap(keep);
 }
 
 // The whole graph for one frame.  stop_after >= 0: run only convolutions 0..stop_after (debug).
@@ -645,9 +682,17 @@ int run_graph(uva_net* n, Workspace* ws, bool f32, const void* src, size_t src_s
     const int nconv = (int)g.convs.size();
     const bool prof = n->prof && stop_after < 0;
     uva_net::EvSet ev;
-    ev.ntrunk = nconv - 2;
+    ev.ntrunk = 0;   // trunk launches of this frame (a fused pair is one launch)
     if (prof) {
-        for (auto& e : ev.e) e = take_event(n);
+        for (auto& e : ev.e) e = nullptr;
+        for (auto& e : ev.e) {
+            e = take_event(n);
+            if (!e) {
+                for (auto q : ev.e)
+                    if (q) n->ev_free.push_back(q);
+                return 1;
+            }
+        }
         HIP_TRY(hipEventRecord(ev.e[0], n->stream));
     }
     HeadArgs ha;
@@ -694,6 +739,7 @@ int run_graph(uva_net* n, Workspace* ws, bool f32, const void* src, size_t src_s
             ta.max_steps = ws->max_steps2;
             ta.sink = n->d_sink;
             if (launch_trunk2(n, ws, ta)) return 1;
+            ++ev.ntrunk;
             ++i;
             cur ^= 1;
             n->last_act_buf = cur;
@@ -706,6 +752,7 @@ int run_graph(uva_net* n, Workspace* ws, bool f32, const void* src, size_t src_s
         ca.slope = n->layers[i].slope;
         ca.reverse = i & 1;   // layer 1 walks backwards over what the head wrote last, layer 2 forwards, ...
         if (launch_trunk(n, ws, ca)) return 1;
+        ++ev.ntrunk;
         cur ^= 1;
         n->last_act_buf = cur;
     }
@@ -874,6 +921,7 @@ int uva_net_wait_for(uva_net* n, uva_net* producer)
     if (ensure_device(n)) return 1;
     if (producer->device != n->device) return fail("uva_net_wait_for: nets are on different devices");
     hipEvent_t e = take_event(n);
+    if (!e) return 1;
     HIP_TRY(hipEventRecord(e, producer->stream));
     HIP_TRY(hipStreamWaitEvent(n->stream, e, 0));
     n->ev_free.push_back(e);   // safe to recycle: the wait has captured the recorded state

@@ -1207,16 +1207,24 @@ __global__ __launch_bounds__(512, 2) void trunk2_kernel(Trunk2Args a)
         prm_b = (grp ? a.bias[1] : a.bias[0])[lane];
         prm_s = (grp ? a.slope[1] : a.slope[0])[lane];
     }
-    int dma_pc[CPW];
+    // LDS-DMA source position of this lane in piece i: (halo row << 13) | byte offset inside the row, two
+    // pieces per register (the k-loop needs every register it can get)
+    unsigned dma_pc2[CPW / 2];
 #pragma unroll
-    for (int i = 0; i < CPW; ++i) dma_pc[i] = trunk_piece_const<NF>(i, wave, lane);
+    for (int i = 0; i < CPW / 2; ++i) {
+        const int lo = trunk_piece_const<NF>(2 * i, wave, lane), hi = trunk_piece_const<NF>(2 * i + 1, wave, lane);
+        dma_pc2[i] = (unsigned)(((lo >> 16) << 13) | (lo & 0x1fff)) | ((unsigned)(((hi >> 16) << 13) | (hi & 0x1fff)) << 16);
+    }
 
     auto issue_tile = [&](const uint4 e, int slot) __attribute__((always_inline)) {
         const unsigned lo = __builtin_amdgcn_readfirstlane(e.x), hi = __builtin_amdgcn_readfirstlane(e.y) & 0xffu;
         const char* base = a.in_act + (((unsigned long long)hi << 32) | lo);
         const int pitch = __builtin_amdgcn_readfirstlane(e.z);
 #pragma unroll
-        for (int i = 0; i < CPW; ++i) trunk_issue_piece<NF>(base, pitch, lds0 + slot * SLOTB, i, wave, dma_pc[i]);
+        for (int i = 0; i < CPW; ++i) {
+            const unsigned pc = (dma_pc2[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+            trunk_issue_piece<NF>(base, pitch, lds0 + slot * SLOTB, i, wave, (int)(((pc >> 13) << 16) | (pc & 0x1fffu)));
+        }
     };
     if (grp == 0) {
         // prologue: the first three input tiles (entries behind the last step are valid dummies)
@@ -1235,7 +1243,6 @@ __global__ __launch_bounds__(512, 2) void trunk2_kernel(Trunk2Args a)
     const float* const bias_lds = prm_all + grp * (PARAM_LDS / 4);
     const float* const prm_lds = bias_lds + 64;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    char* const sink = (char*)a.sink + lane * G::PIXB;
 
     // entries this group needs in its next epilogue phase, fetched one iteration ahead through the
     // scalar cache: A: masks of step it, input tile of step it + 3;  B: output tile of step it - 2
@@ -1303,8 +1310,9 @@ __global__ __launch_bounds__(512, 2) void trunk2_kernel(Trunk2Args a)
         // ---- epilogue phase ---------------------------------------------------------------------------
         const int lane_o = opaque(lane);
         const int cg = lane_o >> 4, p = lane_o & 15;
-        f32x4 b4[2], s4[2], i4[2];
-        if (work) {
+        // per-channel parameters of this lane's 8 channels: loaded inside the branch that uses them (defined
+        // under one `if (work)` and used under another they would be loop-carried and held across the k-loop)
+        auto load_params = [&](f32x4 (&b4)[2], f32x4 (&s4)[2], f32x4 (&i4)[2]) __attribute__((always_inline)) {
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const int cl = 32 * mh + 16 * m + 4 * cg;
@@ -1312,13 +1320,15 @@ __global__ __launch_bounds__(512, 2) void trunk2_kernel(Trunk2Args a)
                 s4[m] = *(const f32x4*)(prm_lds + cl);
                 i4[m] = *(const f32x4*)(prm_lds + 64 + cl);
             }
-        }
+        };
         if (grp == 0) {
             // input tile of step it + 3 -> the slot this k-loop has just released; the pieces issued one and
             // two epilogues ago (steps it + 2, it + 1) are older, so "at most two tiles' pieces outstanding"
             // at the closing barrier proves step it + 1's tile
             issue_tile(e_dma, blk);
             if (work) {
+                f32x4 b4[2], s4[2], i4[2];
+                load_params(b4, s4, i4);
                 const unsigned ey = __builtin_amdgcn_readfirstlane(e_own.y);
                 const int rmask = (ey >> 8) & 15, c_lo = (ey >> 12) & 63, c_hi = (ey >> 18) & 63;
                 char* const wbase = ring + blk * BLOCKB + ((2 * rp) * PW + p) * G::LPIXB + (32 * mh + 4 * cg) * 2;
@@ -1348,6 +1358,8 @@ __global__ __launch_bounds__(512, 2) void trunk2_kernel(Trunk2Args a)
             if (wave == 0) dma_barrier<2 * CPW>(); else dma_barrier<2 * (CPW - 1)>();
         } else {
             if (work) {
+                f32x4 b4[2], s4[2], i4[2];
+                load_params(b4, s4, i4);
                 const unsigned lo = __builtin_amdgcn_readfirstlane(e_own.x), ey = __builtin_amdgcn_readfirstlane(e_own.y);
                 const size_t off = ((unsigned long long)(ey & 0xffu) << 32) | lo;
                 const int pitch = __builtin_amdgcn_readfirstlane(e_own.z);
@@ -1375,7 +1387,7 @@ __global__ __launch_bounds__(512, 2) void trunk2_kernel(Trunk2Args a)
                         const auto y = __builtin_amdgcn_permlane16_swap(o[0][1], o[1][1], false, false);
                         const uint4 val = make_uint4(x[0], y[0], x[1], y[1]);
                         const bool ok = 2 * rp + n < vy && 16 * c + p < vx;
-                        char* dst = ok ? obase + ((size_t)n * pitch + (size_t)(16 * c) * G::PIXB) : sink;
+                        char* dst = ok ? obase + ((size_t)n * pitch + (size_t)(16 * c) * G::PIXB) : (char*)a.sink + lane_o * G::PIXB;
                         *(uint4*)dst = val;
                     }
             }

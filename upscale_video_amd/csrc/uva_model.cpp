@@ -122,8 +122,15 @@ bool parse_param(const std::string& path, Graph& g, std::string& err)
             c.name = r.name;
             c.cout = r.geti(0, 0);
             c.weight_data_size = r.geti(6, 0);
-            if (r.geti(1, 0) != 3 || r.geti(11, 3) != 3 || r.geti(4, 0) != 1 || r.geti(5, 0) != 1 ||
-                r.geti(2, 1) != 1 || r.geti(3, 1) != 1 || r.geti(9, 0) != 0 || r.geti(8, 0) != 0)
+            // ncnn convolution.cpp load_param: kernel_h (11), dilation_h (12), stride_h (13) default to the
+            // _w values (1, 2, 3); pad_right (15) and pad_top (14) to pad_left (4), pad_bottom (16) to pad_top;
+            // pad_value (18) to 0.  Anything but a symmetric 3x3 / dilation 1 / stride 1 / zero pad 1 layer
+            // with a bias, no fused activation (9) and fp weights (8) is refused, not silently computed as one.
+            const int pad_l = r.geti(4, 0), pad_t = r.geti(14, pad_l);
+            if (r.geti(1, 0) != 3 || r.geti(11, 3) != 3 || pad_l != 1 || r.geti(5, 0) != 1 ||
+                r.geti(2, 1) != 1 || r.geti(3, 1) != 1 || r.geti(9, 0) != 0 || r.geti(8, 0) != 0 ||
+                r.geti(12, r.geti(2, 1)) != 1 || r.geti(13, r.geti(3, 1)) != 1 || pad_t != 1 ||
+                r.geti(15, pad_l) != 1 || r.geti(16, pad_t) != 1 || r.getf(18, 0.0) != 0.0 || r.geti(7, 1) != 1)
                 return fail(err, "load_param: " + r.name + " is not a plain 3x3/pad1/stride1/bias convolution");
             if (c.cout <= 0 || c.weight_data_size <= 0 || c.weight_data_size % (c.cout * 9))
                 return fail(err, "load_param: bad sizes in " + r.name);
