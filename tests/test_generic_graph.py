@@ -1,0 +1,176 @@
+"""Generic ncnn graphs (`-m r`, models/4x_Valar_v1.param): host loader on CPU, the HIP
+executor against the numpy restatement (oracle/generic_oracle.py) under -m gpu.  The Valar weights are a
+missing blob upstream, so every comparison here uses synthetic weights: functional coverage, no parity claim."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_net, model_paths, psnr_u8
+
+VALAR = os.path.join(ROOT, "models", "4x_Valar_v1.param")
+
+MINI = """7767517
+19 24
+Input            input      0 1 input
+Convolution      c0         1 1 input a 0=64 1=3 4=1 5=1 6=1728
+Split            s0         1 5 a a0 a1 a2 a3 a4
+Convolution      c1         1 1 a4 b 0=32 1=3 4=1 5=1 6=18432 9=2 -23310=1,2.000000e-01
+Split            s1         1 2 b b0 b1
+Concat           cat1       2 1 a3 b1 c
+Convolution      c2         1 1 c d 0=32 1=3 4=1 5=1 6=27648 9=2 -23310=1,2.000000e-01
+Convolution      c3         1 1 a2 e 0=32 1=1 6=2048
+BinaryOp         add1       2 1 d e f
+Concat           cat2       3 1 a1 b0 f g
+Convolution      c4         1 1 g h 0=64 1=3 4=1 5=1 6=73728
+Eltwise          sum1       2 1 h a0 i 0=1 -23301=2,2.000000e-01,1.000000e+00
+Interp           up1        1 1 i j 0=1 1=2.000000e+00 2=2.000000e+00
+Convolution      c5         1 1 j k 0=64 1=3 4=1 5=1 6=36864 9=2 -23310=1,2.000000e-01
+Interp           up2        1 1 k l 0=1 1=2.000000e+00 2=2.000000e+00
+Convolution      c6         1 1 l m 0=48 1=3 4=1 5=1 6=27648
+PReLU            p6         1 1 m n 0=48
+Convolution      c7         1 1 n o 0=64 1=3 4=1 5=1 6=27648 9=2 -23310=1,2.000000e-01
+Convolution      c8         1 1 o output 0=3 1=3 4=1 5=1 6=1728
+"""
+
+
+@pytest.fixture(scope="module")
+def mini(tmp_path_factory):
+    from oracle import generic_oracle as go
+    d = tmp_path_factory.mktemp("mini")
+    p, b = str(d / "4x_mini.param"), str(d / "4x_mini.bin")
+    open(p, "w").write(MINI)
+    go.write_synthetic_bin(p, b, seed=3)
+    return p, b, go.Model(p, b)
+
+
+def test_numpy_restatement_agrees_with_the_c_oracle_on_the_real_compact_weights(oracle, oracle_models):
+    """The generic numpy oracle is itself checked where a second implementation with REAL weights exists."""
+    from oracle import generic_oracle as go
+    for key in ("2x", "1x"):
+        p, b = model_paths(key)
+        m = go.Model(p, b)
+        img = oracle.synthetic_frame(13, 17, kind="random", seed=4)
+        x = oracle.from_pixels_normalize(img)
+        want = oracle_models[key].forward(x)
+        got = m.forward(x)
+        assert got.shape == want.shape and float(np.abs(got - want).max()) <= 2e-5
+        d = np.abs(m.apply_u8(img).astype(int) - oracle_models[key].apply_model(img).astype(int))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3          # exact .5 ties may fall either way
+
+
+def test_loader_accepts_valar_and_checks_the_weight_stream(uva, tmp_path, mini):
+    from oracle import generic_oracle as go
+    net = uva.Net()
+    assert net.load_param(VALAR) == 0, getattr(net, "last_error", "")
+    assert (net.scale, net.num_convs, net.num_features) == (4, 420, 192)     # 64 + 4 x 32 channels at the widest Concat
+    assert len(go.conv_shapes(go.parse_param(VALAR))) == 420
+    # the reference's .bin is a missing blob: a file of another graph must not fit
+    assert net.load_model(model_paths("4x")[1]) != 0
+    p, b, _ = mini
+    net2 = uva.Net()
+    assert net2.load_param(p) == 0 and net2.load_model(b) == 0, getattr(net2, "last_error", "")
+    assert (net2.scale, net2.num_convs) == (4, 9)
+    raw = open(b, "rb").read()
+    (tmp_path / "short.bin").write_bytes(raw[:-3])
+    (tmp_path / "long.bin").write_bytes(raw + b"\0\0\0\0")
+    assert net2.load_model(str(tmp_path / "short.bin")) != 0
+    assert net2.load_model(str(tmp_path / "long.bin")) != 0 and "unread bytes" in net2.last_error
+    # layer types outside the executor's list are still refused by name
+    bad = MINI.replace("Eltwise          sum1       2 1 h a0 i 0=1 -23301=2,2.000000e-01,1.000000e+00", "Softmax          sum1       1 1 h i")
+    (tmp_path / "bad.param").write_text(bad)
+    n3 = uva.Net()
+    assert n3.load_param(str(tmp_path / "bad.param")) != 0 and "unsupported layer type 'Softmax'" in n3.last_error
+
+
+def _close(got, want, rel):
+    scale = float(np.abs(want).max())
+    return float(np.abs(got - want).max()) <= rel * scale + 1e-3, (float(np.abs(got - want).max()), scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w", [(9, 14), (16, 16), (21, 37), (1, 1)])
+def test_mini_graph_matches_the_restatement(uva, mini, oracle, h, w):
+    p, b, om = mini
+    net = uva.Net()
+    net.set_vulkan_device(0)
+    assert net.load_param(p) == 0 and net.load_model(b) == 0
+    img = oracle.synthetic_frame(h, w, kind="random", seed=h * 100 + w)
+    x = oracle.from_pixels_normalize(img)
+    got = net._extract(x)
+    want16, want32 = om.forward(x, f16_storage=True), om.forward(x)
+    assert got.shape == (3, 4 * h, 4 * w)
+    ok, info = _close(got, want16, 4e-3)
+    assert ok, info
+    ok, info = _close(got, want32, 2e-2)
+    assert ok, info
+    u8 = net.process_u8(img, tile_size=0)
+    ref = om.apply_u8(img, f16_storage=True)
+    d = np.abs(u8.astype(int) - ref.astype(int))
+    assert d.max() <= 2 and (d > 0).mean() < 0.1, (int(d.max()), float((d > 0).mean()))
+
+
+@pytest.mark.gpu
+def test_mini_graph_with_reference_tiling(uva, mini, oracle):
+    """upscale_image's tile loop (upscale_processing.py:499-516) on the generic path: every tile a plane, core pasted."""
+    from upscale_video_amd import upscale_processing as up
+    p, b, om = mini
+    net = uva.Net()
+    net.set_vulkan_device(0)
+    assert net.load_param(p) == 0 and net.load_model(b) == 0
+    h, w, ts = 40, 53, 16
+    img = oracle.synthetic_frame(h, w, seed=77)
+    got = net.process_u8(img, tile_size=ts, border=10)
+    want = np.zeros((4 * h, 4 * w, 3), np.uint8)
+    for ty in range(-(-h // ts)):
+        for tx in range(-(-w // ts)):
+            (y0, y1, x0, x1), (top, bottom, left, right) = up.tile_window(ts, ty, tx, h, w)
+            tile = om.apply_u8(np.ascontiguousarray(img[y0 - top:y1 + bottom, x0 - left:x1 + right]), f16_storage=True)
+            want[4 * y0:4 * y1, 4 * x0:4 * x1] = tile[4 * top:4 * (top + y1 - y0), 4 * left:4 * (left + x1 - x0)]
+    d = np.abs(got.astype(int) - want.astype(int))
+    assert d.max() <= 2 and (d > 0).mean() < 0.1, (int(d.max()), float((d > 0).mean()))
+
+
+@pytest.mark.gpu
+def test_valar_graph_with_synthetic_weights(uva, oracle, tmp_path):
+    """All 1206 layers of 4x_Valar_v1 (23 RRDBs: Concat up to 192 channels, 1x1 convolutions, Eltwise(0.2, 1.0),
+    two nearest x2 Interps) on a small frame, synthetic weights, against the numpy restatement."""
+    from oracle import generic_oracle as go
+    b = str(tmp_path / "4x_Valar_v1.bin")
+    go.write_synthetic_bin(VALAR, b, seed=11, gain=0.5)
+    om = go.Model(VALAR, b)
+    net = uva.Net()
+    net.set_vulkan_device(0)
+    assert net.load_param(VALAR) == 0 and net.load_model(b) == 0, getattr(net, "last_error", "")
+    img = oracle.synthetic_frame(12, 20, seed=5)
+    x = oracle.from_pixels_normalize(img)
+    got = net._extract(x)
+    want = om.forward(x, f16_storage=True)
+    assert got.shape == (3, 48, 80) and np.isfinite(got).all()
+    ok, info = _close(got, want, 2e-2)
+    assert ok, info
+    u8 = net.process_u8(img, tile_size=960, border=10)
+    assert u8.shape == (48, 80, 3)
+    # the worker layer reaches it by name like the reference does (model_file = "x_Valar_v1", :913-916)
+    from upscale_video_amd import upscale_processing as up
+    os.symlink(VALAR, tmp_path / "4x_Valar_v1.param")
+    up.init_worker([0], 0, str(tmp_path), "x_Valar_v1", 4, "input", "output")
+    assert up.net is not None, up.init_error
+    assert np.array_equal(up.net.process_u8(img, tile_size=960, border=10), u8)
+
+
+@pytest.mark.gpu
+def test_compact_graphs_through_the_generic_executor(uva, oracle, oracle_models, monkeypatch):
+    """Cross-check with REAL weights: the generic executor (UVA_GENERIC=1) on the 2x / 1x Compact graphs against
+    the C oracle and against the fused kernels' result."""
+    fused = {k: load_net(uva, k) for k in ("2x", "1x")}
+    monkeypatch.setenv("UVA_GENERIC", "1")
+    for key in ("2x", "1x"):
+        net = load_net(uva, key)
+        img = oracle.synthetic_frame(30, 41, kind="random", seed=8)
+        got = net.process_u8(img, tile_size=0)
+        want = oracle_models[key].apply_model(img)
+        d = np.abs(got.astype(int) - want.astype(int))
+        assert d.max() <= 2 and psnr_u8(got, want) >= 50, (key, int(d.max()), psnr_u8(got, want))
+        d2 = np.abs(got.astype(int) - fused[key].process_u8(img, tile_size=0).astype(int))
+        assert d2.max() <= 1

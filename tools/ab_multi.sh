@@ -5,11 +5,11 @@ cd /root/repo
 HIPCC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-function -Wno-unused-variable"
 F=upscale_video_amd/csrc/uva_kernels.hip.h
 cp $F /tmp/ab_multi.backup
-$HIPCC upscale_video_amd/csrc/uva_api.hip upscale_video_amd/csrc/uva_model.cpp -o upscale_video_amd/libuva_V0.so 2>&1 | grep error
+$HIPCC upscale_video_amd/csrc/uva_api.hip upscale_video_amd/csrc/uva_model.cpp upscale_video_amd/csrc/uva_generic.cpp -o upscale_video_amd/libuva_V0.so 2>&1 | grep error
 i=1
 for e in "$@"; do
   sed -i "$e" $F
-  $HIPCC upscale_video_amd/csrc/uva_api.hip upscale_video_amd/csrc/uva_model.cpp -o upscale_video_amd/libuva_V$i.so 2>&1 | grep error
+  $HIPCC upscale_video_amd/csrc/uva_api.hip upscale_video_amd/csrc/uva_model.cpp upscale_video_amd/csrc/uva_generic.cpp -o upscale_video_amd/libuva_V$i.so 2>&1 | grep error
   cp /tmp/ab_multi.backup $F
   i=$((i+1))
 done

@@ -6,6 +6,7 @@
 // HIP stream, the packed weights, and a small cache of per-geometry workspaces (zero-bordered
 // fp16 NHWC ping-pong planes) sized for 288 GB of HBM: nothing is freed between frames.
 #include "../../include/uva.h"
+#include "uva_generic.hip.h"
 #include "uva_kernels.hip.h"
 #include "uva_model.h"
 
@@ -102,6 +103,10 @@ std::set<uva_net*> g_nets;
 struct uva_net {
     int device = 0;
     Graph g;
+    // graphs outside the SRVGGNetCompact pattern (4x_Valar_v1, `-m r`): generic layer-by-layer executor
+    bool generic = false;
+    GenericGraph gg;
+    GenericDevice gd;
     bool dev_ready = false;
     bool dev_partial = false;     // some device state exists (ensure_device started); free_device() must run
     int ncu = 256;
@@ -156,6 +161,7 @@ struct uva_net {
         layers.clear();
         for (auto& w : wss) w.release();
         wss.clear();
+        gd.release();
         if (d_fin) (void)hipFree(d_fin);
         if (d_fout) (void)hipFree(d_fout);
         if (d_sink) (void)hipFree(d_sink);
@@ -437,7 +443,8 @@ int launch_head(uva_net* n, bool f32, const HeadArgs& a)
 
 int ensure_device(uva_net* n)
 {
-    if (!n->g.param_loaded || !n->g.model_loaded) return fail("net has no model: call load_param and load_model first");
+    if (n->generic ? !(n->gg.param_loaded && n->gg.model_loaded) : !(n->g.param_loaded && n->g.model_loaded))
+        return fail("net has no model: call load_param and load_model first");
     if (n->dev_ready) {
         HIP_TRY(hipSetDevice(n->device));
         return 0;
@@ -463,6 +470,32 @@ int ensure_device(uva_net* n)
     HIP_TRY(hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking));
     if (const char* e = std::getenv("UVA_TRUNK_FUSION")) n->fuse_pairs = std::atoi(e) != 0;
     HIP_TRY(hipMalloc((void**)&n->d_sink, 64 * 128 + 256));
+    if (n->generic) {
+        // generic graph: every convolution's MFMA image ([tap][cin/32][cout/16][lane][8]) and padded bias
+        const GenericGraph& gg = n->gg;
+        n->gd.convs.resize(gg.convs.size());
+        for (const GLayer& gl : gg.layers) {
+            if (gl.kind != GLayer::CONV) continue;
+            const ConvWeights& c = gg.convs[gl.conv];
+            GenericDevice::ConvDev& cd = n->gd.convs[gl.conv];
+            cd.cin_pad = GenericDevice::pad32(c.cin);
+            cd.cout_pad = (c.cout + 15) / 16 * 16;
+            std::vector<uint16_t> pk;
+            pack_generic(c, gl.ksize, cd.cin_pad, cd.cout_pad, pk);
+            if (upload(&cd.wpk, pk.data(), pk.size() * 2, n->stream)) return 1;
+            std::vector<float> b((size_t)cd.cout_pad, 0.f);
+            std::copy(c.bias.begin(), c.bias.end(), b.begin());
+            if (upload(&cd.bias, b.data(), b.size() * 4, n->stream)) return 1;
+            HIP_TRY(hipStreamSynchronize(n->stream));
+        }
+        n->gd.prelu.assign(gg.prelu.size(), nullptr);
+        for (size_t i = 0; i < gg.prelu.size(); ++i) {
+            if (upload(&n->gd.prelu[i], gg.prelu[i].data(), gg.prelu[i].size() * 4, n->stream)) return 1;
+            HIP_TRY(hipStreamSynchronize(n->stream));
+        }
+        n->dev_ready = true;
+        return 0;
+    }
     // weights: head, trunk..., tail
     const Graph& g = n->g;
     n->layers.resize(g.convs.size());
@@ -804,6 +837,135 @@ int grow_host(uint8_t** p, size_t* cap, size_t bytes)
     return 0;
 }
 
+// ---- generic graphs -------------------------------------------------------------------------------
+int generic_acquire(uva_net* n, int h, int w, int c, GBuf* out)
+{
+    out->h = h; out->w = w; out->c = c; out->cpad = GenericDevice::pad32(c);
+    auto& free_list = n->gd.pool[std::make_tuple(h, w, c)];
+    if (!free_list.empty()) {
+        out->p = free_list.back();
+        free_list.pop_back();
+        return 0;
+    }
+    const size_t bytes = out->elems() * 2;
+    HIP_TRY(hipMalloc((void**)&out->p, bytes));
+    HIP_TRY(hipMemsetAsync(out->p, 0, bytes, n->stream));    // border and padding channels stay zero for the array's life
+    n->gd.pool_bytes += bytes;
+    return 0;
+}
+
+void generic_release(uva_net* n, const GBuf& b)
+{
+    if (b.p) n->gd.pool[std::make_tuple(b.h, b.w, b.c)].push_back(b.p);
+}
+
+// One plane (a reference tile, or the whole frame) through the graph.  Arrays are recycled as soon as their last
+// reader has been queued (stream order makes that safe) and only ever for a blob of the same shape, so borders
+// and padding channels -- never written -- stay zero.
+int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, int sy0, int sx0, int h, int w, void* dst,
+                      size_t dst_stride, int cy0, int cy1, int cx0, int cx1)
+{
+    const GenericGraph& g = n->gg;
+    std::vector<GBuf> buf(g.blobs.size());
+    std::vector<int> left(g.blobs.size(), 0);
+    auto root = [&](int b) { while (g.blobs[b].alias_of >= 0) b = g.blobs[b].alias_of; return b; };
+    for (size_t b = 0; b < g.blobs.size(); ++b) left[b] = g.blobs[b].consumers;
+    auto done_with = [&](int b) {
+        b = root(b);
+        if (--left[b] == 0) { generic_release(n, buf[b]); buf[b].p = nullptr; }
+    };
+    struct Cleanup {
+        uva_net* n; std::vector<GBuf>* bufs;
+        ~Cleanup() { for (auto& b : *bufs) if (b.p) generic_release(n, b); }
+    } cleanup{n, &buf};
+    const int T = 256;
+    for (const GLayer& gl : g.layers) {
+        if (gl.kind == GLayer::SPLIT) continue;
+        const GBlob& ob = g.blobs[gl.out[0]];
+        GBuf o;
+        if (generic_acquire(n, h * ob.scale, w * ob.scale, ob.channels, &o)) return 1;
+        buf[gl.out[0]] = o;
+        auto in = [&](int k) -> const GBuf& { return buf[root(gl.in[k])]; };
+        switch (gl.kind) {
+        case GLayer::INPUT:
+            if (f32) hipLaunchKernelGGL(g_input_f32, dim3((w + T - 1) / T, h), dim3(T), 0, n->stream, (const float*)src, h, w, o.p, o.cpad);
+            else hipLaunchKernelGGL(g_input_u8, dim3((w + T - 1) / T, h), dim3(T), 0, n->stream, (const uint8_t*)src, src_stride, sy0, sx0, h, w, o.p, o.cpad);
+            break;
+        case GLayer::CONV: {
+            const GenericDevice::ConvDev& cd = n->gd.convs[gl.conv];
+            const GBuf& a = in(0);
+            const dim3 grid((a.w + 63) / 64, a.h, (cd.cout_pad + 63) / 64);
+            if (gl.ksize == 3)
+                hipLaunchKernelGGL(g_conv<3>, grid, dim3(256), 0, n->stream, a.p, a.cpad, cd.wpk, cd.bias, o.p, o.c, cd.cout_pad, o.cpad, a.h, a.w, gl.has_act ? 1 : 0, gl.act_slope);
+            else
+                hipLaunchKernelGGL(g_conv<1>, grid, dim3(256), 0, n->stream, a.p, a.cpad, cd.wpk, cd.bias, o.p, o.c, cd.cout_pad, o.cpad, a.h, a.w, gl.has_act ? 1 : 0, gl.act_slope);
+            break;
+        }
+        case GLayer::ADD:
+        case GLayer::ELTWISE_SUM: {
+            const size_t n8 = o.elems() / 8;
+            hipLaunchKernelGGL(g_axpby, dim3((unsigned)((n8 + T - 1) / T)), dim3(T), 0, n->stream, (const half8*)in(0).p, gl.coeffs[0],
+                               (const half8*)in(1).p, gl.coeffs[1], (half8*)o.p, n8);
+            break;
+        }
+        case GLayer::CONCAT: {
+            const size_t npix = (size_t)(o.h + 3) * (o.w + 2);
+            int c_off = 0;
+            for (size_t k = 0; k < gl.in.size(); ++k) {
+                const GBuf& a = in((int)k);
+                const size_t work = npix * (a.c / 8);
+                hipLaunchKernelGGL(g_concat_part, dim3((unsigned)((work + T - 1) / T)), dim3(T), 0, n->stream, a.p, a.cpad, a.c, o.p, o.cpad, c_off, npix);
+                c_off += a.c;
+            }
+            break;
+        }
+        case GLayer::INTERP_NEAREST: {
+            const GBuf& a = in(0);
+            const size_t work = (size_t)o.h * o.w * (o.cpad / 8);
+            hipLaunchKernelGGL(g_interp_nearest, dim3((unsigned)((work + T - 1) / T)), dim3(T), 0, n->stream, a.p, a.h, a.w, a.cpad, o.p, gl.factor);
+            break;
+        }
+        case GLayer::PRELU: {
+            const size_t npix = (size_t)(o.h + 3) * (o.w + 2), work = npix * o.c;
+            hipLaunchKernelGGL(g_prelu, dim3((unsigned)((work + T - 1) / T)), dim3(T), 0, n->stream, in(0).p, n->gd.prelu[gl.slopes], o.p, o.c, o.cpad, npix);
+            break;
+        }
+        case GLayer::PIXELSHUFFLE: {
+            const GBuf& a = in(0);
+            const size_t work = (size_t)o.h * o.w * o.c;
+            hipLaunchKernelGGL(g_pixelshuffle, dim3((unsigned)((work + T - 1) / T)), dim3(T), 0, n->stream, a.p, a.h, a.w, a.cpad, o.p, o.c, o.cpad, gl.factor);
+            break;
+        }
+        default: return fail("generic executor: unhandled layer kind");
+        }
+        HIP_TRY(hipGetLastError());
+        for (int b : gl.in) done_with(b);
+    }
+    const GBuf& res = buf[root(g.out_blob)];
+    const int s = g.scale;
+    if (f32) hipLaunchKernelGGL(g_output_f32, dim3((w * s + T - 1) / T, h * s), dim3(T), 0, n->stream, res.p, h * s, w * s, res.cpad, (float*)dst);
+    else if (cx1 > cx0 && cy1 > cy0)
+        hipLaunchKernelGGL(g_output_u8, dim3(((cx1 - cx0) * s + T - 1) / T, (cy1 - cy0) * s), dim3(T), 0, n->stream, res.p, h * s, w * s, res.cpad,
+                           (uint8_t*)dst, dst_stride, sy0 * s, sx0 * s, cy0 * s, cy1 * s, cx0 * s, cx1 * s);
+    HIP_TRY(hipGetLastError());
+    done_with(g.out_blob);
+    return 0;
+}
+
+// the u8 frame call for a generic graph: every reference tile (upscale_processing.py:499-516) is one plane, run in turn
+int generic_process_u8_device(uva_net* n, const void* d_in, int h, int w, size_t in_stride, void* d_out, size_t out_stride,
+                              int tile_size, int border)
+{
+    std::vector<PlaneDesc> planes;
+    if (tile_size <= 0) { tile_size = 0; border = 0; }
+    if (build_planes(h, w, tile_size, border, planes)) return 1;
+    for (const PlaneDesc& p : planes)
+        if (generic_run_plane(n, false, d_in, in_stride, p.src_y0, p.src_x0, p.h, p.w, d_out, out_stride, p.core_y0,
+                              std::min(p.core_y1, p.h), p.core_x0, std::min(p.core_x1, p.w)))
+            return 1;
+    return 0;
+}
+
 int check_dims(const uva_net* n, int h, int w)
 {
     if (!n) return fail("null net");
@@ -885,8 +1047,17 @@ int uva_net_load_param(uva_net* n, const char* path)
 {
     if (!n || !path) return fail("null argument");
     n->free_device();
+    n->generic = false;
+    n->gg = GenericGraph();
     std::string err;
-    if (!parse_param(path, n->g, err)) return fail(err);
+    // UVA_GENERIC=1 (tests): run even the SRVGGNetCompact graphs through the generic executor
+    const char* force = std::getenv("UVA_GENERIC");
+    if (!(force && std::atoi(force)) && parse_param(path, n->g, err)) return 0;
+    // not the SRVGGNetCompact pattern the fused kernels are written for: the generic executor, if every layer
+    // type is one it knows (4x_Valar_v1 is); otherwise the first parser's message stands
+    std::string gerr;
+    if (!parse_param_generic(path, n->gg, gerr)) return fail(gerr.find("unsupported layer type") != std::string::npos ? gerr : err);
+    n->generic = true;
     return 0;
 }
 
@@ -895,13 +1066,28 @@ int uva_net_load_model(uva_net* n, const char* path)
     if (!n || !path) return fail("null argument");
     n->free_device();
     std::string err;
-    if (!load_bin(path, n->g, err)) return fail(err);
+    if (n->generic ? !load_bin_generic(path, n->gg, err) : !load_bin(path, n->g, err)) return fail(err);
     return 0;
 }
 
-int uva_net_scale(const uva_net* n) { return n && n->g.param_loaded ? n->g.scale : 0; }
-int uva_net_num_features(const uva_net* n) { return n && n->g.param_loaded ? n->g.nf : 0; }
-int uva_net_num_convs(const uva_net* n) { return n && n->g.param_loaded ? (int)n->g.convs.size() : 0; }
+int uva_net_scale(const uva_net* n)
+{
+    if (!n) return 0;
+    if (n->generic) return n->gg.param_loaded ? n->gg.scale : 0;
+    return n->g.param_loaded ? n->g.scale : 0;
+}
+int uva_net_num_features(const uva_net* n)
+{
+    if (!n) return 0;
+    if (n->generic) return n->gg.param_loaded ? n->gg.max_channels : 0;
+    return n->g.param_loaded ? n->g.nf : 0;
+}
+int uva_net_num_convs(const uva_net* n)
+{
+    if (!n) return 0;
+    if (n->generic) return n->gg.param_loaded ? (int)n->gg.convs.size() : 0;
+    return n->g.param_loaded ? (int)n->g.convs.size() : 0;
+}
 
 int uva_net_synchronize(uva_net* n)
 {
@@ -934,7 +1120,8 @@ int uva_net_process_u8_device(uva_net* n, const void* d_in, int h, int w, size_t
     if (check_dims(n, h, w)) return 1;
     if (!d_in || !d_out) return fail("null frame pointer");
     if (ensure_device(n)) return 1;
-    if (in_stride < (size_t)w * 3 || out_stride < (size_t)w * n->g.scale * 3) return fail("row stride too small");
+    if (in_stride < (size_t)w * 3 || out_stride < (size_t)w * uva_net_scale(n) * 3) return fail("row stride too small");
+    if (n->generic) return generic_process_u8_device(n, d_in, h, w, in_stride, d_out, out_stride, tile_size, border);
     Workspace* ws = nullptr;
     if (get_workspace(n, h, w, tile_size, border, &ws)) return 1;
     n->last.valid = true; n->last.ws = ws; n->last.f32 = false; n->last.src = d_in; n->last.src_stride = in_stride;
@@ -977,7 +1164,7 @@ long long uva_net_submit_u8(uva_net* n, const uint8_t* in, int h, int w, size_t 
     if (!in || !out) { fail("null frame pointer"); return -1; }
     if (ensure_device(n)) return -1;
     auto tryhip = [](hipError_t e, const char* what) { return e == hipSuccess ? 0 : fail(std::string(what) + ": " + hipGetErrorString(e)); };
-    const int s = n->g.scale;
+    const int s = uva_net_scale(n);
     const size_t in_row = (size_t)w * 3, out_row = (size_t)w * s * 3;
     if (in_stride < in_row || out_stride < out_row) { fail("row stride too small"); return -1; }
     const size_t in_bytes = in_row * h, out_bytes = out_row * (size_t)h * s;
@@ -1058,9 +1245,15 @@ int uva_net_extract_f32(uva_net* n, const float* in_chw, int h, int w, float* ou
     if (check_dims(n, h, w)) return 1;
     if (!in_chw || !out_chw) return fail("null Mat pointer");
     if (ensure_device(n)) return 1;
-    const int s = n->g.scale;
+    const int s = uva_net_scale(n);
     const size_t in_bytes = (size_t)3 * h * w * 4, out_bytes = (size_t)3 * h * s * w * s * 4;
     if (grow_dev(&n->d_fin, &n->d_fin_cap, in_bytes) || grow_dev(&n->d_fout, &n->d_fout_cap, out_bytes)) return 1;
+    if (n->generic) {
+        HIP_TRY(hipMemcpyAsync(n->d_fin, in_chw, in_bytes, hipMemcpyHostToDevice, n->stream));
+        if (generic_run_plane(n, true, n->d_fin, 0, 0, 0, h, w, n->d_fout, 0, 0, h, 0, w)) return 1;
+        HIP_TRY(hipMemcpyAsync(out_chw, n->d_fout, out_bytes, hipMemcpyDeviceToHost, n->stream));
+        return uva_net_synchronize(n);
+    }
     Workspace* ws = nullptr;
     if (get_workspace(n, h, w, 0, 0, &ws)) return 1;
     HIP_TRY(hipMemcpyAsync(n->d_fin, in_chw, in_bytes, hipMemcpyHostToDevice, n->stream));

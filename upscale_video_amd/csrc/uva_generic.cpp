@@ -1,0 +1,279 @@
+// uva_generic.cpp -- parser / shape inference / weight reader for generic ncnn graphs (see uva_generic.h).
+// File formats as in uva_model.cpp (ncnn src/net.cpp text .param, src/modelbin.cpp weight stream).
+#include "uva_generic.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+
+namespace uva {
+namespace {
+
+bool gfail(std::string& err, const std::string& msg) { err = msg; return false; }
+
+struct Raw {
+    std::string type, name;
+    std::vector<std::string> in, out;
+    std::map<int, std::string> kv;
+    int geti(int id, int def) const { auto it = kv.find(id); return it == kv.end() ? def : std::atoi(it->second.c_str()); }
+    double getf(int id, double def) const { auto it = kv.find(id); return it == kv.end() ? def : std::atof(it->second.c_str()); }
+    // array parameter "-233xx=n,v0,v1,..."
+    std::vector<double> geta(int id) const
+    {
+        std::vector<double> v;
+        auto it = kv.find(id);
+        if (it == kv.end()) return v;
+        std::stringstream ss(it->second);
+        std::string tok;
+        bool first = true;
+        while (std::getline(ss, tok, ',')) {
+            if (first) { first = false; continue; }   // the count
+            v.push_back(std::atof(tok.c_str()));
+        }
+        return v;
+    }
+};
+
+}  // namespace
+
+bool parse_param_generic(const std::string& path, GenericGraph& g, std::string& err)
+{
+    g = GenericGraph();
+    std::ifstream f(path);
+    if (!f) return gfail(err, "load_param: cannot open " + path);
+    long magic = 0;
+    int nl = 0, nb = 0;
+    f >> magic >> nl >> nb;
+    if (!f || magic != 7767517) return gfail(err, "load_param: bad magic in " + path);
+    if (nl < 2 || nl > 65536) return gfail(err, "load_param: bad layer count in " + path);
+    std::string line;
+    std::getline(f, line);
+    std::vector<Raw> L;
+    while ((int)L.size() < nl && std::getline(f, line)) {
+        std::istringstream ss(line);
+        Raw r;
+        int nin = 0, nout = 0;
+        if (!(ss >> r.type >> r.name >> nin >> nout)) continue;
+        std::string t;
+        for (int i = 0; i < nin; ++i) { ss >> t; r.in.push_back(t); }
+        for (int i = 0; i < nout; ++i) { ss >> t; r.out.push_back(t); }
+        while (ss >> t) {
+            const size_t eq = t.find('=');
+            if (eq == std::string::npos) continue;
+            r.kv[std::atoi(t.substr(0, eq).c_str())] = t.substr(eq + 1);
+        }
+        L.push_back(r);
+    }
+    if ((int)L.size() != nl) return gfail(err, "load_param: truncated " + path);
+
+    std::map<std::string, int> blob_id;
+    auto blob_of = [&](const std::string& name, bool create) -> int {
+        auto it = blob_id.find(name);
+        if (it != blob_id.end()) return it->second;
+        if (!create) return -1;
+        GBlob b;
+        b.name = name;
+        g.blobs.push_back(b);
+        blob_id[name] = (int)g.blobs.size() - 1;
+        return (int)g.blobs.size() - 1;
+    };
+    auto root = [&](int b) { while (g.blobs[b].alias_of >= 0) b = g.blobs[b].alias_of; return b; };
+
+    for (const Raw& r : L) {
+        GLayer gl;
+        gl.name = r.name;
+        for (const auto& nm : r.in) {
+            const int b = blob_of(nm, false);
+            if (b < 0) return gfail(err, "load_param: " + r.name + " reads undefined blob " + nm);
+            gl.in.push_back(b);
+            g.blobs[root(b)].consumers += 1;
+        }
+        for (const auto& nm : r.out) {
+            if (blob_id.count(nm)) return gfail(err, "load_param: blob " + nm + " defined twice");
+            gl.out.push_back(blob_of(nm, true));
+        }
+        auto in_ch = [&](int k) { return g.blobs[gl.in[k]].channels; };
+        auto in_sc = [&](int k) { return g.blobs[gl.in[k]].scale; };
+        auto set_out = [&](int k, int ch, int sc) { g.blobs[gl.out[k]].channels = ch; g.blobs[gl.out[k]].scale = sc; };
+        if (r.type == "Input") {
+            if (r.in.size() != 0 || r.out.size() != 1 || g.in_blob >= 0) return gfail(err, "load_param: unexpected Input layer " + r.name);
+            gl.kind = GLayer::INPUT;
+            set_out(0, 3, 1);
+            g.in_blob = gl.out[0];
+        } else if (r.type == "Split") {
+            if (r.in.size() != 1 || r.out.empty()) return gfail(err, "load_param: bad Split " + r.name);
+            gl.kind = GLayer::SPLIT;
+            g.blobs[root(gl.in[0])].consumers -= 1;      // a Split is not a consumer, its outputs' readers are
+            for (size_t k = 0; k < gl.out.size(); ++k) {
+                set_out((int)k, in_ch(0), in_sc(0));
+                g.blobs[gl.out[k]].alias_of = root(gl.in[0]);
+            }
+        } else if (r.type == "Convolution") {
+            if (r.in.size() != 1 || r.out.size() != 1) return gfail(err, "load_param: bad blobs in " + r.name);
+            gl.kind = GLayer::CONV;
+            ConvWeights c;
+            c.name = r.name;
+            c.cout = r.geti(0, 0);
+            c.weight_data_size = r.geti(6, 0);
+            const int kw = r.geti(1, 0), kh = r.geti(11, kw), pad = r.geti(4, 0);
+            if (kw != kh || (kw != 1 && kw != 3)) return gfail(err, "load_param: " + r.name + ": only 1x1 and 3x3 kernels are implemented");
+            if (pad != (kw == 3 ? 1 : 0) || r.geti(14, pad) != pad || r.geti(15, pad) != pad || r.geti(16, r.geti(14, pad)) != pad ||
+                r.geti(2, 1) != 1 || r.geti(12, 1) != 1 || r.geti(3, 1) != 1 || r.geti(13, 1) != 1 || r.getf(18, 0.0) != 0.0 ||
+                r.geti(8, 0) != 0 || r.geti(7, 1) != 1)
+                return gfail(err, "load_param: " + r.name + " is not a stride-1 'same' convolution");
+            gl.ksize = kw;
+            gl.has_bias = r.geti(5, 0) != 0;
+            const int act = r.geti(9, 0);
+            if (act == 2) {
+                const auto p = r.geta(-23310);
+                gl.has_act = true;
+                gl.act_slope = p.empty() ? 0.f : (float)p[0];
+            } else if (act != 0) {
+                return gfail(err, "load_param: " + r.name + ": fused activation type " + std::to_string(act) + " is not implemented");
+            }
+            c.cin = in_ch(0);
+            if (c.cout <= 0 || c.cin <= 0 || c.weight_data_size != c.cout * c.cin * kw * kw)
+                return gfail(err, "load_param: bad sizes in " + r.name);
+            gl.conv = (int)g.convs.size();
+            g.convs.push_back(c);
+            set_out(0, c.cout, in_sc(0));
+            g.flops_per_input_px += 2.0 * c.cout * c.cin * kw * kw * in_sc(0) * in_sc(0);
+        } else if (r.type == "Concat") {
+            if (r.in.size() < 2 || r.out.size() != 1 || r.geti(0, 0) != 0) return gfail(err, "load_param: bad Concat " + r.name);
+            gl.kind = GLayer::CONCAT;
+            int ch = 0;
+            for (size_t k = 0; k < gl.in.size(); ++k) {
+                if (in_sc((int)k) != in_sc(0)) return gfail(err, "load_param: Concat of different sizes at " + r.name);
+                if (in_ch((int)k) % 8) return gfail(err, "load_param: Concat inputs must have a multiple of 8 channels at " + r.name);
+                ch += in_ch((int)k);
+            }
+            set_out(0, ch, in_sc(0));
+        } else if (r.type == "BinaryOp" || r.type == "Eltwise") {
+            if (r.in.size() != 2 || r.out.size() != 1) return gfail(err, "load_param: bad blobs in " + r.name);
+            if (in_ch(0) != in_ch(1) || in_sc(0) != in_sc(1)) return gfail(err, "load_param: shape mismatch at " + r.name);
+            if (r.type == "BinaryOp") {
+                if (r.geti(0, 0) != 0 || r.geti(1, 0) != 0) return gfail(err, "load_param: BinaryOp " + r.name + " is not a tensor ADD");
+                gl.kind = GLayer::ADD;
+                gl.coeffs = {1.f, 1.f};
+            } else {
+                if (r.geti(0, 0) != 1) return gfail(err, "load_param: Eltwise " + r.name + " is not SUM");
+                gl.kind = GLayer::ELTWISE_SUM;
+                const auto p = r.geta(-23301);
+                if (p.empty()) gl.coeffs = {1.f, 1.f};
+                else if (p.size() == 2) gl.coeffs = {(float)p[0], (float)p[1]};
+                else return gfail(err, "load_param: Eltwise " + r.name + " needs two coefficients");
+            }
+            set_out(0, in_ch(0), in_sc(0));
+        } else if (r.type == "Interp") {
+            if (r.in.size() != 1 || r.out.size() != 1) return gfail(err, "load_param: bad blobs in " + r.name);
+            const double sh = r.getf(1, 1.0), sw = r.getf(2, 1.0);
+            if (r.geti(0, 0) != 1 || sh != sw || sh != (double)(int)sh || sh < 1 || sh > 8)
+                return gfail(err, "load_param: Interp " + r.name + " must be nearest with an integer scale");
+            gl.kind = GLayer::INTERP_NEAREST;
+            gl.factor = (int)sh;
+            set_out(0, in_ch(0), in_sc(0) * gl.factor);
+        } else if (r.type == "PReLU") {
+            if (r.in.size() != 1 || r.out.size() != 1 || r.geti(0, 0) != in_ch(0)) return gfail(err, "load_param: bad PReLU " + r.name);
+            gl.kind = GLayer::PRELU;
+            gl.slopes = (int)g.prelu_sizes.size();
+            g.prelu_sizes.push_back(in_ch(0));
+            set_out(0, in_ch(0), in_sc(0));
+        } else if (r.type == "PixelShuffle") {
+            const int f = r.geti(0, 1);
+            if (r.in.size() != 1 || r.out.size() != 1 || r.geti(1, 0) != 0 || f < 1 || f > 8 || in_ch(0) % (f * f))
+                return gfail(err, "load_param: bad PixelShuffle " + r.name);
+            gl.kind = GLayer::PIXELSHUFFLE;
+            gl.factor = f;
+            set_out(0, in_ch(0) / (f * f), in_sc(0) * f);
+        } else {
+            return gfail(err, "load_param: unsupported layer type '" + r.type + "' (" + r.name + ")");
+        }
+        g.layers.push_back(gl);
+    }
+    if (g.in_blob < 0 || g.blobs[g.in_blob].name != "input") return gfail(err, "load_param: no Input layer named 'input'");
+    g.out_blob = blob_of("output", false);
+    if (g.out_blob < 0) return gfail(err, "load_param: no blob named 'output'");
+    if (g.blobs[g.out_blob].channels != 3) return gfail(err, "load_param: 'output' must have 3 channels");
+    g.blobs[root(g.out_blob)].consumers += 1;            // the caller reads it
+    g.scale = g.blobs[g.out_blob].scale;
+    for (const auto& b : g.blobs) g.max_channels = b.channels > g.max_channels ? b.channels : g.max_channels;
+    g.param_loaded = true;
+    return true;
+}
+
+bool load_bin_generic(const std::string& path, GenericGraph& g, std::string& err)
+{
+    if (!g.param_loaded) return gfail(err, "load_model: load_param first");
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return gfail(err, "load_model: cannot open " + path);
+    std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    size_t off = 0;
+    auto need = [&](size_t n) { return off + n <= raw.size(); };
+    g.prelu.assign(g.prelu_sizes.size(), {});
+    for (const GLayer& gl : g.layers) {
+        if (gl.kind == GLayer::CONV) {
+            ConvWeights& c = g.convs[gl.conv];
+            const size_t n = (size_t)c.weight_data_size;
+            if (!need(4)) return gfail(err, "load_model: truncated at " + c.name);
+            std::memcpy(&c.tag, raw.data() + off, 4);
+            off += 4;
+            c.w.resize(n);
+            if (c.tag == 0x01306B47u) {
+                const size_t bytes = (n * 2 + 3) & ~(size_t)3;
+                if (!need(bytes)) return gfail(err, "load_model: truncated at " + c.name);
+                for (size_t k = 0; k < n; ++k) {
+                    uint16_t h;
+                    std::memcpy(&h, raw.data() + off + 2 * k, 2);
+                    c.w[k] = f16_bits_to_f32(h);
+                }
+                off += bytes;
+            } else if (c.tag == 0) {
+                if (!need(n * 4)) return gfail(err, "load_model: truncated at " + c.name);
+                std::memcpy(c.w.data(), raw.data() + off, n * 4);
+                off += n * 4;
+            } else {
+                return gfail(err, "load_model: unsupported weight flag at " + c.name);
+            }
+            c.bias.assign((size_t)c.cout, 0.f);
+            if (gl.has_bias) {
+                if (!need((size_t)c.cout * 4)) return gfail(err, "load_model: truncated at " + c.name);
+                std::memcpy(c.bias.data(), raw.data() + off, (size_t)c.cout * 4);
+                off += (size_t)c.cout * 4;
+            }
+        } else if (gl.kind == GLayer::PRELU) {
+            const size_t n = (size_t)g.prelu_sizes[gl.slopes];
+            if (!need(n * 4)) return gfail(err, "load_model: truncated at " + gl.name);
+            g.prelu[gl.slopes].resize(n);
+            std::memcpy(g.prelu[gl.slopes].data(), raw.data() + off, n * 4);
+            off += n * 4;
+        }
+    }
+    if (off != raw.size())
+        return gfail(err, "load_model: " + std::to_string(raw.size() - off) + " unread bytes in " + path +
+                              " (weights do not match the graph)");
+    g.model_loaded = true;
+    return true;
+}
+
+void pack_generic(const ConvWeights& c, int ksize, int cin_pad, int cout_pad, std::vector<uint16_t>& out)
+{
+    const int taps = ksize * ksize, c32n = cin_pad / 32, mbn = cout_pad / 16;
+    out.assign((size_t)taps * c32n * mbn * 64 * 8, 0);
+    for (int tap = 0; tap < taps; ++tap)
+        for (int c32 = 0; c32 < c32n; ++c32)
+            for (int mb = 0; mb < mbn; ++mb)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int co = 16 * mb + (lane & 15);
+                    if (co >= c.cout) continue;
+                    for (int e = 0; e < 8; ++e) {
+                        const int ci = 32 * c32 + 8 * (lane >> 4) + e;
+                        if (ci >= c.cin) continue;
+                        out[((((size_t)tap * c32n + c32) * mbn + mb) * 64 + lane) * 8 + e] =
+                            f32_to_f16_bits(c.w[((size_t)co * c.cin + ci) * taps + tap]);
+                    }
+                }
+}
+
+}  // namespace uva
