@@ -25,8 +25,9 @@
 extern "C" {
 #endif
 
-#define UVA_ABI_VERSION 3   /* 2: + uva_net_submit_u8 / uva_net_collect_u8 / uva_host_alloc / uva_host_free;
-                               3: + uva_get_gpu_pci_bus_id, uva_debug_trunk2_schedule */
+#define UVA_ABI_VERSION 4   /* 2: + uva_net_submit_u8 / uva_net_collect_u8 / uva_host_alloc / uva_host_free;
+                               3: + uva_get_gpu_pci_bus_id, uva_debug_trunk2_schedule;
+                               4: + uva_denoise_u8, uva_debug_denoise_stage; generic graphs (4x_Valar_v1) load */
 
 typedef struct uva_net uva_net;
 
@@ -115,6 +116,19 @@ int uva_net_synchronize(uva_net* net);
  * hops through an 8-bit PNG between them, upscale/upscale_processing.py:888-909; a u8 frame in HBM
  * carries exactly the same information). */
 int uva_net_wait_for(uva_net* net, uva_net* producer);
+
+/* ---- `-m n=K` film-grain denoise ------------------------------------------------------------ */
+
+/* cv2.fastNlMeansDenoisingColored(cv2.UMat(img), None, K, K, 5, 9)   upscale/upscale_processing.py:350-354
+ * (apply_denoise; K = 1..30 from `-m n=K`, :782-789): BGR -> 8-bit Lab (linear light), non-local means on L
+ * with h_luma and on (a, b) with h_color (template 5, search 9), Lab -> BGR; on HIP device `device`.
+ * in / out: host u8 HWC BGR [h][w][3].  OpenCV's integer weighting scheme is reproduced exactly; its 8-bit Lab
+ * conversions (fixed-point tables) are replaced by the CIE formulas in fp32 (csrc/uva_denoise.hip.h). */
+int uva_denoise_u8(int device, const uint8_t* in, int h, int w, size_t in_stride, uint8_t* out, size_t out_stride,
+                   float h_luma, float h_color);
+/* Test hook: one stage of the above on dense host arrays.  stage 0: BGR -> Lab [h][w][3]; 1: Lab -> BGR;
+ * 2: non-local means on a 1-channel image; 3: on a 2-channel image (strength = h). */
+int uva_debug_denoise_stage(int device, int stage, const uint8_t* in, int h, int w, float strength, uint8_t* out);
 
 /* ---- introspection used by the parity tests and bench.py ------------------------------ */
 

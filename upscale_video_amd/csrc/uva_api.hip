@@ -6,6 +6,7 @@
 // HIP stream, the packed weights, and a small cache of per-geometry workspaces (zero-bordered
 // fp16 NHWC ping-pong planes) sized for 288 GB of HBM: nothing is freed between frames.
 #include "../../include/uva.h"
+#include "uva_denoise.hip.h"
 #include "uva_generic.hip.h"
 #include "uva_kernels.hip.h"
 #include "uva_model.h"
@@ -13,6 +14,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -974,6 +977,151 @@ int check_dims(const uva_net* n, int h, int w)
 }
 
 }  // namespace
+
+// ---- `-m n=K`: non-local-means denoise (upscale/upscale_processing.py:350-361) -------------------------
+namespace {
+
+struct DenoiseCtx {
+    hipStream_t stream = nullptr;
+    uint8_t *d_in = nullptr, *d_out = nullptr, *d_l = nullptr, *d_l2 = nullptr, *d_ab = nullptr, *d_ab2 = nullptr;
+    size_t cap_px = 0;
+    int* d_table[2] = {nullptr, nullptr};
+    int table_size[2] = {0, 0};
+    float table_h[2] = {-1.f, -1.f};
+};
+std::mutex g_denoise_mu;
+DenoiseCtx g_denoise[16];
+
+// OpenCV fast_nlmeans_denoising_invoker.hpp: almost_dist2weight_ for 8-bit samples, squared distance
+void nlm_weight_table(float h, int cn, std::vector<int>& table)
+{
+    const int search = 2 * NLM_S + 1, templ = 2 * NLM_T + 1;
+    const int fixed_point_mult = INT_MAX / (search * search * 255);
+    const double mult = (double)(1 << NLM_SHIFT) / (templ * templ);
+    const int max_dist = 255 * 255 * cn;
+    const int almost_max = (int)(max_dist / mult + 1);
+    table.resize(almost_max);
+    for (int ad = 0; ad < almost_max; ++ad) {
+        const double dist = ad * mult;
+        double w = std::exp(-dist / ((double)h * h * cn));
+        if (std::isnan(w)) w = 1.0;
+        int weight = (int)std::lrint(fixed_point_mult * w);
+        if (weight < 0.001 * fixed_point_mult) weight = 0;
+        table[ad] = weight;
+    }
+}
+
+int denoise_ctx(int device, size_t px, DenoiseCtx** out)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail("no HIP device available: libuva has no CPU path");
+    if (device < 0 || device >= count || device >= 16) return fail("HIP device " + std::to_string(device) + " does not exist");
+    HIP_TRY(hipSetDevice(device));
+    DenoiseCtx& c = g_denoise[device];
+    if (!c.stream) HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    if (c.cap_px < px) {
+        for (uint8_t** p : {&c.d_in, &c.d_out, &c.d_l, &c.d_l2, &c.d_ab, &c.d_ab2}) {
+            if (*p) (void)hipFree(*p);
+            *p = nullptr;
+        }
+        c.cap_px = 0;
+        HIP_TRY(hipMalloc((void**)&c.d_in, px * 3));
+        HIP_TRY(hipMalloc((void**)&c.d_out, px * 3));
+        HIP_TRY(hipMalloc((void**)&c.d_l, px));
+        HIP_TRY(hipMalloc((void**)&c.d_l2, px));
+        HIP_TRY(hipMalloc((void**)&c.d_ab, px * 2));
+        HIP_TRY(hipMalloc((void**)&c.d_ab2, px * 2));
+        c.cap_px = px;
+    }
+    *out = &c;
+    return 0;
+}
+
+int denoise_table(DenoiseCtx& c, int which, float h, int cn)
+{
+    if (c.table_h[which] == h && c.d_table[which]) return 0;
+    std::vector<int> t;
+    nlm_weight_table(h, cn, t);
+    if (c.d_table[which]) (void)hipFree(c.d_table[which]);
+    c.d_table[which] = nullptr;
+    HIP_TRY(hipMalloc((void**)&c.d_table[which], t.size() * sizeof(int)));
+    HIP_TRY(hipMemcpy(c.d_table[which], t.data(), t.size() * sizeof(int), hipMemcpyHostToDevice));
+    c.table_size[which] = (int)t.size();
+    c.table_h[which] = h;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int uva_denoise_u8(int device, const uint8_t* in, int h, int w, size_t in_stride, uint8_t* out, size_t out_stride,
+                   float h_luma, float h_color)
+{
+    if (!in || !out || h <= 0 || w <= 0 || (long long)h * w > (1ll << 28)) return fail("bad image");
+    if (in_stride < (size_t)w * 3 || out_stride < (size_t)w * 3) return fail("row stride too small");
+    if (!(h_luma > 0.f) || !(h_color > 0.f)) return fail("denoise strength must be positive");
+    std::lock_guard<std::mutex> lk(g_denoise_mu);
+    DenoiseCtx* c = nullptr;
+    const size_t px = (size_t)h * w;
+    if (denoise_ctx(device, px, &c)) return 1;
+    if (denoise_table(*c, 0, h_luma, 1) || denoise_table(*c, 1, h_color, 2)) return 1;
+    HIP_TRY(hipMemcpy2DAsync(c->d_in, (size_t)w * 3, in, in_stride, (size_t)w * 3, h, hipMemcpyHostToDevice, c->stream));
+    const dim3 rows((w + 255) / 256, h), tiles((w + NLM_BLK - 1) / NLM_BLK, (h + NLM_BLK - 1) / NLM_BLK);
+    hipLaunchKernelGGL(nlm_bgr2lab, rows, dim3(256), 0, c->stream, c->d_in, (size_t)w * 3, h, w, c->d_l, c->d_ab);
+    hipLaunchKernelGGL(nlm_plane<1>, tiles, dim3(NLM_BLK * NLM_BLK), 0, c->stream, c->d_l, h, w, c->d_table[0], c->table_size[0], c->d_l2);
+    hipLaunchKernelGGL(nlm_plane<2>, tiles, dim3(NLM_BLK * NLM_BLK), 0, c->stream, c->d_ab, h, w, c->d_table[1], c->table_size[1], c->d_ab2);
+    hipLaunchKernelGGL(nlm_lab2bgr, rows, dim3(256), 0, c->stream, c->d_l2, c->d_ab2, h, w, c->d_out, (size_t)w * 3);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy2DAsync(out, out_stride, c->d_out, (size_t)w * 3, (size_t)w * 3, h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int uva_debug_denoise_stage(int device, int stage, const uint8_t* in, int h, int w, float strength, uint8_t* out)
+{
+    if (!in || !out || h <= 0 || w <= 0) return fail("bad argument");
+    std::lock_guard<std::mutex> lk(g_denoise_mu);
+    DenoiseCtx* c = nullptr;
+    const size_t px = (size_t)h * w;
+    if (denoise_ctx(device, px, &c)) return 1;
+    const dim3 rows((w + 255) / 256, h), tiles((w + NLM_BLK - 1) / NLM_BLK, (h + NLM_BLK - 1) / NLM_BLK);
+    if (stage == 0) {          // bgr [h][w][3] -> Lab interleaved [h][w][3]
+        HIP_TRY(hipMemcpy(c->d_in, in, px * 3, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(nlm_bgr2lab, rows, dim3(256), 0, c->stream, c->d_in, (size_t)w * 3, h, w, c->d_l, c->d_ab);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        std::vector<uint8_t> l(px), ab(px * 2);
+        HIP_TRY(hipMemcpy(l.data(), c->d_l, px, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(ab.data(), c->d_ab, px * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < px; ++i) { out[3 * i] = l[i]; out[3 * i + 1] = ab[2 * i]; out[3 * i + 2] = ab[2 * i + 1]; }
+    } else if (stage == 1) {   // Lab interleaved -> bgr
+        std::vector<uint8_t> l(px), ab(px * 2);
+        for (size_t i = 0; i < px; ++i) { l[i] = in[3 * i]; ab[2 * i] = in[3 * i + 1]; ab[2 * i + 1] = in[3 * i + 2]; }
+        HIP_TRY(hipMemcpy(c->d_l, l.data(), px, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_ab, ab.data(), px * 2, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(nlm_lab2bgr, rows, dim3(256), 0, c->stream, c->d_l, c->d_ab, h, w, c->d_out, (size_t)w * 3);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(out, c->d_out, px * 3, hipMemcpyDeviceToHost));
+    } else if (stage == 2 || stage == 3) {   // NLM on a 1-channel (2) / 2-channel (3) u8 image
+        const int cn = stage - 1;
+        if (!(strength > 0.f)) return fail("denoise strength must be positive");
+        if (denoise_table(*c, cn - 1, strength, cn)) return 1;
+        uint8_t* src = cn == 1 ? c->d_l : c->d_ab;
+        uint8_t* dst = cn == 1 ? c->d_l2 : c->d_ab2;
+        HIP_TRY(hipMemcpy(src, in, px * cn, hipMemcpyHostToDevice));
+        if (cn == 1) hipLaunchKernelGGL(nlm_plane<1>, tiles, dim3(NLM_BLK * NLM_BLK), 0, c->stream, src, h, w, c->d_table[0], c->table_size[0], dst);
+        else hipLaunchKernelGGL(nlm_plane<2>, tiles, dim3(NLM_BLK * NLM_BLK), 0, c->stream, src, h, w, c->d_table[1], c->table_size[1], dst);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(out, dst, px * cn, hipMemcpyDeviceToHost));
+    } else {
+        return fail("bad stage");
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"
 
 extern "C" {
 

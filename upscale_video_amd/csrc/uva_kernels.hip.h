@@ -1151,12 +1151,37 @@ struct Trunk2Args {
     _Float16* sink;
 };
 
+// LDS layout of trunk2_kernel: a pixel is 128 bytes = eight 16-byte slots with NO padding; slot s of the
+// pixel in tile / ring column cc holds channel octet s ^ (cc & 7).  With that XOR a B-fragment read of
+// v_mfma_f32_16x16x32_f16 (lane = (octet << 4) | pixel: 16 consecutive columns, 4 octets) is bank-conflict free
+// for every fragment origin and both input-channel halves, which the padded 144-byte stride of trunk_kernel
+// is NOT for this lane mapping: it is 2-way conflicting (profiles/r02_a_trunk_pmc.json: 47 % of the LDS
+// cycles were conflict cycles).  Also 26 instead of 29 LDS-DMA pieces per input tile.
+constexpr int T2_PIXB = 128;
+constexpr int T2_ROWB = PW * T2_PIXB;                        // one halo-tile / ring row in LDS
+constexpr int T2_PIECES = (TH4 + 2) * PW * 8 / 64 + 1;       // 6 x 34 pixels x 8 slots = 1632 slots -> 26 one-KiB pieces
+constexpr int T2_SLOTB = T2_PIECES * 1024;
+constexpr int T2_CPW = (T2_PIECES + 3) / 4;                  // 7 per wave (waves 2, 3: 6)
+static_assert(T2_PIECES == 26 && T2_SLOTB % 128 == 0, "trunk2 tile geometry");
 template <int NF>
 constexpr int trunk2_lds_bytes()
 {
-    return T2_SLOTS * TrunkGeo<NF>::SLOTB + T2_RING_ROWS * PW * Geo<NF, TH4>::LPIXB + 2 * PARAM_LDS;
+    return T2_SLOTS * T2_SLOTB + T2_RING_ROWS * T2_ROWB + 2 * PARAM_LDS;
 }
 static_assert(trunk2_lds_bytes<64>() <= 160 * 1024, "trunk2 kernel LDS budget");
+
+// LDS-DMA piece i of wave `wave`: piece c = 4i + wave covers slots [64c, 64c + 64) of the tile; slot q is
+// pixel q / 8 (halo row r, column cc) and holds channel octet (q % 8) ^ (cc & 7).  -> (r << 13) | byte offset
+// of that octet inside the source row.
+__device__ __forceinline__ unsigned t2_piece_const(int i, int wave, int lane)
+{
+    const int q = (4 * i + wave) * 64 + lane;
+    int pix = q >> 3;
+    const int s = q & 7;
+    if (pix >= (TH4 + 2) * PW) pix = (TH4 + 2) * PW - 1;      // tail of the last piece: any valid address
+    const int r = pix / PW, cc = pix - r * PW;
+    return (unsigned)((r << 13) | (cc * T2_PIXB + ((s ^ (cc & 7)) << 4)));
+}
 
 template <int KEEP>
 __device__ __forceinline__ void dma_barrier()
@@ -1169,12 +1194,11 @@ __global__ __launch_bounds__(512, 2) void trunk2_kernel(Trunk2Args a)
 {
     static_assert(NF == 64, "written for 64 features");
     using G = Geo<NF, TH4>;
-    using TG = TrunkGeo<NF>;
     constexpr int KS = G::KS;
-    constexpr int CPW = TG::CPW;
-    constexpr int SLOTB = TG::SLOTB;
+    constexpr int CPW = T2_CPW;
+    constexpr int SLOTB = T2_SLOTB;
     constexpr int PFF = 6;
-    constexpr int ROWB = PW * G::LPIXB;            // one ring / halo-tile row in LDS
+    constexpr int ROWB = T2_ROWB;
     constexpr int BLOCKB = 4 * ROWB;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1209,12 +1233,10 @@ __global__ __launch_bounds__(512, 2) void trunk2_kernel(Trunk2Args a)
     }
     // LDS-DMA source position of this lane in piece i: (halo row << 13) | byte offset inside the row, two
     // pieces per register (the k-loop needs every register it can get)
-    unsigned dma_pc2[CPW / 2];
+    unsigned dma_pc2[(CPW + 1) / 2];
 #pragma unroll
-    for (int i = 0; i < CPW / 2; ++i) {
-        const int lo = trunk_piece_const<NF>(2 * i, wave, lane), hi = trunk_piece_const<NF>(2 * i + 1, wave, lane);
-        dma_pc2[i] = (unsigned)(((lo >> 16) << 13) | (lo & 0x1fff)) | ((unsigned)(((hi >> 16) << 13) | (hi & 0x1fff)) << 16);
-    }
+    for (int i = 0; i < (CPW + 1) / 2; ++i)
+        dma_pc2[i] = t2_piece_const(2 * i, wave, lane) | (2 * i + 1 < CPW ? t2_piece_const(2 * i + 1, wave, lane) << 16 : 0u);
 
     auto issue_tile = [&](const uint4 e, int slot) __attribute__((always_inline)) {
         const unsigned lo = __builtin_amdgcn_readfirstlane(e.x), hi = __builtin_amdgcn_readfirstlane(e.y) & 0xffu;
@@ -1222,8 +1244,9 @@ __global__ __launch_bounds__(512, 2) void trunk2_kernel(Trunk2Args a)
         const int pitch = __builtin_amdgcn_readfirstlane(e.z);
 #pragma unroll
         for (int i = 0; i < CPW; ++i) {
+            if (4 * i + wave >= T2_PIECES) continue;          // 26 pieces, 4 waves x 7: waves 2, 3 have no 7th piece
             const unsigned pc = (dma_pc2[i >> 1] >> (16 * (i & 1))) & 0xffffu;
-            trunk_issue_piece<NF>(base, pitch, lds0 + slot * SLOTB, i, wave, (int)(((pc >> 13) << 16) | (pc & 0x1fffu)));
+            glds16_s(base, (pc >> 13) * (unsigned)pitch + (pc & 0x1fffu), lds0 + slot * SLOTB + (4 * i + wave) * 1024);
         }
     };
     if (grp == 0) {
@@ -1261,12 +1284,23 @@ __global__ __launch_bounds__(512, 2) void trunk2_kernel(Trunk2Args a)
             // wraps behind row 11, which only the second row pair (rows 2..5 of the window) can cross.
             const int bblk = blk + 1 >= 3 ? blk - 2 : blk + 1;
             const char* const win = grp ? ring + bblk * BLOCKB : smem + blk * SLOTB;
-            const char* const bbase_lo = win + ((2 * rp) * PW + (lane & 15)) * G::LPIXB + (lane >> 4) * 16;
-            const char* const bbase_hi = bbase_lo - ((grp && rp && bblk == 2) ? T2_RING_ROWS * ROWB : 0);
+            // lane (pixel p = lane & 15, octet o = lane >> 4) reads slot (4*ch + o) ^ ((p + dx) & 7) of pixel
+            // (row 2rp + R, column 16c + p + dx): the XOR term depends on dx only (16c = 0 mod 8), and the channel
+            // half flips bit 6 of an address whose other terms are multiples of 128
+            const int pq = lane & 15, oq = lane >> 4;
+            const unsigned wrap = (grp && rp && bblk == 2) ? T2_RING_ROWS * ROWB : 0;
+            const unsigned a0 = (unsigned)(win - smem) + ((2 * rp) * PW + pq) * T2_PIXB;   // smem itself starts 128-byte aligned (offset 0)
+            unsigned blo[3], bhi[3];
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                blo[dx] = a0 + ((oq ^ ((pq + dx) & 7)) << 4);
+                bhi[dx] = blo[dx] - wrap;
+            }
             auto read_b = [&](int f) __attribute__((always_inline)) -> half8 {
                 const int st = f >> 1, c = f & 1;
                 const int R = st & 3, ch = (st >> 2) & 1, dx = st >> 3;
-                return *(const half8*)((R < 2 ? bbase_lo : bbase_hi) + (R * PW + dx + 16 * c) * G::LPIXB + ch * 64);
+                const unsigned a = ((R < 2 ? blo[dx] : bhi[dx]) ^ (ch ? 64u : 0u)) + (R * PW + dx + 16 * c) * T2_PIXB;
+                return *(const half8*)(smem + a);
             };
             constexpr int NSTEP = 24, NFRAG = 48;
             constexpr int RQ = PFF + 2;
@@ -1331,7 +1365,9 @@ __global__ __launch_bounds__(512, 2) void trunk2_kernel(Trunk2Args a)
                 load_params(b4, s4, i4);
                 const unsigned ey = __builtin_amdgcn_readfirstlane(e_own.y);
                 const int rmask = (ey >> 8) & 15, c_lo = (ey >> 12) & 63, c_hi = (ey >> 18) & 63;
-                char* const wbase = ring + blk * BLOCKB + ((2 * rp) * PW + p) * G::LPIXB + (32 * mh + 4 * cg) * 2;
+                // 8-byte piece (m, cg) of pixel column 16c + p: slot (4 mh + 2 m + (cg >> 1)) ^ (p & 7), half cg & 1
+                char* const wbase = ring + blk * BLOCKB + ((2 * rp) * PW + p) * T2_PIXB + 8 * (cg & 1);
+                const int wslot[2] = {((4 * mh + (cg >> 1)) ^ (p & 7)) << 4, ((4 * mh + 2 + (cg >> 1)) ^ (p & 7)) << 4};
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -1349,13 +1385,13 @@ __global__ __launch_bounds__(512, 2) void trunk2_kernel(Trunk2Args a)
                             o.x = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, half2v));
                             o.y = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, half2v));
                             if (!inside) o = make_uint2(0, 0);   // layer i+1's zero padding
-                            *(uint2*)(wbase + (n * PW + 16 * c) * G::LPIXB + 32 * m) = o;
+                            *(uint2*)(wbase + (n * PW + 16 * c) * T2_PIXB + wslot[m]) = o;
                         }
                     }
             }
             e_own = load_a(min(it + 1, nsteps - 1));
             e_dma = load_a(it + 1 + T2_SLOTS <= nsteps + T2_PAD_STEPS - 1 ? it + 1 + T2_SLOTS : nsteps + T2_PAD_STEPS - 1);
-            if (wave == 0) dma_barrier<2 * CPW>(); else dma_barrier<2 * (CPW - 1)>();
+            if (wave < 2) dma_barrier<2 * CPW>(); else dma_barrier<2 * (CPW - 1)>();
         } else {
             if (work) {
                 f32x4 b4[2], s4[2], i4[2];

@@ -6,6 +6,7 @@ upscale/upscale_processing.py for the hot path only:
     get_frames        :27-37      logging_callback  :40-51     init_worker     :54-73
     apply_model       :258-299    process_model     :302-347   process_tile    :395-477
     upscale_image     :480-542    upscale_frames    :545-601
+    apply_denoise     :350-361    process_denoise   :364-392   (`-m n=K`)
 
 so that the reference's orchestrator (process_file, ffmpeg extract/merge; out of scope here) can
 import these instead of its own.  Differences, all behind the same signatures:
@@ -263,6 +264,67 @@ def process_model(frames_count, model_path, model_file, scale, model_input, mode
     pool.close()
     pool.join()
     collect.finish()
+
+
+DENOISE_GPU = 0        # HIP device of a denoise worker (set per worker by _init_denoise_worker)
+
+
+def denoise_u8(img_bgr, strength, device=None):
+    """cv2.fastNlMeansDenoisingColored(img, None, K, K, 5, 9) on the MI355X (include/uva.h uva_denoise_u8)."""
+    from . import _lib
+    img = np.ascontiguousarray(img_bgr, dtype=np.uint8)
+    if img.ndim != 3 or img.shape[2] != 3:
+        raise ValueError("frame must be u8 [h][w][3]")
+    h, w, _ = img.shape
+    out = np.empty_like(img)
+    _lib.check(_lib.load().uva_denoise_u8(DENOISE_GPU if device is None else int(device), img.ctypes.data, h, w, w * 3,
+                                          out.ctypes.data, w * 3, float(strength), float(strength)))
+    return out
+
+
+def apply_denoise(input_file_name, output_file_name, denoise, remove):
+    """One frame of the `-m n=K` film-grain pass: PNG -> non-local means -> PNG  (reference :350-361).  The
+    reference lets an exception escape (the pool swallows it and the frame is silently missing); here a
+    failure comes back as error items like every other worker function's."""
+    try:
+        img = imread(input_file_name)
+        if img is None:
+            raise RuntimeError("cannot read " + str(input_file_name))
+        imwrite(output_file_name, denoise_u8(img, denoise))
+    except Exception as e:  # noqa: BLE001
+        return [["error", "Denoise failed"], ["error", e]]
+    if remove:
+        os.remove(input_file_name)
+    return [["info", "Processed Denoise: " + output_file_name]]
+
+
+def _init_denoise_worker(gpus):
+    global DENOISE_GPU
+    slot = _worker_slot(0)
+    DENOISE_GPU = gpus[slot % len(gpus)]
+
+
+def process_denoise(frames_count, input_file_tag, denoise, remove=True, gpus=None, workers_per_gpu=4):
+    """Frame work queue of the denoise pass (reference :364-392): one task per existing '<n>.<tag>.png', output
+    '<n>.denoise.png'.  The reference spreads cv2's CPU / OpenCL code over a pool of os.cpu_count() processes;
+    here the arithmetic runs on the GPUs of `gpus` (default: device 0) and the pool's processes only decode,
+    encode and wait, `workers_per_gpu` of them per GPU.  Returns the number of pool processes like the
+    reference (its caller adds it to workers_used, :885)."""
+    frames = range(1, frames_count + 1) if isinstance(frames_count, int) else frames_count
+    gpus = list(gpus) if gpus else [0]
+    _check_gpus(gpus)
+    nproc = len(gpus) * max(1, int(workers_per_gpu))
+    pool = multiprocessing.get_context("spawn").Pool(nproc, initializer=_init_denoise_worker, initargs=(gpus,))
+    collect = _Collector()
+    for frame in frames:
+        src = "%s.%s.png" % (frame, input_file_tag)
+        dst = "%s.denoise.png" % frame
+        if os.path.exists(src):
+            pool.apply_async(apply_denoise, args=(src, dst, denoise, remove), callback=collect)
+    pool.close()
+    pool.join()
+    collect.finish()
+    return nproc
 
 
 def tile_window(tile_size, y, x, height, width, border=TILE_BORDER):
