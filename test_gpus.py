@@ -19,16 +19,16 @@ import time
 
 from upscale_video_amd import ncnn
 from upscale_video_amd.synth import synthetic_frame
-from upscale_video_amd.upscale_processing import init_worker, logging_callback, upscale_image
+from upscale_video_amd.upscale_processing import init_worker, logging_callback, upscale_image, workers_spawned_so_far
 
 RULE = "=" * 36
 DEVICE_KINDS = ("Discrete", "Integrated", "Virtual", "CPU")     # ncnn's gpu_info.type() enumeration
 
 
-def timed_upscale(png, scale, gpus):
+def timed_upscale(png, scale, gpus, workers_used=0):
     """Worker task: one upscale_image call on this worker's net, timed; returns log items."""
     me = mp.current_process()._identity
-    slot = me[0] - 1 if me else 0
+    slot = me[0] - 1 - workers_used if me else 0
     t0 = time.perf_counter()
     log = [["info", "Testing GPU: %s" % gpus[slot]]]
     log.extend(upscale_image(png, None, scale, None, 1, 1, remove=False))
@@ -49,13 +49,14 @@ def list_devices():
 
 def time_pool(gpu_list, scale, runs, png):
     models = os.path.join(os.path.dirname(os.path.realpath(__file__)), "models")
+    used = workers_spawned_so_far()        # 0 + 1 in a fresh process; later pools of a long-lived caller continue the count
     workers = mp.get_context("spawn").Pool(
-        len(gpu_list), init_worker, (gpu_list, 0, models, "x_Compact_Pretrain", scale, "input", "output"))
+        len(gpu_list), init_worker, (gpu_list, used, models, "x_Compact_Pretrain", scale, "input", "output"))
     for line in ("", "Starting test runs", RULE):
         logging.info(line)
     t0 = time.perf_counter()
     for _ in range(runs):
-        workers.apply_async(timed_upscale, (png, scale, gpu_list), callback=logging_callback)
+        workers.apply_async(timed_upscale, (png, scale, gpu_list, used), callback=logging_callback)
     workers.close()
     workers.join()
     elapsed = time.perf_counter() - t0

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Run ON THE MI355X BOX (through gpurun): everything profiles/ holds for one build.
+#   tools/round_profiles.sh r02_c    -> gpurun_out/profiles_<tag>/
+set -u
+TAG=${1:-r02_x}
+REPO=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$REPO/gpurun_out/profiles_$TAG
+mkdir -p "$OUT"
+bash "$REPO/tools/collect_profiles.sh" "$TAG" > "$OUT/collect.log" 2>&1
+cd "$REPO"
+for wl in 4x_compact_1080p 1x_hurrdeblur_1080p chain_1x_2x_1080p 2x_compact_2160p; do
+  python bench.py --workload $wl --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_${wl}.json" 2>> "$OUT/bench.err"
+done
+python bench.py --tile 0 --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_2x_whole_frame.json" 2>> "$OUT/bench.err"
+UVA_TRUNK_FUSION=0 python bench.py --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_unfused_trunk_kernel.json" 2>> "$OUT/bench.err"
+python tools/png_route_bench.py 64 > "$OUT/${TAG}_png_route_bench.txt" 2>&1
+python tools/rawvideo_bench.py 600 > "$OUT/${TAG}_rawvideo_bench.txt" 2>&1
+python test_gpus.py -g 0,0,0,0 -s 2 -r 16 > "$OUT/${TAG}_test_gpus_harness.txt" 2>&1
+rocm-smi --showpower --showclocks > "$OUT/${TAG}_rocm_smi.txt" 2>&1
+ls -la "$OUT"

@@ -21,7 +21,7 @@ def per_launch(sub):
     for name, d in vals.items():
         v = sorted(d.values())
         big = [x for x in v if x > 0.5 * v[-1]]
-        res[name] = statistics.median(big)
+        res[name] = statistics.median(big) if big else 0.0     # a counter that is zero in every launch
     return res
 
 

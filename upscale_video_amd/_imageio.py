@@ -18,10 +18,37 @@ def imread(path):
     from PIL import Image
     try:
         with Image.open(path) as im:
-            rgb = np.asarray(im.convert("RGB"), dtype=np.uint8)
+            im = im.convert("RGB")
+            w, h = im.size
+            # Pillow's raw encoder writes the channels in BGR order itself (in C, without the GIL)
+            return np.frombuffer(im.tobytes("raw", "BGR"), np.uint8).reshape(h, w, 3).copy()
     except Exception:  # noqa: BLE001
         return None
-    return np.ascontiguousarray(rgb[:, :, ::-1])
+
+
+def png_bytes(bgr, level=1):
+    """8-bit RGB PNG of a u8 BGR frame: every scanline with the Sub filter, one zlib stream at `level` with
+    the Z_RLE strategy -- cv2.imwrite's own defaults (IMWRITE_PNG_COMPRESSION 1, IMWRITE_PNG_STRATEGY_RLE; the
+    reference calls it at :288/:519, and OpenCV is not available here).  Pillow's encoder spends more time
+    choosing a filter per row than compressing: a 3840x2160 frame takes 1.3 s there, 0.65 s with this filter
+    and the default strategy, 0.27 s with Z_RLE (and is 10 % smaller).  zlib releases the GIL, so a worker's
+    encode threads run in parallel."""
+    import struct
+    import zlib
+    h, w, _ = bgr.shape
+    flat = bgr[:, :, ::-1].reshape(h, 3 * w)
+    rows = np.empty((h, 1 + 3 * w), np.uint8)
+    rows[:, 0] = 1                                   # filter type 1 (Sub): byte minus the byte one pixel to the left
+    rows[:, 1:4] = flat[:, :3]
+    np.subtract(flat[:, 3:], flat[:, :-3], out=rows[:, 4:])
+
+    deflate = zlib.compressobj(level, zlib.DEFLATED, 15, 9, zlib.Z_RLE)
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) +
+            chunk(b"IDAT", deflate.compress(rows.tobytes()) + deflate.flush()) + chunk(b"IEND", b""))
 
 
 def to_u8(arr):
@@ -36,7 +63,9 @@ def imwrite(path, arr):
     """arr: [h][w][3] BGR, u8 or float (floats are converted like cv2.imwrite does)."""
     if _cv2 is not None:
         return bool(_cv2.imwrite(path, arr))
-    from PIL import Image
     bgr = to_u8(arr)
-    Image.fromarray(np.ascontiguousarray(bgr[:, :, ::-1]), "RGB").save(path, format="PNG", compress_level=1)
+    if bgr.ndim != 3 or bgr.shape[2] != 3:
+        raise ValueError("frame must be [h][w][3]")
+    with open(path, "wb") as f:
+        f.write(png_bytes(bgr))
     return True

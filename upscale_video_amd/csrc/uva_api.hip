@@ -1524,6 +1524,37 @@ int uva_net_debug_trunk_stamps(uva_net* n, unsigned long long* out, int max_tile
         if (tiles) *tiles = pingpong_tail ? per_block : (ca.tiles_per_xcd + grid3 / 8 - 1) / (grid3 / 8);
         return rc3;
     }
+    if (ablate == 5) {
+        // the fused pair kernel: stamps of workgroup 0, both groups (out[16*it + 8*group + k], entry at out[16*niter])
+        if (!ws->d_steps2) { (void)hipFree(d); return fail("no fused-pair schedule for this net"); }
+        Trunk2Args ta;
+        std::memset(&ta, 0, sizeof ta);
+        ta.in_act = ws->act_base[0];
+        ta.out_act = ws->act_base[1];
+        for (int k = 0; k < 2; ++k) { ta.wpk[k] = n->layers[1 + k].wpk; ta.bias[k] = n->layers[1 + k].bias; ta.slope[k] = n->layers[1 + k].slope; }
+        ta.steps = ws->d_steps2; ta.nsteps = ws->d_nsteps2; ta.max_steps = ws->max_steps2; ta.sink = n->d_sink;
+        if (2 * (ws->max_steps2 + 3) + 1 > max_tiles) { (void)hipFree(d); return fail("max_tiles too small"); }
+        int rc5 = launch_trunk2(n, ws, ta);
+        HIP_TRY(hipEventRecord(e0, n->stream));
+        for (int r = 0; r < 50 && !rc5; ++r) rc5 = launch_trunk2(n, ws, ta);
+        HIP_TRY(hipEventRecord(e1, n->stream));
+        ta.dbg = d;
+        if (!rc5) rc5 = launch_trunk2(n, ws, ta);
+        if (!rc5) {
+            HIP_TRY(hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, n->stream));
+            HIP_TRY(hipStreamSynchronize(n->stream));
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+            if (kernel_ms) *kernel_ms = ms / 50;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        (void)hipFree(d);
+        std::vector<int> ns(ws->grid2);
+        HIP_TRY(hipMemcpy(ns.data(), ws->d_nsteps2, ns.size() * sizeof(int), hipMemcpyDeviceToHost));
+        if (tiles) *tiles = ns[0] + 2;
+        return rc5;
+    }
     // bits 8.. of `ablate`: hundreds of timed repetitions (sustained, power-limited state) instead of 10
     const int reps = (ablate >> 8) > 0 ? (ablate >> 8) * 100 : 10;
     ablate &= 0xff;

@@ -1124,9 +1124,10 @@ __global__ __launch_bounds__(512, 2) void trunk_kernel(ConvArgs a)
 //      columns x0 .. x0+29, from ring blocks g % 3 and (g+1) % 3; executed in iteration g+2.
 // ----------------------------------------------------------------------------------------------
 constexpr int T2_SW = 30;                       // output columns per strip
-constexpr int T2_SLOTS = 3;                     // input halo-tile ring (A only: one tile per period)
+constexpr int T2_SLOTS = 4;                     // input halo-tile ring (A only: one tile per period; tile it+1 is complete
+                                                // one barrier before its k-loop, so its first fragments are read early)
 constexpr int T2_RING_ROWS = 12;                // intermediate ring: 3 blocks of 4 rows
-constexpr int T2_PAD_STEPS = 3;                 // dummy entries behind a workgroup's last step (DMA look-ahead)
+constexpr int T2_PAD_STEPS = T2_SLOTS;          // dummy entries behind a workgroup's last step (DMA look-ahead)
 
 struct Trunk2Step {                             // 32 bytes
     // A half: x = input halo origin byte offset (low 32), y = offset bits 32..39 | row mask << 8 (bit r:
@@ -1149,6 +1150,8 @@ struct Trunk2Args {
     const int* nsteps;            // [gridDim.x]
     int max_steps;
     _Float16* sink;
+    unsigned long long* dbg;      // instrumented builds: s_memtime stamps of workgroup 0, [16 * it + 8 * group + {0: k-loop start,
+                                  // 1: k-loop end, 2: roles swapped, 3: epilogue end}], entry time at [16 * niter]
 };
 
 // LDS layout of trunk2_kernel: a pixel is 128 bytes = eight 16-byte slots with NO padding; slot s of the
@@ -1213,6 +1216,7 @@ __global__ __launch_bounds__(512, 2) void trunk2_kernel(Trunk2Args a)
     const int mh = wave & 1;      // which 32 output channels
     const int rp = wave >> 1;     // which row pair of the 4-row block
 
+    const unsigned long long t_entry = UVA_MEMTIME();
     const int nsteps = __builtin_amdgcn_readfirstlane(a.nsteps[blockIdx.x]);
     if (nsteps <= 0) return;
     const Trunk2Step* const steps = a.steps + (size_t)blockIdx.x * (a.max_steps + T2_PAD_STEPS);
@@ -1272,42 +1276,75 @@ __global__ __launch_bounds__(512, 2) void trunk2_kernel(Trunk2Args a)
     uint4 e_own = grp ? make_uint4(0, 0, 0, 0) : load_a(0);
     uint4 e_dma = grp ? make_uint4(0, 0, 0, 0) : load_a(T2_SLOTS);
 
+    // Fragment addressing of one k-loop.  A: halo tile in slot `sl`.  B: 6 ring rows starting at block bblk; the ring
+    // wraps behind row 11, which only the second row pair (rows 2..5 of the window) can cross.  Lane (pixel
+    // p = lane & 15, octet o = lane >> 4) reads slot (4*ch + o) ^ ((p + dx) & 7) of pixel (row 2rp + R, column
+    // 16c + p + dx): the XOR term depends on dx only (16c = 0 mod 8), and the channel half flips bit 6 of an address
+    // whose other terms are multiples of 128.
+    struct Win { unsigned lo[3], hi[3]; };
+    auto window = [&](int sl, int bblk) __attribute__((always_inline)) {
+        const int pq = lane & 15, oq = lane >> 4;
+        const unsigned start = grp ? (unsigned)(T2_SLOTS * SLOTB + bblk * BLOCKB) : (unsigned)(sl * SLOTB);
+        const unsigned wrap = (grp && rp && bblk == 2) ? T2_RING_ROWS * ROWB : 0;
+        const unsigned a0 = start + ((2 * rp) * PW + pq) * T2_PIXB;   // smem itself starts 128-byte aligned (offset 0)
+        Win wn;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            wn.lo[dx] = a0 + ((oq ^ ((pq + dx) & 7)) << 4);
+            wn.hi[dx] = wn.lo[dx] - wrap;
+        }
+        return wn;
+    };
+    auto read_frag = [&](const Win& wn, int f) __attribute__((always_inline)) -> half8 {
+        const int st = f >> 1, c = f & 1;
+        const int R = st & 3, ch = (st >> 2) & 1, dx = st >> 3;
+        const unsigned a = ((R < 2 ? wn.lo[dx] : wn.hi[dx]) ^ (ch ? 64u : 0u)) + (R * PW + dx + 16 * c) * T2_PIXB;
+        return *(const half8*)(smem + a);
+    };
+    // The first PFF fragments of a k-loop are read one phase early, at the end of the group's previous epilogue phase
+    // and in front of the barrier that starts the k-loop -- their LDS latency then falls into the barrier wait instead
+    // of keeping the matrix pipe idle at the top of every k-loop (tools/trunk2_anatomy.py: 2 770 cycles per k-loop
+    // against 144 x 17 = 2 450 of MFMA issue).  The data is there: A's tile it+1 was proven complete by ALL waves one
+    // barrier earlier (4 slots: look-ahead of 4 tiles, the wait below leaves 2 in flight); B's blocks were written by
+    // A two and four phases ago.
+    half8 pre[PFF];
+    if (grp == 0) {
+        const Win w0 = window(0, 0);
+#pragma unroll
+        for (int f = 0; f < PFF; ++f) pre[f] = read_frag(w0, f);
+    } else {
+#pragma unroll
+        for (int f = 0; f < PFF; ++f) pre[f] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+
     const int niter = nsteps + 2;
-    int blk = 0;                       // it % 3: A's input slot and ring block; B reads blocks blk+1, blk+2 (mod 3)
+#ifdef UVA_INSTRUMENT
+    const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && (threadIdx.x & 255) == 0;
+    unsigned long long* const sdbg = a.dbg + 8 * grp;
+    if (stamp && grp == 0) a.dbg[16 * niter] = t_entry;
+#else
+    constexpr bool stamp = false;
+    unsigned long long* const sdbg = nullptr;
+    (void)t_entry;
+#endif
+    int blk = 0;                       // it % 3: A's ring block; B reads blocks blk+1, blk+2 (mod 3)
+    int sl = 0;                        // it % 4: A's input slot
     for (int it = 0; it < niter; ++it) {
         const bool work = grp ? it >= 2 : it < nsteps;
         f32x4 acc[2][2][2];            // [output row n][column half c][16-channel block m]
+        if (stamp) sdbg[16 * it + 0] = __builtin_amdgcn_s_memtime();
         if (work) {
             // ---- k-loop phase: MFMAs and their fragment reads, nothing else (see trunk_kernel) ----------
             __builtin_amdgcn_s_setprio(2);
-            // A: halo tile in slot blk.  B: 6 ring rows starting at block (it - 2) % 3 = (blk + 1) % 3; the ring
-            // wraps behind row 11, which only the second row pair (rows 2..5 of the window) can cross.
-            const int bblk = blk + 1 >= 3 ? blk - 2 : blk + 1;
-            const char* const win = grp ? ring + bblk * BLOCKB : smem + blk * SLOTB;
-            // lane (pixel p = lane & 15, octet o = lane >> 4) reads slot (4*ch + o) ^ ((p + dx) & 7) of pixel
-            // (row 2rp + R, column 16c + p + dx): the XOR term depends on dx only (16c = 0 mod 8), and the channel
-            // half flips bit 6 of an address whose other terms are multiples of 128
-            const int pq = lane & 15, oq = lane >> 4;
-            const unsigned wrap = (grp && rp && bblk == 2) ? T2_RING_ROWS * ROWB : 0;
-            const unsigned a0 = (unsigned)(win - smem) + ((2 * rp) * PW + pq) * T2_PIXB;   // smem itself starts 128-byte aligned (offset 0)
-            unsigned blo[3], bhi[3];
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                blo[dx] = a0 + ((oq ^ ((pq + dx) & 7)) << 4);
-                bhi[dx] = blo[dx] - wrap;
-            }
-            auto read_b = [&](int f) __attribute__((always_inline)) -> half8 {
-                const int st = f >> 1, c = f & 1;
-                const int R = st & 3, ch = (st >> 2) & 1, dx = st >> 3;
-                const unsigned a = ((R < 2 ? blo[dx] : bhi[dx]) ^ (ch ? 64u : 0u)) + (R * PW + dx + 16 * c) * T2_PIXB;
-                return *(const half8*)(smem + a);
-            };
+            const int bblk = blk + 1 >= 3 ? blk - 2 : blk + 1;        // B: block (it - 2) % 3
+            const Win wn = window(sl, bblk);
+            auto read_b = [&](int f) __attribute__((always_inline)) -> half8 { return read_frag(wn, f); };
             constexpr int NSTEP = 24, NFRAG = 48;
             constexpr int RQ = PFF + 2;
             half8 bq[RQ];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int f = 0; f < PFF; ++f) bq[f] = read_b(f);
+            for (int f = 0; f < PFF; ++f) bq[f] = pre[f];
 #pragma unroll
             for (int st = 0; st < NSTEP; ++st) {
 #pragma unroll
@@ -1327,7 +1364,6 @@ __global__ __launch_bounds__(512, 2) void trunk2_kernel(Trunk2Args a)
                     }
                 }
             }
-            __builtin_amdgcn_sched_group_barrier(0x100, PFF, 0);
 #pragma unroll
             for (int st = 0; st < NSTEP; ++st) {
                 const int R = st & 3;
@@ -1340,7 +1376,9 @@ __global__ __launch_bounds__(512, 2) void trunk2_kernel(Trunk2Args a)
             }
             __builtin_amdgcn_s_setprio(0);
         }
+        if (stamp) sdbg[16 * it + 1] = __builtin_amdgcn_s_memtime();
         group_barrier();               // roles swap: every wave is done reading slot / blocks of this phase
+        if (stamp) sdbg[16 * it + 2] = __builtin_amdgcn_s_memtime();
         // ---- epilogue phase ---------------------------------------------------------------------------
         const int lane_o = opaque(lane);
         const int cg = lane_o >> 4, p = lane_o & 15;
@@ -1359,20 +1397,24 @@ __global__ __launch_bounds__(512, 2) void trunk2_kernel(Trunk2Args a)
             // input tile of step it + 3 -> the slot this k-loop has just released; the pieces issued one and
             // two epilogues ago (steps it + 2, it + 1) are older, so "at most two tiles' pieces outstanding"
             // at the closing barrier proves step it + 1's tile
-            issue_tile(e_dma, blk);
+            issue_tile(e_dma, sl);
             if (work) {
                 f32x4 b4[2], s4[2], i4[2];
                 load_params(b4, s4, i4);
                 const unsigned ey = __builtin_amdgcn_readfirstlane(e_own.y);
                 const int rmask = (ey >> 8) & 15, c_lo = (ey >> 12) & 63, c_hi = (ey >> 18) & 63;
-                // 8-byte piece (m, cg) of pixel column 16c + p: slot (4 mh + 2 m + (cg >> 1)) ^ (p & 7), half cg & 1
-                char* const wbase = ring + blk * BLOCKB + ((2 * rp) * PW + p) * T2_PIXB + 8 * (cg & 1);
-                const int wslot[2] = {((4 * mh + (cg >> 1)) ^ (p & 7)) << 4, ((4 * mh + 2 + (cg >> 1)) ^ (p & 7)) << 4};
+                // After the lane exchange (see trunk_kernel's epilogue) lane (p, cg) holds 8 consecutive channels =
+                // one 16-byte slot of pixel column 16c + p: logical slot 4 mh + {0, 2, 1, 3}[cg], stored at that
+                // slot ^ (p & 7).  ds_write_b128 goes out in groups of 8 consecutive lanes = 8 pixels with 8
+                // different slots: conflict-free (8-byte pieces of 16 pixels were 2-way conflicting).
+                char* const wbase = ring + blk * BLOCKB + ((2 * rp) * PW + p) * T2_PIXB +
+                                    (((4 * mh + 2 * (cg & 1) + (cg >> 1)) ^ (p & 7)) << 4);
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
                         const bool inside = ((rmask >> (2 * rp + n)) & 1) && 16 * c + p >= c_lo && 16 * c + p < c_hi;
+                        unsigned o[2][2];
 #pragma unroll
                         for (int m = 0; m < 2; ++m) {
                             f32x4 v;
@@ -1381,16 +1423,24 @@ __global__ __launch_bounds__(512, 2) void trunk2_kernel(Trunk2Args a)
                                 const float xv = acc[n][c][m][j] + b4[m][j];
                                 v[j] = __builtin_amdgcn_fmed3f(xv, xv * s4[m][j], i4[m][j]);
                             }
-                            uint2 o;
-                            o.x = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, half2v));
-                            o.y = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, half2v));
-                            if (!inside) o = make_uint2(0, 0);   // layer i+1's zero padding
-                            *(uint2*)(wbase + (n * PW + 16 * c) * T2_PIXB + wslot[m]) = o;
+                            o[m][0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, half2v));
+                            o[m][1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, half2v));
                         }
+                        const auto x = __builtin_amdgcn_permlane16_swap(o[0][0], o[1][0], false, false);
+                        const auto y = __builtin_amdgcn_permlane16_swap(o[0][1], o[1][1], false, false);
+                        uint4 val = make_uint4(x[0], y[0], x[1], y[1]);
+                        if (!inside) val = make_uint4(0, 0, 0, 0);   // layer i+1's zero padding
+                        *(uint4*)(wbase + (n * PW + 16 * c) * T2_PIXB) = val;
                     }
             }
             e_own = load_a(min(it + 1, nsteps - 1));
             e_dma = load_a(it + 1 + T2_SLOTS <= nsteps + T2_PAD_STEPS - 1 ? it + 1 + T2_SLOTS : nsteps + T2_PAD_STEPS - 1);
+            {   // unconditionally (a value kept across iterations would hold 24 registers through the k-loop)
+                const Win wnext = window(sl + 1 == T2_SLOTS ? 0 : sl + 1, 0);
+#pragma unroll
+                for (int f = 0; f < PFF; ++f) pre[f] = read_frag(wnext, f);
+            }
+            if (stamp) sdbg[16 * it + 3] = __builtin_amdgcn_s_memtime();
             if (wave < 2) dma_barrier<2 * CPW>(); else dma_barrier<2 * (CPW - 1)>();
         } else {
             if (work) {
@@ -1428,9 +1478,17 @@ __global__ __launch_bounds__(512, 2) void trunk2_kernel(Trunk2Args a)
                     }
             }
             e_own = load_b(max(it - 1, 0));      // step (it + 1) - 2
+            {
+                const int bnext = blk + 2 >= 3 ? blk - 1 : blk + 2;       // block ((it + 1) - 2) % 3
+                const Win wnext = window(0, bnext);
+#pragma unroll
+                for (int f = 0; f < PFF; ++f) pre[f] = read_frag(wnext, f);
+            }
+            if (stamp) sdbg[16 * it + 3] = __builtin_amdgcn_s_memtime();
             group_barrier();
         }
         blk = blk + 1 == 3 ? 0 : blk + 1;
+        sl = sl + 1 == T2_SLOTS ? 0 : sl + 1;
     }
     if (grp == 0) group_barrier();
     // nothing of the dummy look-ahead tiles may land after the workgroup's LDS is released

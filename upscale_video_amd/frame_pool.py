@@ -31,8 +31,15 @@ from concurrent.futures import ThreadPoolExecutor
 from ._imageio import imread, imwrite
 
 PIPE_DEPTH = 3            # include/uva.h: frames in flight per net on the pipelined route
-DEFAULT_DECODE_THREADS = 4
-DEFAULT_ENCODE_THREADS = 12
+DEFAULT_DECODE_THREADS = int(os.environ.get("UVA_DECODE_THREADS", "4"))
+DEFAULT_ENCODE_THREADS = int(os.environ.get("UVA_ENCODE_THREADS", "0"))     # 0: the host's cores shared out over the workers
+
+
+def default_encode_threads(n_workers, decode_threads):
+    """PNG encode of a 4K result is ~100x the GPU time of the frame: give every worker its share of the host's
+    cores (minus its decode threads and its GPU thread), between 4 and 48 threads."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
+    return max(4, min(48, cores // max(1, n_workers) - decode_threads - 1))
 DEFAULT_NET_FACTORY = "upscale_video_amd.frame_pool:load_reference_net"
 
 
@@ -213,6 +220,9 @@ class FramePool:
         if not gpus:
             raise ValueError("FramePool needs at least one -g entry")
         self.gpus = list(gpus)
+        if not encode_threads:
+            encode_threads = default_encode_threads(len(self.gpus), decode_threads)
+        self.decode_threads, self.encode_threads = decode_threads, encode_threads
         ctx = multiprocessing.get_context("spawn")     # the reference's start method (:321, :565)
         self.task_q = ctx.Queue()
         self.result_q = ctx.Queue()

@@ -78,6 +78,14 @@ def _worker_slot(workers_used):
     return (ident[0] - 1 - workers_used) if ident else 0
 
 
+def workers_spawned_so_far():
+    """How many pool identities this process has handed out: the `workers_used` a caller must pass to the
+    reference-shaped route so that the next pool's workers map onto entries 0.. of its -g list (the reference
+    threads the count by hand, :880-948; its own harness passes 0 because it starts from a fresh process,
+    test_gpus.py:79-84).  Asking costs one identity, which is included in the answer."""
+    return multiprocessing.get_context("spawn").Process()._identity[0]
+
+
 def init_worker(gpus, workers_used, model_path, model_file, scale, model_input, model_output):
     """Pool initializer: position of this worker in the pool picks its entry of the -g list
     (duplicates allowed: '0,0,1' = two workers on GPU 0), then the net is built and loaded from
