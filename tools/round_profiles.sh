@@ -13,8 +13,15 @@ for wl in 4x_compact_1080p 1x_hurrdeblur_1080p chain_1x_2x_1080p 2x_compact_2160
 done
 python bench.py --tile 0 --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_2x_whole_frame.json" 2>> "$OUT/bench.err"
 UVA_TRUNK_FUSION=0 python bench.py --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_unfused_trunk_kernel.json" 2>> "$OUT/bench.err"
-python tools/png_route_bench.py 64 > "$OUT/${TAG}_png_route_bench.txt" 2>&1
+python tools/png_route_bench.py 384 > "$OUT/${TAG}_png_route_bench.txt" 2>&1
 python tools/rawvideo_bench.py 600 > "$OUT/${TAG}_rawvideo_bench.txt" 2>&1
 python test_gpus.py -g 0,0,0,0 -s 2 -r 16 > "$OUT/${TAG}_test_gpus_harness.txt" 2>&1
-rocm-smi --showpower --showclocks > "$OUT/${TAG}_rocm_smi.txt" 2>&1
+# package power and shader clock while the bench runs (sustained state)
+python bench.py --steps 6000 --warmup 50 --no-cpu-baseline > "$OUT/power_bench.json" 2>/dev/null &
+sleep 6
+for i in 1 2 3 4 5 6; do rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power|sclk"; sleep 1; done > "$OUT/${TAG}_power_during_bench.txt"
+wait
+sleep 8
+python -c "import json; d=json.load(open('$OUT/power_bench.json')); print('bench --steps 6000:', d['value'], 'fps, trunk', d['config']['kernel_ms_per_frame']['trunk'], 'ms/frame, frac', d['roofline']['frac'])" >> "$OUT/${TAG}_power_during_bench.txt" 2>&1
+UVA_LIB_PATH=$REPO/upscale_video_amd/libuva_instr.so python tools/trunk2_anatomy.py > "$OUT/${TAG}_trunk2_anatomy.txt" 2>&1
 ls -la "$OUT"
