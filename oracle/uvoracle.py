@@ -70,8 +70,29 @@ def lib():
     return _lib
 
 
+def cpu_quota():
+    """CPUs this process may actually use: the affinity mask capped by the container's CFS quota (cgroup v2
+    cpu.max / v1 cpu.cfs_quota_us).  The GPU boxes show 256 CPUs and grant 16."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:  # noqa: BLE001
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:  # noqa: BLE001
+            pass
+    return n
+
+
 def max_threads():
-    return lib().uvo_max_threads()
+    """OpenMP threads for the oracle: what the host grants, not what it shows"""
+    return max(1, min(lib().uvo_max_threads(), cpu_quota()))
 
 
 def _ptr(a):

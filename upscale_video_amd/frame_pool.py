@@ -38,8 +38,27 @@ DEFAULT_ENCODE_THREADS = int(os.environ.get("UVA_ENCODE_THREADS", "0"))     # 0:
 def default_encode_threads(n_workers, decode_threads):
     """PNG encode of a 4K result is ~100x the GPU time of the frame: give every worker its share of the host's
     cores (minus its decode threads and its GPU thread), between 4 and 48 threads."""
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
+    cores = usable_cpus()
     return max(4, min(48, cores // max(1, n_workers) - decode_threads - 1))
+
+
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask capped by the container's CFS quota (cgroup v2
+    cpu.max / v1 cpu.cfs_quota_us) -- a box that shows 256 CPUs may grant 16."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:  # noqa: BLE001
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:  # noqa: BLE001
+            pass
+    return n
 DEFAULT_NET_FACTORY = "upscale_video_amd.frame_pool:load_reference_net"
 
 
