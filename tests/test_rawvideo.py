@@ -70,6 +70,18 @@ def test_max_frames_and_writer_errors():
         rawvideo.stream(io.BytesIO(data), Broken(), h, w, [(FakeNet(2), 0)], alloc=lambda s: np.empty(s, np.uint8))
 
 
+def test_scale_1_without_the_anime_pass_copies_frames_through(tmp_path):
+    """upscale_video.py with -s 1 and no -m a runs no network at all (frames are renamed, :924-929)."""
+    h, w = 4, 6
+    data = b"".join(f.tobytes() for f in _frames(5, h, w))
+    src, dst = tmp_path / "in.bgr24", tmp_path / "out.bgr24"
+    src.write_bytes(data)
+    assert rawvideo.main(["-i", str(src), "-o", str(dst), "-W", str(w), "-H", str(h), "-s", "1"]) == 0
+    assert dst.read_bytes() == data
+    assert rawvideo.main(["-i", str(src), "-o", str(dst), "-W", str(w), "-H", str(h), "-s", "1", "--frames", "2"]) == 0
+    assert dst.read_bytes() == data[:2 * h * w * 3]
+
+
 def test_cli_rejects_models_that_are_not_on_the_path(capsys):
     with pytest.raises(SystemExit):
         rawvideo.main(["-W", "8", "-H", "8", "-m", "r"])

@@ -20,7 +20,7 @@ def wall(cmd, shell=False):
     return time.perf_counter() - t0
 
 
-for args in (["-s", "2"], ["-s", "2", "-m", "a"], ["-s", "4"], ["-s", "1"]):
+for args in (["-s", "2"], ["-s", "2", "-m", "a"], ["-s", "4"], ["-s", "1", "-m", "a"]):
     t1 = wall(base + args + ["-i", src, "-o", "/dev/null", "--frames", "1"])
     tn = wall(base + args + ["-i", src, "-o", "/dev/null"])
     print(f"{' '.join(args):12s} file -> /dev/null : {N} frames in {tn:6.2f} s (start-up {t1:5.2f} s) = {(N - 1) / (tn - t1):7.1f} frames/s")

@@ -1011,6 +1011,23 @@ void nlm_weight_table(float h, int cn, std::vector<int>& table)
     }
 }
 
+void denoise_release_all()
+{
+    std::lock_guard<std::mutex> lk(g_denoise_mu);
+    for (int d = 0; d < 16; ++d) {
+        DenoiseCtx& c = g_denoise[d];
+        if (!c.stream && !c.d_in && !c.d_table[0] && !c.d_table[1]) continue;
+        (void)hipSetDevice(d);
+        if (c.stream) (void)hipStreamSynchronize(c.stream);
+        for (uint8_t* p : {c.d_in, c.d_out, c.d_l, c.d_l2, c.d_ab, c.d_ab2})
+            if (p) (void)hipFree(p);
+        for (int* t : c.d_table)
+            if (t) (void)hipFree(t);
+        if (c.stream) (void)hipStreamDestroy(c.stream);
+        c = DenoiseCtx();
+    }
+}
+
 int denoise_ctx(int device, size_t px, DenoiseCtx** out)
 {
     int count = 0;
@@ -1159,8 +1176,11 @@ int uva_get_gpu_pci_bus_id(int index, char* out, size_t out_len)
 
 void uva_destroy_gpu_instance(void)
 {
-    std::lock_guard<std::mutex> lk(g_nets_mu);
-    for (uva_net* n : g_nets) n->free_device();
+    {
+        std::lock_guard<std::mutex> lk(g_nets_mu);
+        for (uva_net* n : g_nets) n->free_device();
+    }
+    denoise_release_all();
 }
 
 uva_net* uva_net_create(void)

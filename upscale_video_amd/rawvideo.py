@@ -154,6 +154,19 @@ def stream(fin, fout, h, w, nets_tiles, alloc=None, max_frames=None):
     return written
 
 
+def copy_through(fin, fout, h, w, max_frames=None):
+    """`-s 1` without `-m a`: the reference renames the frames, nothing is computed (:924-929)."""
+    buf = bytearray(h * w * 3)
+    n = 0
+    while max_frames is None or n < max_frames:
+        if not read_exact(fin, memoryview(buf)):
+            break
+        fout.write(buf)
+        n += 1
+    fout.flush()
+    return n
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
     ap.add_argument("-i", "--input", default="-", help="bgr24 rawvideo file, '-' = stdin")
@@ -173,14 +186,21 @@ def main(argv=None):
     for m in models:
         if m != "a":
             ap.error("only -m a is available on the MI355X path (r: weights missing upstream; n: OpenCV NLM, host only)")
+    # upscale_video.py: `-m a` runs the 1x HurrDeblur pass (process_model, :888-909), `-s 2|4` the Compact net
+    # (upscale_frames, :930-944), and `-s 1` performs NO network pass of its own: its frames are only renamed
+    # (:924-929).  So `-s 1` alone copies frames through, `-s 1 -m a` is the HurrDeblur pass alone.
     nets = []
-    if "a" in models and a.scale != 1:
+    if "a" in models:
         nets.append((load_net(MODEL_FILES[1], a.gpu, a.model_path), 0))          # apply_model: whole frame
-    nets.append((load_net(MODEL_FILES[a.scale], a.gpu, a.model_path), 0 if a.scale == 1 else a.tile))
+    if a.scale != 1:
+        nets.append((load_net(MODEL_FILES[a.scale], a.gpu, a.model_path), a.tile))
     fin = sys.stdin.buffer if a.input == "-" else open(a.input, "rb")
     fout = sys.stdout.buffer if a.output == "-" else open(a.output, "wb")
     try:
-        n = stream(fin, fout, a.height, a.width, nets, max_frames=a.frames)
+        if nets:
+            n = stream(fin, fout, a.height, a.width, nets, max_frames=a.frames)
+        else:
+            n = copy_through(fin, fout, a.height, a.width, a.frames)
     finally:
         if fin is not sys.stdin.buffer:
             fin.close()
