@@ -39,20 +39,25 @@ def test_config1_png_to_png_256(tmp_path, oracle, oracle_models, uva, monkeypatc
     assert items[0][0] == "error"
 
 
-def test_frame_queue_two_workers_one_gpu(tmp_path, oracle, oracle_models, monkeypatch):
+@pytest.mark.parametrize("persistent", [True, False])
+def test_frame_queue_two_workers_one_gpu(tmp_path, oracle, oracle_models, monkeypatch, persistent):
     """process_model + upscale_frames: '-g 0,0' = two spawned workers sharing GPU 0
-    (README.md:45-61), tasks only for existing inputs, inputs deleted after outputs exist."""
+    (README.md:45-61), tasks only for existing inputs, inputs deleted after outputs exist -- on the
+    persistent FramePool workers and on the reference-shaped route (a fresh spawn Pool per call, pool
+    identities offset by `workers_used`)."""
     from upscale_video_amd import upscale_processing as up
     from upscale_video_amd import _imageio
     monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(up, "PERSISTENT_WORKERS", persistent)
     frames = {}
     for n in (1, 2, 3, 5):
         frames[n] = oracle.synthetic_frame(24, 40, seed=n)
         _imageio.imwrite(f"{n}.extract.png", frames[n])
     gpus = [0, 0]
+    used = 0 if persistent else up.workers_spawned_so_far()     # a fresh process would pass 0 (reference :880)
     up.process_model(5, MODELS, "x_HurrDeblur_SubCompact_nf24-nc8_244k_net_g", 1, "input", "output",
-                     "extract", "anime", gpus, 0, remove=True)
-    workers_used = len(gpus)
+                     "extract", "anime", gpus, used, remove=True)
+    workers_used = used + len(gpus) if persistent else up.workers_spawned_so_far()
     for n in frames:
         assert os.path.exists(f"{n}.anime.png") and not os.path.exists(f"{n}.extract.png")
     assert not os.path.exists("4.anime.png")
@@ -64,3 +69,4 @@ def test_frame_queue_two_workers_one_gpu(tmp_path, oracle, oracle_models, monkey
         assert out is not None and out.shape == (48, 80, 3)
         assert np.abs(out.astype(int) - want.astype(int)).max() <= 3 and psnr_u8(out, want) >= 48
         assert not os.path.exists(f"{n}.anime.png")
+    up.shutdown_workers()

@@ -430,6 +430,20 @@ int launch_trunk2(uva_net* n, const Workspace* ws, const Trunk2Args& a)
     return 0;
 }
 
+// two trunk layers of the 24-feature net per launch (pair24_kernel), two persistent workgroups per CU
+int launch_pair24(uva_net* n, const ConvArgs& a)
+{
+    const size_t lds = pair24_lds_bytes();
+    if (!n->attr_set[9]) {
+        HIP_TRY(hipFuncSetAttribute((const void*)pair24_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        n->attr_set[9] = true;
+    }
+    const int grid = std::max(8, (n->ncu / 8) * 8) * 2;
+    hipLaunchKernelGGL(pair24_kernel, dim3(grid), dim3(256), lds, n->stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_head(uva_net* n, bool f32, const HeadArgs& a)
 {
     const dim3 grid(a.ntiles), block(256);
@@ -787,6 +801,19 @@ int run_graph(uva_net* n, Workspace* ws, bool f32, const void* src, size_t src_s
         ca.bias = n->layers[i].bias;
         ca.slope = n->layers[i].slope;
         ca.reverse = i & 1;   // layer 1 walks backwards over what the head wrote last, layer 2 forwards, ...
+        if (n->fuse_pairs && g.nf == 24 && i + 1 < nconv - 1 && (stop_after < 0 || i + 1 <= stop_after)) {
+            ca.wpk2 = n->layers[i + 1].wpk;
+            ca.bias2 = n->layers[i + 1].bias;
+            ca.slope2 = n->layers[i + 1].slope;
+            ca.ntiles = ws->ntiles;
+            ca.tiles_per_xcd = (ws->ntiles + 7) / 8;
+            if (launch_pair24(n, ca)) return 1;
+            ++ev.ntrunk;
+            ++i;
+            cur ^= 1;
+            n->last_act_buf = cur;
+            continue;
+        }
         if (launch_trunk(n, ws, ca)) return 1;
         ++ev.ntrunk;
         cur ^= 1;
@@ -1543,6 +1570,33 @@ int uva_net_debug_trunk_stamps(uva_net* n, unsigned long long* out, int max_tile
         const bool pingpong_tail = n->g.nf == 64 && (n->g.scale == 2 || n->g.scale == 4);   // 4-row tiles, 2 groups
         if (tiles) *tiles = pingpong_tail ? per_block : (ca.tiles_per_xcd + grid3 / 8 - 1) / (grid3 / 8);
         return rc3;
+    }
+    if (ablate == 6) {
+        // pair24_kernel (two 24-feature trunk layers): out[8*it + {0 top, 1 tile landed, 2 stage A done, 3 intermediate
+        // complete, 4 stage B k-loop done, 5 stores issued}] of workgroup 0 / wave 0
+        if (n->g.nf != 24) { (void)hipFree(d); return fail("pair24 stamps need the 24-feature net"); }
+        ca.wpk2 = n->layers[2].wpk; ca.bias2 = n->layers[2].bias; ca.slope2 = n->layers[2].slope;
+        ca.ntiles = ws->ntiles; ca.tiles_per_xcd = (ws->ntiles + 7) / 8;
+        ca.dbg = nullptr;
+        int rc6 = launch_pair24(n, ca);
+        HIP_TRY(hipEventRecord(e0, n->stream));
+        for (int r = 0; r < 50 && !rc6; ++r) rc6 = launch_pair24(n, ca);
+        HIP_TRY(hipEventRecord(e1, n->stream));
+        ca.dbg = d;
+        if (!rc6) rc6 = launch_pair24(n, ca);
+        if (!rc6) {
+            HIP_TRY(hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, n->stream));
+            HIP_TRY(hipStreamSynchronize(n->stream));
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+            if (kernel_ms) *kernel_ms = ms / 50;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        (void)hipFree(d);
+        const int grid6 = std::max(8, (n->ncu / 8) * 8) * 2;
+        if (tiles) *tiles = (ca.tiles_per_xcd + grid6 / 8 - 1) / (grid6 / 8);
+        return rc6;
     }
     if (ablate == 5) {
         // the fused pair kernel: stamps of workgroup 0, both groups (out[16*it + 8*group + k], entry at out[16*niter])

@@ -133,6 +133,9 @@ struct ConvArgs {
     const uint4* sched4;          // trunk_kernel / tail_kernel: per 4-row work tile, built by the host per geometry:
                                   // x = halo origin byte offset (low 32 bits), y = offset bits 32..39 | plane << 8,
                                   // z = row pitch in bytes, w = valid columns | valid rows << 6 | tx << 9 | ty << 17
+    const half8* wpk2;            // pair24_kernel: the second layer of the pair
+    const float* bias2;
+    const float* slope2;
     int reverse;                  // walk the tiles last-to-first: consecutive layers alternate direction so
                                   // that a layer starts on what the previous one wrote last, i.e. on what is
                                   // still in the 256 MB Infinity Cache
@@ -685,6 +688,295 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a)
         cur = cur + 1 == NBUF ? 0 : cur + 1;
     }
     // LDS-DMA of the re-fetched look-ahead tiles must not outlive the workgroup's LDS allocation
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ----------------------------------------------------------------------------------------------
+// pair24_kernel: TWO consecutive trunk layers of the 24-feature net (1x HurrDeblur SubCompact, 24 -> 24 -> 24,
+// each + bias + PReLU) per launch.  That net is HBM-bound layer by layer (96 B of activations per pixel and layer
+// against 10 kFLOP): here the intermediate image of a pair lives only in LDS, so a pair moves what one layer
+// moved.  conv3x3_kernel's scheme (persistent 4-wave workgroups, two per CU, 8x32 output tiles, weights of BOTH
+// layers stationary in registers, halo tiles by LDS-DMA, XCD-contiguous tile ranges), with a 2-D tile pair: the
+// first layer is computed on the 10x34 halo of the output tile from a 12x36 input tile (+33 % MFMA work on that
+// layer -- irrelevant for a memory-bound net, unlike for the 64-feature one, see trunk2_kernel).
+//   stage A: 11 fragments of 32 pixels -- rows 0..9 x columns 0..31 of the intermediate tile plus one fragment
+//            for its columns 32, 33 -- three per wave; bias + PReLU, pixels outside the plane written as ZERO (they
+//            are the second layer's padding), fp16 into the LDS intermediate tile (48 B per pixel);
+//   stage B: conv3x3_kernel's k-loop on that tile, output through the LDS transpose of store_trunk_rows.
+// ----------------------------------------------------------------------------------------------
+constexpr int P24_XH = TH + 4, P24_XW = TW + 4;                     // input halo tile of a pair: 12 x 36 pixels
+constexpr int P24_PIXB = 48;                                        // 24 channels fp16, no padding (HBM and LDS)
+constexpr int P24_PIECES = (P24_XH * P24_XW * 3 + 63) / 64;         // 1296 sixteen-byte slots -> 21 pieces
+constexpr int P24_CPW = (P24_PIECES + 3) / 4;                       // 6 per wave (24 issued, the last 3 re-fetch)
+constexpr int P24_SLOTB = 4 * P24_CPW * 1024;
+constexpr int P24_INTERB = PH * PW * P24_PIXB;                      // 10 x 34 intermediate pixels
+constexpr int P24_NBUF = 2;
+constexpr int pair24_lds_bytes() { return P24_NBUF * P24_SLOTB + P24_INTERB + 2 * PARAM_LDS + PLANE_LDS; }
+static_assert(2 * pair24_lds_bytes() <= 160 * 1024, "two pair24 workgroups per CU");
+static_assert(StageGeo<24>::BYTES <= P24_CPW * 1024, "output staging must fit a wave's DMA region");
+
+__device__ __forceinline__ int p24_piece_const(int i, int wave, int lane)
+{
+    const int q = (wave * P24_CPW + i) * 64 + lane;
+    int p = q / 3;
+    const int s = q - p * 3;
+    if (p >= P24_XH * P24_XW) p = P24_XH * P24_XW - 1;      // tail of the last pieces: any valid address
+    const int r = p / P24_XW, cc = p - r * P24_XW;
+    return (r << 16) | (cc * P24_PIXB + s * 16);
+}
+
+__global__ __launch_bounds__(256, 2) void pair24_kernel(ConvArgs a)
+{
+    constexpr int NF = 24, KS = 14, SPP = 3, KO = 27, PF = 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = lds_offset(smem);
+    char* const inter = smem + P24_NBUF * P24_SLOTB;
+    float* const prm = (float*)(inter + P24_INTERB);          // per layer: bias[64], slope[64], med3 selector[64]
+    PlaneDesc* planes_lds = (PlaneDesc*)((char*)prm + 2 * PARAM_LDS);
+    int* tile_begin_lds = (int*)((char*)planes_lds + MAX_PLANES * 64);
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5;
+    const int px = lane & 31;
+
+    const int g8 = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7;
+    const int slot = blockIdx.x >> 3;
+    const int t_first = xcd * a.tiles_per_xcd + slot;
+    const int t_lim = min((xcd + 1) * a.tiles_per_xcd, a.ntiles);
+    if (t_first >= t_lim) return;
+    const int niter = (t_lim - t_first + g8 - 1) / g8;
+
+    if (threadIdx.x < 64) {
+        const int c = threadIdx.x;
+        for (int l = 0; l < 2; ++l) {
+            const float b = c < 32 ? (l ? a.bias2 : a.bias)[c] : 0.f;
+            const float sl = c < 32 ? (l ? a.slope2 : a.slope)[c] : 0.f;
+            prm[l * 192 + c] = b;
+            prm[l * 192 + 64 + c] = sl;
+            prm[l * 192 + 128 + c] = sl <= 1.f ? __builtin_inff() : -__builtin_inff();
+        }
+        tile_begin_lds[c] = c < a.nplanes ? a.planes[c].tile_begin : 0x7fffffff;
+    }
+    for (int i = threadIdx.x; i < a.nplanes * 16; i += 256) ((int*)planes_lds)[i] = ((const int*)a.planes)[i];
+
+    // both layers' weights, resident in registers for the whole kernel (KS k-steps of 16, one 32-row block each)
+    half8 wA[KS], wB[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { wA[ks] = a.wpk[ks * 64 + lane]; wB[ks] = a.wpk2[ks * 64 + lane]; }
+
+    int dma_pc[P24_CPW];
+#pragma unroll
+    for (int i = 0; i < P24_CPW; ++i) dma_pc[i] = p24_piece_const(i, wave, lane);
+
+    __syncthreads();
+    PlaneTable pt;
+    pt.pl = planes_lds;
+    pt.tile_begin = tile_begin_lds;
+    pt.nplanes = a.nplanes;
+
+    auto tile_of = [&](int i) __attribute__((always_inline)) {
+        const int t = t_first + i * g8;
+        return a.reverse ? a.ntiles - 1 - t : t;
+    };
+    // halo origin of a pair's input tile: input pixel (ty*8 - 2, tx*32 - 2) = array position (ty*8 - 1, tx*32 - 1);
+    // the activation buffers carry a guard in front of plane 0 and behind the last plane
+    auto issue_tile = [&](const TileId& id, int buf) __attribute__((always_inline)) {
+        const PlaneDesc& pl = planes_lds[id.plane];
+        const long long pitch = __builtin_amdgcn_readfirstlane(pl.pitch);
+        const char* tb = (const char*)a.in_act +
+                         ((long long)pl.act_off + (long long)(id.ty * TH - 1) * pitch + (id.tx * TW - 1)) * P24_PIXB;
+        tb = uniform_ptr(tb);
+        const int pitchb = (int)pitch * P24_PIXB;
+#pragma unroll
+        for (int i = 0; i < P24_CPW; ++i) {
+            const unsigned off = (unsigned)(dma_pc[i] >> 16) * (unsigned)pitchb + (unsigned)(dma_pc[i] & 0xffff);
+            glds16(tb + off, lds0 + buf * P24_SLOTB + (wave * P24_CPW + i) * 1024);
+        }
+    };
+    TileId next = pt.decode(tile_of(0), lane);
+    issue_tile(next, 0);
+    int cur = 0;
+
+    // accumulator chains start from C = 0; the biases are added in the epilogues (in registers they would be 32
+    // more loop-carried VGPRs next to the 112 of the two weight sets)
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+
+    // K octet ko = 2ks + half: tap ko / 3, channel octet ko % 3 (ko = 27 exists only as zero weights)
+    auto tap_off = [&](int ks, int rowpix) __attribute__((always_inline)) -> int {
+        const int koA = 2 * ks, koB = (2 * ks + 1 < KO) ? 2 * ks + 1 : 2 * ks;
+        const int tA = koA / SPP, tB = koB / SPP;
+        const int offA = ((tA / 3) * rowpix + (tA % 3)) * P24_PIXB + (koA % SPP) * 16;
+        const int offB = ((tB / 3) * rowpix + (tB % 3)) * P24_PIXB + (koB % SPP) * 16;
+        return half ? offB : offA;
+    };
+
+    const bool stamp = UVA_STAMP_ON(a);
+    for (int it = 0; it < niter; ++it) {
+        if (stamp) a.dbg[8 * it + 0] = __builtin_amdgcn_s_memtime();
+        const TileId id = next;
+        const PlaneDesc& pl = planes_lds[id.plane];
+        // This wave's pieces of tile `it` have landed: they were issued BEFORE the previous tile's four output stores,
+        // memory operations retire in order, so "at most 4 outstanding" proves them without waiting for the stores
+        // (a store's round trip is microseconds).  After the barrier every wave's share of the tile is there and
+        // nobody reads the other slot or the intermediate tile any more.
+        if (it == 0) tile_barrier<0>(); else tile_barrier<4>();
+        if (stamp) a.dbg[8 * it + 1] = __builtin_amdgcn_s_memtime();
+        if (it + 1 < niter) {
+            next = pt.decode(tile_of(it + 1), lane);
+            issue_tile(next, cur ^ 1);
+        }
+        const char* const in_tile = smem + cur * P24_SLOTB;
+        const int pl_h = __builtin_amdgcn_readfirstlane(pl.h), pl_w = __builtin_amdgcn_readfirstlane(pl.w);
+        const int iy0 = id.ty * TH - 1, ix0 = id.tx * TW - 1;       // plane position of intermediate pixel (0, 0)
+
+        // ---- stage A: intermediate fragments wave, wave + 4, wave + 8 (fragment 10 = columns 32, 33 of all rows) ----
+        // per-channel parameters of this lane's 12 channels, fetched once per tile (inside the fragment loop every
+        // one of these nine LDS reads is a full latency: stage A took 4 800 cycles instead of 2 000)
+        f32x4 pb[3], ps[3], pi[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            pb[g] = *(const f32x4*)(prm + 8 * g + 4 * half);
+            ps[g] = *(const f32x4*)(prm + 64 + 8 * g + 4 * half);
+            pi[g] = *(const f32x4*)(prm + 128 + 8 * g + 4 * half);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int f = wave + 4 * j;
+            if (f > 10) continue;                                       // uniform
+            const bool edge = f == 10;
+            const int r = edge ? min(px >> 1, PH - 1) : f;
+            const int c = edge ? TW + (px & 1) : px;
+            const char* const base = in_tile + (r * P24_XW + c) * P24_PIXB;
+            // B fragments are read PF k-steps ahead of the MFMA that consumes them (one wave per SIMD of this
+            // workgroup: nothing else hides the LDS latency), order pinned with sched_group_barrier
+            f32x16 acc;
+            half8 bq[PF + 1];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < PF; ++ks) bq[ks] = *(const half8*)(base + tap_off(ks, P24_XW));
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + PF < KS) bq[(ks + PF) % (PF + 1)] = *(const half8*)(base + tap_off(ks + PF, P24_XW));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wA[ks], bq[ks % (PF + 1)], ks == 0 ? zero16 : acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (ks + PF < KS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            const bool inside = (!edge || px < 2 * PH) && iy0 + r >= 0 && iy0 + r < pl_h && ix0 + c >= 0 && ix0 + c < pl_w;
+            const bool write = !edge || px < 2 * PH;
+            char* const dst = inter + (r * PW + c) * P24_PIXB;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const int cb = 8 * g + 4 * half;
+                const f32x4 b4 = pb[g], s4 = ps[g], i4 = pi[g];
+                f32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float x = acc[4 * g + q] + b4[q];
+                    v[q] = __builtin_amdgcn_fmed3f(x, x * s4[q], i4[q]);
+                }
+                uint2 o;
+                o.x = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, half2v));
+                o.y = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, half2v));
+                if (!inside) o = make_uint2(0, 0);                      // the second layer's zero padding
+                if (write) *(uint2*)(dst + cb * 2) = o;
+            }
+        }
+        if (stamp) a.dbg[8 * it + 2] = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the intermediate tile is complete (LDS only:
+                                                                              // the next tile's DMA stays in flight)
+        // ---- stage B: rows 2*wave, 2*wave + 1 of the output tile from the intermediate tile ----
+        if (stamp) a.dbg[8 * it + 3] = __builtin_amdgcn_s_memtime();
+        f32x16 accB[2][1];
+        {
+            const char* const base0 = inter + ((2 * wave) * PW + px) * P24_PIXB;
+            half8 bq[PF + 1][2];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < PF; ++ks)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) bq[ks][n] = *(const half8*)(base0 + n * PW * P24_PIXB + tap_off(ks, PW));
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + PF < KS) {
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        bq[(ks + PF) % (PF + 1)][n] = *(const half8*)(base0 + n * PW * P24_PIXB + tap_off(ks + PF, PW));
+                }
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    accB[n][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wB[ks], bq[ks % (PF + 1)][n], ks == 0 ? zero16 : accB[n][0], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * PF, 0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                if (ks + PF < KS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+        }
+        if (stamp) a.dbg[8 * it + 4] = __builtin_amdgcn_s_memtime();
+        f32x4 qb[3], qs[3], qi[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            qb[g] = *(const f32x4*)(prm + 192 + 8 * g + 4 * half);
+            qs[g] = *(const f32x4*)(prm + 192 + 64 + 8 * g + 4 * half);
+            qi[g] = *(const f32x4*)(prm + 192 + 128 + 8 * g + 4 * half);
+        }
+        // PReLU, fp16, LDS transpose (this wave's own DMA region of the slot stage A consumed: its next refill is
+        // issued by this wave, after these reads), then exactly FOUR store instructions per tile whatever the tile's
+        // valid extent -- lanes outside the plane store to the sink -- so that the vmcnt above is a constant
+        {
+            constexpr int SPX = StageGeo<NF>::SPX, PIXB = P24_PIXB;
+            char* const stage = smem + cur * P24_SLOTB + wave * (P24_CPW * 1024);
+            const int lane_o = opaque(lane);
+            const int spx = lane_o & 31, shalf = lane_o >> 5;
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const int cb = 8 * g + 4 * shalf;
+                    const f32x4 b4 = qb[g], s4 = qs[g], i4 = qi[g];
+                    f32x4 v;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float x = accB[n][0][4 * g + q] + b4[q];
+                        v[q] = __builtin_amdgcn_fmed3f(x, x * s4[q], i4[q]);
+                    }
+                    uint2 o;
+                    o.x = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, half2v));
+                    o.y = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, half2v));
+                    *(uint2*)(stage + (n * 32 + spx) * SPX + cb * 2) = o;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int y0 = id.ty * TH + 2 * wave, x0 = id.tx * TW;
+            const int vx = min(TW, pl_w - x0);
+            const long long pitch = __builtin_amdgcn_readfirstlane(pl.pitch);
+            const long long act_off = pl.act_off;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                char* const grow = (char*)a.out_act + (act_off + (long long)(y0 + n + 1) * pitch + (x0 + 1)) * PIXB;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int q = min(kk * 64 + lane_o, 32 * SPP - 1);          // 96 sixteen-byte chunks per row
+                    const int pix = q / SPP, sl = q - pix * SPP;
+                    const bool ok = kk * 64 + lane_o < 32 * SPP && pix < vx && y0 + n < pl_h;
+                    char* dst = ok ? grow + pix * PIXB + sl * 16 : (char*)a.sink + lane_o * 16;
+                    *(uint4*)dst = *(const uint4*)(stage + (n * 32 + pix) * SPX + sl * 16);
+                }
+            }
+        }
+        if (stamp) a.dbg[8 * it + 5] = __builtin_amdgcn_s_memtime();
+        cur ^= 1;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
