@@ -924,7 +924,7 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
         case GLayer::CONV: {
             const GenericDevice::ConvDev& cd = n->gd.convs[gl.conv];
             const GBuf& a = in(0);
-            const dim3 grid((a.w + 63) / 64, a.h, (cd.cout_pad + 63) / 64);
+            const dim3 grid((a.w + 63) / 64, (a.h + 3) / 4, (cd.cout_pad + 63) / 64);
             if (gl.ksize == 3)
                 hipLaunchKernelGGL(g_conv<3>, grid, dim3(256), 0, n->stream, a.p, a.cpad, cd.wpk, cd.bias, o.p, o.c, cd.cout_pad, o.cpad, a.h, a.w, gl.has_act ? 1 : 0, gl.act_slope);
             else

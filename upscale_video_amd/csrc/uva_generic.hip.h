@@ -49,43 +49,56 @@ __global__ void g_input_f32(const float* src, int h, int w, _Float16* out, int c
 }
 
 // ncnn convolution.cpp (stride 1, 'same' zero padding, optional bias, optional fused LeakyReLU):
-// one wave = 16 pixels of a row x up to 64 output channels; A = weights, B = pixels, both from L2.
+// one wave = 64 pixels of a row (four 16-pixel B fragments) x up to 64 output channels (four A fragments), so
+// every operand fetched from L2 feeds four MFMAs; a workgroup = 4 consecutive rows.
 template <int KSIZE>
 __global__ __launch_bounds__(256) void g_conv(const _Float16* in, int cin_pad, const half8* wpk, const float* bias, _Float16* out,
                                               int cout, int cout_pad, int out_cpad, int h, int w, int has_act, float slope)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int x0 = (blockIdx.x * 4 + wave) * 16, y = blockIdx.y;
-    if (x0 >= w) return;
+    const int x0 = blockIdx.x * 64, y = blockIdx.y * 4 + wave;
+    if (y >= h) return;
     const int mbn = cout_pad / 16, mb0 = blockIdx.z * 4, nmb = min(4, mbn - mb0);
     const int c32n = cin_pad / 32, p = lane & 15, oct = lane >> 4;
-    f32x4 acc[4];
+    const int nfr = min(4, (w - x0 + 15) / 16);
+    f32x4 acc[4][4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[f][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     constexpr int TAPS = KSIZE * KSIZE;
     for (int tap = 0; tap < TAPS; ++tap) {
         const int dy = KSIZE == 3 ? tap / 3 - 1 : 0, dx = KSIZE == 3 ? tap % 3 - 1 : 0;
         const _Float16* src = in + gb_off(w, cin_pad, y + dy, x0 + p + dx) + 8 * oct;
         for (int c32 = 0; c32 < c32n; ++c32) {
-            const half8 b = *(const half8*)(src + 32 * c32);
             const half8* wp = wpk + ((size_t)(tap * c32n + c32) * mbn + mb0) * 64 + lane;
+            half8 a[4], b[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
-                if (m < nmb) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wp[m * 64], b, acc[m], 0, 0, 0);
+            for (int m = 0; m < 4; ++m) a[m] = wp[(m < nmb ? m : 0) * 64];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) b[f] = *(const half8*)(src + (size_t)(f < nfr ? f : 0) * 16 * cin_pad + 32 * c32);
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m], b[f], acc[f][m], 0, 0, 0);
         }
     }
-    if (x0 + p >= w) return;
-    _Float16* o = out + gb_off(w, out_cpad, y, x0 + p);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        if (m >= nmb) continue;
-        const int ch = 16 * (mb0 + m) + 4 * oct;
+    for (int f = 0; f < 4; ++f) {
+        const int x = x0 + 16 * f + p;
+        if (f >= nfr || x >= w) continue;
+        _Float16* o = out + gb_off(w, out_cpad, y, x);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (ch + j >= cout) continue;
-            float v = acc[m][j] + bias[ch + j];
-            if (has_act) v = v > 0.f ? v : v * slope;      // ncnn activation_type 2: LeakyReLU
-            o[ch + j] = (_Float16)v;
+        for (int m = 0; m < 4; ++m) {
+            if (m >= nmb) continue;
+            const int ch = 16 * (mb0 + m) + 4 * oct;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (ch + j >= cout) continue;
+                float v = acc[f][m][j] + bias[ch + j];
+                if (has_act) v = v > 0.f ? v : v * slope;      // ncnn activation_type 2: LeakyReLU
+                o[ch + j] = (_Float16)v;
+            }
         }
     }
 }
