@@ -120,7 +120,7 @@ def pmc_traffic(args, nf, kernel):
     for path in reversed(paths):
         try:
             d = json.load(open(path))
-            if d.get("kernel", "trunk_kernel").startswith(kernel):
+            if kernel + "<" in d.get("kernel", "trunk_kernel<"):
                 return int(d["hbm_bytes_per_launch"]), "profiles/" + os.path.basename(path)
         except Exception:  # noqa: BLE001
             pass
