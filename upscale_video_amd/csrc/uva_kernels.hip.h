@@ -1515,17 +1515,20 @@ __global__ __launch_bounds__(512, 2) void trunk2_kernel(Trunk2Args a)
     auto load_a = [&](int g) __attribute__((always_inline)) { return scalar_load16(&steps[g].a); };
     auto load_b = [&](int g) __attribute__((always_inline)) { return scalar_load16(&steps[g].b); };
 
+    // Prologue, ordered so that the producer's first k-loop waits for as little as possible: parameters, the
+    // producer's weights and its first TWO input tiles.  The consumer's weights (not needed before iteration 2) and
+    // tiles 2, 3 arrive behind the first k-loops.
+    float prm_b = 0.f, prm_s = 0.f;
+    if (wave == 0) {
+        prm_b = (grp ? a.bias[1] : a.bias[0])[lane];
+        prm_s = (grp ? a.slope[1] : a.slope[0])[lane];
+    }
     // this wave's half of its layer's weights, resident in registers for the whole kernel
     half8 w[KS];
     {
         const half8* wp = grp ? a.wpk[1] : a.wpk[0];
 #pragma unroll
         for (int i = 0; i < KS; ++i) w[i] = wp[((i >> 1) * 4 + 2 * mh + (i & 1)) * 64 + lane];
-    }
-    float prm_b = 0.f, prm_s = 0.f;
-    if (lane < 64 && wave == 0) {
-        prm_b = (grp ? a.bias[1] : a.bias[0])[lane];
-        prm_s = (grp ? a.slope[1] : a.slope[0])[lane];
     }
     // LDS-DMA source position of this lane in piece i: (halo row << 13) | byte offset inside the row, two
     // pieces per register (the k-loop needs every register it can get)
@@ -1545,18 +1548,24 @@ __global__ __launch_bounds__(512, 2) void trunk2_kernel(Trunk2Args a)
             glds16_s(base, (pc >> 13) * (unsigned)pitch + (pc & 0x1fffu), lds0 + slot * SLOTB + (4 * i + wave) * 1024);
         }
     };
-    if (grp == 0) {
-        // prologue: the first three input tiles (entries behind the last step are valid dummies)
-#pragma unroll
-        for (int g = 0; g < T2_SLOTS; ++g) issue_tile(load_a(g), g);
-    }
     if (wave == 0) {
         float* prm = prm_all + grp * (PARAM_LDS / 4);
         prm[lane] = prm_b;
         prm[64 + lane] = prm_s;
         prm[128 + lane] = prm_s <= 1.f ? __builtin_inff() : -__builtin_inff();
     }
-    tile_barrier<0>();                 // weights, parameters and the first tiles have landed
+    if (grp == 0) {
+        // input tiles 0 and 1 (entries behind the last step are valid dummies), then a "use" of the weights: hipcc
+        // places its wait for them -- a vmcnt(0), which also covers the two tiles -- HERE and not in front of the
+        // loop, where it would wait for tiles 2 and 3 as well
+        issue_tile(load_a(0), 0);
+        issue_tile(load_a(1), 1);
+#pragma unroll
+        for (int i = 0; i < KS; ++i) asm volatile("" : "+v"(w[i]));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    group_barrier();                   // parameters, the producer's weights and tiles 0, 1 are in place
+    static_assert(T2_SLOTS == 4, "tiles 0, 1 here, tiles 2, 3 with tile 4 in the first epilogue phase");
     if (grp == 1) group_barrier();     // the consumer runs half a period behind the producer
 
     const float* const bias_lds = prm_all + grp * (PARAM_LDS / 4);
@@ -1689,6 +1698,10 @@ __global__ __launch_bounds__(512, 2) void trunk2_kernel(Trunk2Args a)
             // input tile of step it + 3 -> the slot this k-loop has just released; the pieces issued one and
             // two epilogues ago (steps it + 2, it + 1) are older, so "at most two tiles' pieces outstanding"
             // at the closing barrier proves step it + 1's tile
+            if (it == 0) {             // tiles 2 and 3 were left out of the prologue: hipcc's own wait for the consumer's
+                issue_tile(load_a(2), 2);   // weights sits in front of the loop on BOTH groups' path and would have
+                issue_tile(load_a(3), 3);   // waited for them too
+            }
             issue_tile(e_dma, sl);
             if (work) {
                 f32x4 b4[2], s4[2], i4[2];

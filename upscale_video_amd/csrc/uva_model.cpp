@@ -306,4 +306,26 @@ void pack_head(const ConvWeights& c, std::vector<uint16_t>& out, int* mf_out)
     if (mf_out) *mf_out = mf;
 }
 
+void pack_sub16(const ConvWeights& c, std::vector<uint16_t>& out, int* ks_out, int* mb_out)
+{
+    const bool head = c.cin == 3;
+    const int ks_n = head ? 2 : 7, mbn = (c.cout + 15) / 16;
+    out.assign((size_t)ks_n * mbn * 64 * 8, 0);
+    for (int ks = 0; ks < ks_n; ++ks)
+        for (int mb = 0; mb < mbn; ++mb)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int co = 16 * mb + (lane & 15), ko = 4 * ks + (lane >> 4);
+                if (co >= c.cout) continue;
+                for (int e = 0; e < 8; ++e) {
+                    int tap, ci;
+                    if (head) { tap = 2 * ko + (e >> 2); ci = e & 3; if (ci >= 3) continue; }
+                    else { tap = ko / 3; ci = 8 * (ko % 3) + e; }
+                    if (tap >= 9) continue;
+                    out[(((size_t)ks * mbn + mb) * 64 + lane) * 8 + e] = f32_to_f16_bits(c.w[((size_t)co * c.cin + ci) * 9 + tap]);
+                }
+            }
+    if (ks_out) *ks_out = ks_n;
+    if (mb_out) *mb_out = mbn;
+}
+
 }  // namespace uva

@@ -50,4 +50,10 @@ void pack_tail64(const ConvWeights& c, std::vector<uint16_t>& out);
 // image [3][MF][64][8].
 void pack_head(const ConvWeights& c, std::vector<uint16_t>& out, int* mf_out);
 
+// sub10_kernel (the whole 24-feature 1x net in one launch, v_mfma_f32_16x16x32_f16): image [k-step][m-block][64 lanes][8],
+// lane = (o << 4) | i supplies output channel 16*mb + i and K octet ko = 4*ks + o.
+//   cin = 24 (trunk, tail): ko = 3*tap + channel octet, 27 octets -> 7 k-steps; cout padded to 16*mbn;
+//   cin = 3  (head):        octet ko holds taps 2ko and 2ko+1 as [B, G, R, 0] each, 5 octets -> 2 k-steps.
+void pack_sub16(const ConvWeights& c, std::vector<uint16_t>& out, int* ks_out, int* mb_out);
+
 }  // namespace uva
