@@ -25,9 +25,10 @@
 extern "C" {
 #endif
 
-#define UVA_ABI_VERSION 4   /* 2: + uva_net_submit_u8 / uva_net_collect_u8 / uva_host_alloc / uva_host_free;
+#define UVA_ABI_VERSION 5   /* 2: + uva_net_submit_u8 / uva_net_collect_u8 / uva_host_alloc / uva_host_free;
                                3: + uva_get_gpu_pci_bus_id, uva_debug_trunk2_schedule;
-                               4: + uva_denoise_u8, uva_debug_denoise_stage; generic graphs (4x_Valar_v1) load */
+                               4: + uva_denoise_u8, uva_debug_denoise_stage; generic graphs (4x_Valar_v1) load;
+                               5: + uva_debug_sub10_rows */
 
 typedef struct uva_net uva_net;
 
@@ -167,6 +168,13 @@ int uva_net_debug_packed_weights(uva_net* net, int conv_idx, uint16_t* out, size
 int uva_debug_trunk2_schedule(int h, int w, int tile_size, int border, int grid, uint32_t* steps_words,
                               size_t capacity_words, size_t* needed_words, int* nsteps, int* stride,
                               long long* plane_info, int max_planes, int* nplanes, long long* guard_bytes);
+
+/* Test hook (host only): the row lists sub10_kernel (the whole 24-feature 1x net, one launch) walks for an h x w
+ * frame on `grid` workgroups.  Every workgroup has `*stride` 16-byte entries of 4 words {y, x0, emit, 0}
+ * (csrc/uva_kernels.hip.h Sub10Args), nrows[b] of them real: the kernel computes columns x0 .. x0+79 of row y and
+ * writes columns x0+10 .. x0+69 of it when emit is set. */
+int uva_debug_sub10_rows(int h, int w, int grid, uint32_t* rows_words, size_t capacity_words, size_t* needed_words,
+                         int* nrows, int* stride);
 
 const char* uva_last_error(void);
 int uva_abi_version(void);

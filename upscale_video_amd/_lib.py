@@ -6,11 +6,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UVA_LIB_PATH") or os.path.join(_HERE, "libuva.so")   # override: A/B builds
 
 # every symbol include/uva.h declares
-ABI_VERSION = 4   # include/uva.h UVA_ABI_VERSION
+ABI_VERSION = 5   # include/uva.h UVA_ABI_VERSION
 
 SYMBOLS = [
     "uva_get_gpu_count", "uva_get_default_gpu_index", "uva_get_gpu_info", "uva_get_gpu_pci_bus_id",
-    "uva_debug_trunk2_schedule", "uva_denoise_u8", "uva_debug_denoise_stage", "uva_destroy_gpu_instance",
+    "uva_debug_trunk2_schedule", "uva_debug_sub10_rows", "uva_denoise_u8", "uva_debug_denoise_stage", "uva_destroy_gpu_instance",
     "uva_net_create", "uva_net_set_device", "uva_net_load_param", "uva_net_load_model",
     "uva_net_destroy", "uva_net_scale", "uva_net_num_features", "uva_net_num_convs",
     "uva_net_extract_f32", "uva_net_process_u8", "uva_net_process_u8_device", "uva_net_synchronize",
@@ -47,6 +47,8 @@ def load():
         _lib = L
         return L
     L.uva_get_gpu_pci_bus_id.argtypes = [c_i, ctypes.c_char_p, c_sz]
+    if hasattr(L, "uva_debug_sub10_rows"):
+        L.uva_debug_sub10_rows.argtypes = [c_i, c_i, c_i, c_p, c_sz, ctypes.POINTER(c_sz), c_p, ctypes.POINTER(c_i)]
     L.uva_debug_trunk2_schedule.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_sz, ctypes.POINTER(c_sz), c_p,
                                             ctypes.POINTER(c_i), c_p, c_i, ctypes.POINTER(c_i),
                                             ctypes.POINTER(ctypes.c_longlong)]

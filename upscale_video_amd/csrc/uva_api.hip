@@ -60,6 +60,11 @@ struct Workspace {
     size_t alloc_bytes = 0;      // device bytes of the two activation buffers (the cache's LRU budget)
     char* act_base[2] = {nullptr, nullptr};
     _Float16* act[2] = {nullptr, nullptr};
+    // sub10_kernel (the whole 24-feature 1x net in one launch): per-workgroup row descriptors
+    uint4* d_rows10 = nullptr;
+    int* d_nrows10 = nullptr;
+    int max_rows10 = 0, grid10 = 0;
+    bool sub10_unfit = false;
     // trunk2_kernel (fused layer pair): per-workgroup step lists
     Trunk2Step* d_steps2 = nullptr;
     int* d_nsteps2 = nullptr;
@@ -70,6 +75,10 @@ struct Workspace {
         if (d_sched4) (void)hipFree(d_sched4);
         if (d_steps2) (void)hipFree(d_steps2);
         if (d_nsteps2) (void)hipFree(d_nsteps2);
+        if (d_rows10) (void)hipFree(d_rows10);
+        if (d_nrows10) (void)hipFree(d_nrows10);
+        d_rows10 = nullptr;
+        d_nrows10 = nullptr;
         d_sched4 = nullptr;
         d_steps2 = nullptr;
         d_nsteps2 = nullptr;
@@ -84,6 +93,8 @@ struct Workspace {
 struct DeviceLayer {
     half8* wpk = nullptr;
     half8* wpk16 = nullptr;   // tail layer of the 64-feature 2x / 4x nets: pack_tail64 image for tail_kernel / tail4_kernel
+    half8* wpk_s10 = nullptr; // 24-feature 1x net: pack_sub16 image for sub10_kernel, with its own (sign-folded) bias
+    float* bias_s10 = nullptr;
     float* bias = nullptr;
     float* slope = nullptr;
 };
@@ -122,6 +133,7 @@ struct uva_net {
     _Float16* d_sink = nullptr;   // where out-of-image lanes of the trunk kernel store to
     bool attr_set[16] = {false};  // hipFuncAttributeMaxDynamicSharedMemorySize done for kernel slot k on this net's device
     int last_act_buf = 0;         // which ping-pong buffer the last run_graph() left its last trunk activation in
+    bool fuse_all = true;         // 24-feature 1x net: all ten convolutions in one launch (sub10_kernel); UVA_SUB10=0 turns it off
     bool fuse_pairs = true;       // 64-feature nets: trunk layers run two per launch (trunk2_kernel); UVA_TRUNK_FUSION=0 turns it off
     LastCall last;
     // pipelined host route (uva_net_submit_u8 / uva_net_collect_u8): H2D, kernels and D2H of
@@ -158,6 +170,8 @@ struct uva_net {
         for (auto& l : layers) {
             if (l.wpk) (void)hipFree(l.wpk);
             if (l.wpk16) (void)hipFree(l.wpk16);
+            if (l.wpk_s10) (void)hipFree(l.wpk_s10);
+            if (l.bias_s10) (void)hipFree(l.bias_s10);
             if (l.bias) (void)hipFree(l.bias);
             if (l.slope) (void)hipFree(l.slope);
         }
@@ -430,6 +444,89 @@ int launch_trunk2(uva_net* n, const Workspace* ws, const Trunk2Args& a)
     return 0;
 }
 
+// Row descriptors of sub10_kernel for an h x w frame: 60-column strips, the sequence (strip, row) dealt out to the
+// workgroups in contiguous ranges; every range (segment) starts 10 rows early and ends 9 rows late (the rows the
+// layers in between need), only its own rows are written out.
+int build_sub10_rows(int h, int w, int grid, std::vector<uint4>& rows, std::vector<int>& nrows, int* max_rows)
+{
+    const int ns = (w + S10_VALID - 1) / S10_VALID;
+    const long long total = (long long)ns * h;
+    struct Seg { int k, y0, n; };
+    std::vector<std::vector<Seg>> per_wg;
+    int D = (int)std::max<long long>(2 * S10_NL + 4, (total + grid - 1) / grid + 2 * S10_NL);
+    for (;; ++D) {
+        per_wg.assign(1, {});
+        int cap = D;
+        for (int k = 0; k < ns; ++k) {
+            int y = 0;
+            while (y < h) {
+                if (cap < 2 * S10_NL + 1) { per_wg.emplace_back(); cap = D; }
+                const int n = std::min(h - y, cap - 2 * S10_NL);
+                per_wg.back().push_back({k, y, n});
+                cap -= n + 2 * S10_NL;
+                y += n;
+            }
+        }
+        if ((int)per_wg.size() <= grid) break;
+    }
+    if (D > S10_MAX_ROWS) return 2;      // row table does not fit the kernel's LDS copy: the caller takes the per-pair path
+    *max_rows = D;
+    rows.assign((size_t)grid * D, make_uint4(0, 0, 0, 0));
+    nrows.assign(grid, 0);
+    const int per_xcd = grid / 8;
+    for (size_t c = 0; c < per_wg.size(); ++c) {
+        const int b = (int)(c % per_xcd) * 8 + (int)(c / per_xcd);
+        uint4* out = rows.data() + (size_t)b * D;
+        int g = 0;
+        for (const Seg& sg : per_wg[c])
+            for (int y = sg.y0 - S10_NL; y < sg.y0 + sg.n + S10_NL; ++y, ++g)
+                out[g] = make_uint4((unsigned)y, (unsigned)(sg.k * S10_VALID - S10_NL), (y >= sg.y0 && y < sg.y0 + sg.n) ? 1u : 0u, 0u);
+        nrows[b] = g;
+    }
+    return 0;
+}
+
+// the whole 24-feature 1x net in one launch (u8 route, one plane); returns 2 when the frame is too large for it
+int launch_sub10(uva_net* n, Workspace* ws, const void* src, size_t src_stride, void* dst, size_t dst_stride,
+                 unsigned long long* dbg = nullptr)
+{
+    if (ws->sub10_unfit) return 2;
+    if (!ws->d_rows10) {
+        std::vector<uint4> rows;
+        std::vector<int> nrows;
+        ws->grid10 = std::max(8, (n->ncu / 8) * 8);
+        if (build_sub10_rows(ws->h, ws->w, ws->grid10, rows, nrows, &ws->max_rows10)) {
+            ws->sub10_unfit = true;
+            return 2;
+        }
+        HIP_TRY(hipMalloc((void**)&ws->d_rows10, rows.size() * sizeof(uint4)));
+        HIP_TRY(hipMalloc((void**)&ws->d_nrows10, nrows.size() * sizeof(int)));
+        HIP_TRY(hipMemcpyAsync(ws->d_rows10, rows.data(), rows.size() * sizeof(uint4), hipMemcpyHostToDevice, n->stream));
+        HIP_TRY(hipMemcpyAsync(ws->d_nrows10, nrows.data(), nrows.size() * sizeof(int), hipMemcpyHostToDevice, n->stream));
+        HIP_TRY(hipStreamSynchronize(n->stream));
+    }
+    Sub10Args a;
+    std::memset(&a, 0, sizeof a);
+    a.src = (const uint8_t*)src; a.src_stride = src_stride;
+    a.dst = (uint8_t*)dst; a.dst_stride = dst_stride;
+    a.h = ws->h; a.w = ws->w;
+    a.rows = ws->d_rows10; a.nrows = ws->d_nrows10; a.max_rows = ws->max_rows10;
+    a.dbg = dbg;
+    for (int i = 0; i < S10_NL; ++i) {
+        a.wpk[i] = n->layers[i].wpk_s10;
+        a.bias[i] = n->layers[i].bias_s10;
+        a.slope[i] = n->layers[i].slope;
+    }
+    const size_t lds = sub10_lds_bytes();
+    if (!n->attr_set[10]) {
+        HIP_TRY(hipFuncSetAttribute((const void*)sub10_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        n->attr_set[10] = true;
+    }
+    hipLaunchKernelGGL(sub10_kernel, dim3(ws->grid10), dim3(64 * S10_NL), lds, n->stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // two trunk layers of the 24-feature net per launch (pair24_kernel), two persistent workgroups per CU
 int launch_pair24(uva_net* n, const ConvArgs& a)
 {
@@ -486,6 +583,7 @@ int ensure_device(uva_net* n)
     } undo{n};
     HIP_TRY(hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking));
     if (const char* e = std::getenv("UVA_TRUNK_FUSION")) n->fuse_pairs = std::atoi(e) != 0;
+    if (const char* e = std::getenv("UVA_SUB10")) n->fuse_all = std::atoi(e) != 0;
     HIP_TRY(hipMalloc((void**)&n->d_sink, 64 * 128 + 256));
     if (n->generic) {
         // generic graph: every convolution's MFMA image ([tap][cin/32][cout/16][lane][8]) and padded bias
@@ -528,6 +626,20 @@ int ensure_device(uva_net* n)
         if (g.nf == 64 && (g.scale == 2 || g.scale == 4) && i + 1 == g.convs.size()) {
             pack_tail64(g.convs[i], pk16);
             if (upload(&dl.wpk16, pk16.data(), pk16.size() * 2, n->stream)) return 1;
+        }
+        if (g.nf == 24 && g.scale == 1 && g.convs.size() == (size_t)S10_NL) {
+            // channels whose PReLU slope exceeds 1 travel negated between the layers (uva_model.h pack_sub16)
+            std::vector<float> sin(g.convs[i].cin, 1.f), sout(g.convs[i].cout, 1.f), bs(32, 0.f);
+            if (i > 0)
+                for (int c = 0; c < g.convs[i].cin; ++c) sin[c] = g.slopes[i - 1][c] > 1.f ? -1.f : 1.f;
+            if (i + 1 < g.convs.size())
+                for (int c = 0; c < g.convs[i].cout; ++c) sout[c] = g.slopes[i][c] > 1.f ? -1.f : 1.f;
+            for (int c = 0; c < g.convs[i].cout; ++c) bs[c] = sout[c] * g.convs[i].bias[c];
+            std::vector<uint16_t> pks;
+            pack_sub16(g.convs[i], pks, nullptr, nullptr, sin.data(), sout.data());
+            if (upload(&dl.wpk_s10, pks.data(), pks.size() * 2, n->stream)) return 1;
+            if (upload(&dl.bias_s10, bs.data(), bs.size() * 4, n->stream)) return 1;
+            HIP_TRY(hipStreamSynchronize(n->stream));
         }
         std::vector<float> b((size_t)mf * 32, 0.f), s((size_t)mf * 32, 0.f);
         std::copy(g.convs[i].bias.begin(), g.convs[i].bias.end(), b.begin());
@@ -730,6 +842,31 @@ int run_graph(uva_net* n, Workspace* ws, bool f32, const void* src, size_t src_s
 {
     const Graph& g = n->g;
     const int nconv = (int)g.convs.size();
+    // the 24-feature 1x net on a whole-frame plane, u8 in / u8 out: one launch for all ten convolutions
+    if (n->fuse_all && !f32 && stop_after < 0 && g.nf == 24 && g.scale == 1 && nconv == S10_NL && ws->planes.size() == 1 &&
+        n->layers[0].wpk_s10 && !ws->sub10_unfit) {
+        uva_net::EvSet ev1;
+        const bool prof1 = n->prof;
+        if (prof1) {
+            for (auto& e : ev1.e) e = nullptr;
+            for (auto& e : ev1.e) {
+                e = take_event(n);
+                if (!e) return 1;
+            }
+            HIP_TRY(hipEventRecord(ev1.e[0], n->stream));
+            HIP_TRY(hipEventRecord(ev1.e[1], n->stream));
+        }
+        const int rc = launch_sub10(n, ws, src, src_stride, dst, dst_stride);
+        if (rc == 1) return 1;
+        if (prof1) {
+            HIP_TRY(hipEventRecord(ev1.e[2], n->stream));
+            HIP_TRY(hipEventRecord(ev1.e[3], n->stream));
+            ev1.ntrunk = 1;
+            if (rc == 0) n->ev_pending.push_back(ev1);
+            else for (auto e : ev1.e) n->ev_free.push_back(e);
+        }
+        if (rc == 0) return 0;
+    }
     const bool prof = n->prof && stop_after < 0;
     uva_net::EvSet ev;
     ev.ntrunk = 0;   // trunk launches of this frame (a fused pair is one launch)
@@ -1571,6 +1708,29 @@ int uva_net_debug_trunk_stamps(uva_net* n, unsigned long long* out, int max_tile
         if (tiles) *tiles = pingpong_tail ? per_block : (ca.tiles_per_xcd + grid3 / 8 - 1) / (grid3 / 8);
         return rc3;
     }
+    if (ablate == 7) {
+        // sub10_kernel (the whole 1x net): out[(step*10 + wave)*4 + {0 step start, 1 MFMAs done, 2 at the barrier}] of
+        // workgroup 0 (max_tiles*8 words must hold 40 per step); *tiles = steps
+        if (n->last.f32 || !n->last.dst || ws->planes.size() != 1) { (void)hipFree(d); return fail("sub10 stamps need a previous whole-frame uva_net_process_u8 call"); }
+        int rc7 = launch_sub10(n, ws, n->last.src, n->last.src_stride, n->last.dst, n->last.dst_stride);
+        if (rc7 == 0 && (size_t)(ws->max_rows10 + S10_DRAIN + 2) * 40 > (size_t)max_tiles * 8) { (void)hipFree(d); return fail("max_tiles too small"); }
+        HIP_TRY(hipEventRecord(e0, n->stream));
+        for (int r = 0; r < 50 && !rc7; ++r) rc7 = launch_sub10(n, ws, n->last.src, n->last.src_stride, n->last.dst, n->last.dst_stride);
+        HIP_TRY(hipEventRecord(e1, n->stream));
+        if (!rc7) rc7 = launch_sub10(n, ws, n->last.src, n->last.src_stride, n->last.dst, n->last.dst_stride, d);
+        if (!rc7) {
+            HIP_TRY(hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, n->stream));
+            HIP_TRY(hipStreamSynchronize(n->stream));
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+            if (kernel_ms) *kernel_ms = ms / 50;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        (void)hipFree(d);
+        if (tiles) *tiles = ws->max_rows10 + S10_DRAIN;
+        return rc7 ? (rc7 == 2 ? fail("frame too large for sub10_kernel") : 1) : 0;
+    }
     if (ablate == 6) {
         // pair24_kernel (two 24-feature trunk layers): out[8*it + {0 top, 1 tile landed, 2 stage A done, 3 intermediate
         // complete, 4 stage B k-loop done, 5 stores issued}] of workgroup 0 / wave 0
@@ -1701,6 +1861,24 @@ int uva_debug_trunk2_schedule(int h, int w, int tile_size, int border, int grid,
     if (!steps_words || capacity_words < steps.size() * 8) return fail("steps buffer too small");
     std::memcpy(steps_words, steps.data(), steps.size() * sizeof(Trunk2Step));
     if (nsteps) std::copy(ns.begin(), ns.end(), nsteps);
+    return 0;
+}
+
+int uva_debug_sub10_rows(int h, int w, int grid, uint32_t* rows_words, size_t capacity_words, size_t* needed_words,
+                         int* nrows, int* stride)
+{
+    if (h <= 0 || w <= 0 || grid < 8 || grid % 8) return fail("bad argument");
+    std::vector<uint4> rows;
+    std::vector<int> nr;
+    int max_rows = 0;
+    const int rc = build_sub10_rows(h, w, grid, rows, nr, &max_rows);
+    if (rc == 2) return fail("frame too large for the fused 1x kernel's row table");
+    if (rc) return 1;
+    if (needed_words) *needed_words = rows.size() * 4;
+    if (stride) *stride = max_rows;
+    if (!rows_words || capacity_words < rows.size() * 4) return fail("rows buffer too small");
+    std::memcpy(rows_words, rows.data(), rows.size() * sizeof(uint4));
+    if (nrows) std::copy(nr.begin(), nr.end(), nrows);
     return 0;
 }
 

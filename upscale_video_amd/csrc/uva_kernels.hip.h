@@ -34,6 +34,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
 #include <utility>
 
 // In-kernel cycle stamps (s_memtime of workgroup 0 / wave 0 per phase) and the trunk kernel's ablation
@@ -978,6 +979,394 @@ __global__ __launch_bounds__(256, 2) void pair24_kernel(ConvArgs a)
         cur ^= 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ----------------------------------------------------------------------------------------------
+// sub10_kernel: the WHOLE 1x HurrDeblur SubCompact net (conv 3->24, 8 x conv 24->24, conv 24->3, + input, u8 in ->
+// u8 out; models/1x_HurrDeblur_SubCompact_nf24-nc8_244k_net_g.param:3-26) in one launch: only the u8 frame touches
+// HBM (6 B per pixel instead of ~870).
+//
+// One 10-wave workgroup per CU is a systolic pipeline: WAVE s IS LAYER s.  Its weights (<= 56 registers) never
+// move; rows of an 80-column strip stream top to bottom through 4-row rings in LDS, one ring per layer output
+// (48 B per pixel), wave s reading rows r-1..r+1 of ring s-1 and writing row r of ring s, two rows behind wave s-1;
+// one workgroup barrier per row.  Every layer is computed on the full 80 columns; what is correct shrinks by one
+// column per side and layer, so 60 columns of the last layer are valid (the same happens at the top of a strip
+// segment: it starts 10 rows early).  Pixels outside the plane are written as zero by every layer (the next layer's
+// zero padding).  The head wave also loads the u8 rows (as [B,G,R,0] fp16, the 1/255 goes to the fp32 accumulator);
+// the tail wave adds the input pixel, *255, rounds half-even, saturates and stores 3 bytes per pixel.
+// ----------------------------------------------------------------------------------------------
+constexpr int S10_WC = 80;                       // computed columns per strip (five 16-pixel fragments)
+constexpr int S10_NL = 10;                       // layers = pipeline stages = waves
+constexpr int S10_VALID = S10_WC - 2 * S10_NL;   // columns of the strip the last layer gets right
+constexpr int S10_ROWPX = S10_WC + 2;            // ring row: one margin pixel either side (never written)
+constexpr int S10_PIXB = 48;
+constexpr int S10_ROWB = S10_ROWPX * S10_PIXB;
+constexpr int S10_RINGB = 4 * S10_ROWB;
+constexpr int S10_UROWB = S10_ROWPX * 8;         // input ring: [B, G, R, 0] fp16 per pixel
+constexpr int S10_URINGB = 4 * S10_UROWB;
+constexpr int S10_PRMB = S10_NL * 96 * 4;        // per layer: bias[32], slope[32], spare[32]
+constexpr int S10_RES_ROWS = 32;                 // u8 input rows kept for the residual add: the last layer writes 29 rows behind
+constexpr int S10_RESB = S10_RES_ROWS * S10_ROWPX * 4;
+constexpr int S10_MAX_ROWS = 640;                // row descriptors of a workgroup, copied to LDS (8 B each)
+constexpr int S10_DRAIN = 2 * S10_NL;            // steps after the last row went in until it has come out
+__host__ __device__ constexpr int sub10_lag(int stage) { return 2 * stage + 2; }
+constexpr int sub10_lds_bytes() { return (S10_NL - 1) * S10_RINGB + S10_URINGB + S10_PRMB + S10_RESB + S10_MAX_ROWS * 8; }
+static_assert(sub10_lds_bytes() <= 160 * 1024, "sub10 kernel LDS budget");
+
+struct Sub10Args {
+    const uint8_t* src;           // u8 HWC BGR frame (one plane = the whole frame: apply_model, :263-288)
+    size_t src_stride;
+    uint8_t* dst;
+    size_t dst_stride;
+    int h, w;
+    const uint4* rows;            // [gridDim.x][max_rows]: x = plane row y (may be outside), y = plane column of computed
+                                  // column 0, z = 1: the last layer's row is written out
+    const int* nrows;             // [gridDim.x]
+    int max_rows;
+    const half8* wpk[S10_NL];     // pack_sub16 images
+    const float* bias[S10_NL];    // [32] each, zero padded
+    const float* slope[S10_NL];   // [32] each (none for the last layer)
+    unsigned long long* dbg;      // UVA_INSTRUMENT builds: workgroup 0 stamps [step][wave][4] here
+};
+
+struct Sub10Lds {
+    char* smem;
+    char* uring;
+    float* prm;
+    char* resring;
+    int2* rows;
+};
+__device__ __forceinline__ Sub10Lds sub10_lds(char* smem)
+{
+    Sub10Lds l;
+    l.smem = smem;
+    l.uring = smem + (S10_NL - 1) * S10_RINGB;
+    l.prm = (float*)(l.uring + S10_URINGB);
+    l.resring = (char*)l.prm + S10_PRMB;
+    l.rows = (int2*)(l.resring + S10_RESB);
+    return l;
+}
+#ifndef S10_ABLATE
+#define S10_ABLATE 0
+#endif
+#if S10_ABLATE == 4
+__device__ __forceinline__ void sub10_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#else
+__device__ __forceinline__ void sub10_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
+
+#ifdef UVA_INSTRUMENT
+#define S10_STAMP(k) do { if (stamp) a.dbg[(t * S10_NL + stage) * 4 + (k)] = UVA_MEMTIME(); } while (0)
+#else
+#define S10_STAMP(k) do { } while (0)
+#endif
+
+// per-lane parameters of a 24-channel layer's epilogue: block 0 rows 4o..4o+3 = channels 4o..4o+3, block 1 rows
+// 4o, 4o+1 = channels 16+2o, 16+2o+1 (pack_sub16)
+struct Sub10Prm {
+    f32x4 s0;
+    f32x2 s1;
+};
+__device__ __forceinline__ Sub10Prm sub10_params(const float* myprm, int o)
+{
+    Sub10Prm q;
+    q.s0 = *(const f32x4*)(myprm + 32 + 4 * o);
+    q.s1 = *(const f32x2*)(myprm + 32 + 16 + 2 * o);
+    return q;
+}
+// PReLU (x already holds the bias) as max(x, slope*x) -- channels with a slope above 1 arrive negated, the host folded
+// the sign into the weights (uva_model.h pack_sub16) -- -> fp16 -> this lane's 8 + 4 bytes of a ring pixel
+template <bool MASKED>
+__device__ __forceinline__ void sub10_store(const f32x4 x0, const f32x4 x1, const Sub10Prm& q, char* px0, char* px1, bool inside)
+{
+    const f32x2 xa = {x0[0], x0[1]}, xb = {x0[2], x0[3]}, xc = {x1[0], x1[1]};
+    const f32x2 ya = xa * f32x2{q.s0[0], q.s0[1]}, yb = xb * f32x2{q.s0[2], q.s0[3]}, yc = xc * q.s1;
+    // max as med3(x, y, +inf), the +inf hidden from the optimiser in a scalar register: one instruction (fmaxf, and
+    // med3 with a visible constant, cost a second one that quiets signalling NaNs)
+    float inf = __builtin_inff();
+    asm("" : "+s"(inf));
+    const f32x2 va = {__builtin_amdgcn_fmed3f(xa[0], ya[0], inf), __builtin_amdgcn_fmed3f(xa[1], ya[1], inf)};
+    const f32x2 vb = {__builtin_amdgcn_fmed3f(xb[0], yb[0], inf), __builtin_amdgcn_fmed3f(xb[1], yb[1], inf)};
+    const f32x2 vc = {__builtin_amdgcn_fmed3f(xc[0], yc[0], inf), __builtin_amdgcn_fmed3f(xc[1], yc[1], inf)};
+    uint2 w0;
+    w0.x = __builtin_bit_cast(unsigned, __builtin_convertvector(va, half2v));
+    w0.y = __builtin_bit_cast(unsigned, __builtin_convertvector(vb, half2v));
+    unsigned w1 = __builtin_bit_cast(unsigned, __builtin_convertvector(vc, half2v));
+    if (MASKED && !inside) { w0 = make_uint2(0, 0); w1 = 0; }
+#if S10_ABLATE == 3
+    asm volatile("" :: "v"(x0), "v"(x1));
+#else
+    *(uint2*)px0 = w0;
+    *(unsigned*)px1 = w1;
+#endif
+}
+
+// ---- wave 0: u8 rows in, conv 3 -> 24 (+bias, PReLU) ----
+__device__ __forceinline__ void sub10_head(const Sub10Args& a, const Sub10Lds L, const int lane, const int nrows, const int nsteps)
+{
+    constexpr int stage = 0;
+    const int p = lane & 15, o = lane >> 4;
+    const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && lane == 0;
+    (void)stamp; (void)stage;
+    half8 wgt[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) wgt[ks][m] = a.wpk[0][(ks * 2 + m) * 64 + lane];
+    // K octet ko = 4ks + o holds taps 2ko and 2ko+1 as [B,G,R,0] each; taps past 8 meet zero weights
+    int sel_lo[2], sel_hi[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int ta = min(2 * (4 * ks + o), 8), tb = min(2 * (4 * ks + o) + 1, 8);
+        sel_lo[ks] = ((ta / 3) << 16) | ((ta % 3) * 8 + p * 8);
+        sel_hi[ks] = ((tb / 3) << 16) | ((tb % 3) * 8 + p * 8);
+    }
+    const Sub10Prm q = sub10_params(L.prm, o);
+    const f32x4 hb0 = *(const f32x4*)(L.prm + 4 * o);
+    const f32x2 hb1 = *(const f32x2*)(L.prm + 16 + 2 * o);
+    const float norm = (float)(1 / 255.0);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // the u8 row of descriptor r (two pixels per lane: ring columns lane and lane + 64), packed B | G<<8 | R<<16;
+    // outside the plane: 0.  Fetched one step before it is needed so that HBM latency has a whole step to pass.
+    auto fetch_row = [&](int r, unsigned (&px)[2]) {
+        px[0] = 0; px[1] = 0;
+        if (r < nrows) {
+            const int2 e = L.rows[r];
+            const int y = e.x >> 1, x0c = e.y;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int qq = lane + 64 * k, X = x0c - 1 + qq;
+                if (qq < S10_ROWPX && y >= 0 && y < a.h && X >= 0 && X < a.w) {
+                    const uint8_t* sp = a.src + (size_t)y * a.src_stride + (size_t)X * 3;
+                    px[k] = (unsigned)sp[0] | ((unsigned)sp[1] << 8) | ((unsigned)sp[2] << 16);
+                }
+            }
+        }
+    };
+    auto step = [&](const int t, const unsigned (&upx)[2], unsigned (&upx_next)[2]) {
+        S10_STAMP(0);
+        fetch_row(t + 1, upx_next);
+        const int d = t - 2;
+        if (d >= 0 && d < nrows) {
+            const int2 e = L.rows[d];
+            const int ye = __builtin_amdgcn_readfirstlane(e.x), x0c = __builtin_amdgcn_readfirstlane(e.y);
+            const int y = ye >> 1;
+            const bool row_in = y >= 0 && y < a.h;
+            unsigned rb[3];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) rb[dy] = (unsigned)(L.uring - L.smem) + ((d + dy - 1) & 3) * S10_UROWB;
+            f32x4 acc[5][2];
+#pragma unroll
+            for (int f = 0; f < 5; ++f) {
+                acc[f][0] = zero4; acc[f][1] = zero4;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int ra = sel_lo[ks] >> 16, rh = sel_hi[ks] >> 16;
+                    const uint2 lo = *(const uint2*)(L.smem + (ra == 0 ? rb[0] : ra == 1 ? rb[1] : rb[2]) + (sel_lo[ks] & 0xffff) + f * 16 * 8);
+                    const uint2 hi = *(const uint2*)(L.smem + (rh == 0 ? rb[0] : rh == 1 ? rb[1] : rb[2]) + (sel_hi[ks] & 0xffff) + f * 16 * 8);
+                    const half8 b = __builtin_bit_cast(half8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                    acc[f][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wgt[ks][0], b, acc[f][0], 0, 0, 0);
+                    acc[f][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wgt[ks][1], b, acc[f][1], 0, 0, 0);
+                }
+            }
+            S10_STAMP(1);
+            char* const px0 = L.smem + (d & 3) * S10_ROWB + (p + 1) * S10_PIXB + 8 * o;
+            char* const px1 = L.smem + (d & 3) * S10_ROWB + (p + 1) * S10_PIXB + 32 + 4 * o;
+#pragma unroll
+            for (int f = 0; f < 5; ++f) {
+                const int X = x0c + 16 * f + p;
+                const bool inside = row_in && X >= 0 && X < a.w;
+                const f32x4 x0 = __builtin_elementwise_fma(acc[f][0], f32x4{norm, norm, norm, norm}, hb0);
+                const f32x2 x1h = __builtin_elementwise_fma(f32x2{acc[f][1][0], acc[f][1][1]}, f32x2{norm, norm}, hb1);
+                const f32x4 x1 = {x1h[0], x1h[1], 0.f, 0.f};
+                sub10_store<true>(x0, x1, q, px0 + f * 16 * S10_PIXB, px1 + f * 16 * S10_PIXB, inside);
+            }
+        }
+        if (t < nrows) {
+            // the fetched u8 row -> [B, G, R, 0] fp16 in ring row t (outside the plane: zeros, already in upx), and as it
+            // is for the last layer's residual add
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int qq = lane + 64 * k;
+                if (qq < S10_ROWPX) {
+                    const half2v bg = {(_Float16)(float)(upx[k] & 0xff), (_Float16)(float)((upx[k] >> 8) & 0xff)};
+                    const half2v r0 = {(_Float16)(float)((upx[k] >> 16) & 0xff), (_Float16)0.f};
+                    *(uint2*)(L.uring + (t & 3) * S10_UROWB + qq * 8) =
+                        make_uint2(__builtin_bit_cast(unsigned, bg), __builtin_bit_cast(unsigned, r0));
+                    *(unsigned*)(L.resring + ((t & (S10_RES_ROWS - 1)) * S10_ROWPX + qq) * 4) = upx[k];
+                }
+            }
+        }
+        S10_STAMP(2);
+        sub10_barrier();
+    };
+    // two steps per trip: the row fetched during one step is converted at the end of the next
+    unsigned pxa[2], pxb[2];
+    fetch_row(0, pxa);
+    for (int t = 0; t < nsteps; t += 2) {
+        step(t, pxa, pxb);
+        step(t + 1, pxb, pxa);
+    }
+}
+
+// ---- waves 1..8: conv 24 -> 24 (+bias, PReLU);  wave 9 (TAIL): conv 24 -> 3, + input pixel, -> u8 ----
+// LDS reads: a B fragment is one ds_read_b128 per lane (16 pixels x the K octet of the lane's group o).  The hardware
+// serves such a read in groups of 8 lanes of one o and 8 lanes of o^1 ({0-3,12-15} with {20-27}, ...), and 48-byte
+// pixels would make those collide.  Two choices make every read conflict-free: MFMA column p holds pixel S10_PIX(p) --
+// even pixels in the lanes {0-3,12-15}, odd ones in {4-11} -- and the two octets a k-step gives to o, o^1 differ by an
+// even number of 16-byte units (uva_model.h SUB16_OCTET): one half of a group then touches even units only, the other
+// odd ones.
+//
+// Software pipeline: fragment f's epilogue (PReLU, conversion, LDS stores: VALU work) is written after fragment f+1's
+// MFMAs so that the scheduler runs the one under the other.
+__device__ __forceinline__ int sub10_pix(int p) { return p < 4 ? 2 * p : p >= 12 ? 2 * (p - 8) : 2 * (p - 4) + 1; }
+
+template <bool TAIL>
+__device__ __forceinline__ void sub10_body(const Sub10Args& a, const Sub10Lds L, const int stage, const int lane, const int nrows,
+                                           const int nsteps)
+{
+    constexpr int KS = 7, MB = TAIL ? 1 : 2;
+    const int p = lane & 15, o = lane >> 4, pix = sub10_pix(p);
+    const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && lane == 0;
+    (void)stamp;
+    half8 wgt[KS][MB];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) wgt[ks][m] = a.wpk[stage][(ks * MB + m) * 64 + lane];
+    // per k-step: the LDS address this lane's K octet is read from.  They are kept for the row the wave works on and move
+    // one ring row per step.
+    const int lag = sub10_lag(stage);
+    const unsigned in_ring = (unsigned)(stage - 1) * S10_RINGB;
+    unsigned adr[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int oct = min((int)(o == 0 ? SUB16_OCTET[ks][0] : o == 1 ? SUB16_OCTET[ks][1] : o == 2 ? SUB16_OCTET[ks][2] : SUB16_OCTET[ks][3]), 26);
+        const int tap = oct / 3;
+        // the wave's first row is d = 0 (at step t = lag): tap row dy reads ring row (dy - 1) & 3
+        adr[ks] = in_ring + ((tap / 3 - 1) & 3) * S10_ROWB + (tap % 3 + pix) * S10_PIXB + (oct % 3) * 16;
+    }
+    const float* const myprm = L.prm + stage * 96;
+    const Sub10Prm q = sub10_params(myprm, o);
+    const f32x4 binit[2] = {*(const f32x4*)(myprm + 4 * o), f32x4{myprm[16 + 2 * o], myprm[17 + 2 * o], 0.f, 0.f}};
+    char* const out_ring = L.smem + stage * S10_RINGB;
+    const float norm = (float)(1 / 255.0);
+
+    auto mma = [&](const int f, f32x4 (&acc)[MB]) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#if S10_ABLATE == 1
+            const half8 b = wgt[(ks + f) % KS][0];
+#else
+            const half8 b = *(const half8*)(L.smem + adr[ks] + f * 16 * S10_PIXB);
+#endif
+#if S10_ABLATE == 2
+            if (ks == 0) for (int m = 0; m < MB; ++m) acc[m] = binit[m];
+            asm volatile("" :: "v"(b));
+#else
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wgt[ks][m], b, ks == 0 ? binit[m] : acc[m], 0, 0, 0);
+#endif
+        }
+    };
+    for (int t = 0; t < nsteps; ++t) {
+        S10_STAMP(0);
+        const int d = t - lag;
+        if (d >= 0 && d < nrows) {
+            const int2 e = L.rows[d];
+            const int ye = __builtin_amdgcn_readfirstlane(e.x), x0c = __builtin_amdgcn_readfirstlane(e.y);
+            const int yy = ye >> 1;
+            const bool row_in = yy >= 0 && yy < a.h;
+            // epilogue of fragment f from acc
+            auto epi = [&](const int f, const f32x4 (&acc)[MB], auto masked) {
+                const int c = 16 * f + pix, X = x0c + c;
+                if constexpr (!TAIL) {
+                    // PReLU, zero outside the plane, fp16 -> this layer's ring row d (ring column = computed column + 1)
+                    char* const px = out_ring + (d & 3) * S10_ROWB + (pix + 1 + 16 * f) * S10_PIXB;
+                    sub10_store<decltype(masked)::value>(acc[0], acc[MB - 1], q, px + 8 * o, px + 32 + 4 * o, row_in && X >= 0 && X < a.w);
+                } else {
+                    // + input pixel (Interp x1 = identity, BinaryOp add; left in LDS by the head wave), *255, cv2
+                    // convertTo(CV_8U); only rows that are written out and only the columns this strip gets right
+                    if ((ye & 1) && row_in && o == 0 && c >= S10_NL && c < S10_WC - S10_NL && X >= 0 && X < a.w) {
+                        const unsigned res = *(const unsigned*)(L.resring + ((d & (S10_RES_ROWS - 1)) * S10_ROWPX + c + 1) * 4);
+                        uint8_t* dp = a.dst + (size_t)yy * a.dst_stride + (size_t)X * 3;
+                        // v_cvt_pk_u8_f32 rounds half to even and saturates: cv2's convertTo(CV_8U) in one instruction
+                        unsigned out = 0;
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            const float r = (float)((res >> (8 * j)) & 0xff) * norm;
+                            const float v = acc[0][j] + r;
+                            out = __builtin_amdgcn_cvt_pk_u8_f32(v * 255.0f, j, out);
+                        }
+                        dp[0] = (uint8_t)out; dp[1] = (uint8_t)(out >> 8); dp[2] = (uint8_t)(out >> 16);
+                    }
+                }
+            };
+            auto row = [&](auto masked) {
+                f32x4 a0[MB], a1[MB];
+                mma(0, a0);
+                mma(1, a1);
+                epi(0, a0, masked);
+                mma(2, a0);
+                epi(1, a1, masked);
+                mma(3, a1);
+                epi(2, a0, masked);
+                mma(4, a0);
+                epi(3, a1, masked);
+                epi(4, a0, masked);
+            };
+            if (!TAIL && row_in && x0c >= 0 && x0c + S10_WC <= a.w) row(std::false_type{});
+            else row(std::true_type{});
+        }
+        S10_STAMP(1);
+        if (d >= 0) {
+            // next row: every address one ring row on, wrapping after the fourth
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const unsigned n0 = adr[ks] + S10_ROWB;
+                adr[ks] = n0 >= in_ring + S10_RINGB ? n0 - S10_RINGB : n0;
+            }
+        }
+        S10_STAMP(2);
+        sub10_barrier();
+    }
+}
+
+__global__ __launch_bounds__(64 * S10_NL, 1) void sub10_kernel(Sub10Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Sub10Lds L = sub10_lds(smem);
+    const int stage = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int nrows = __builtin_amdgcn_readfirstlane(a.nrows[blockIdx.x]);
+    if (nrows <= 0) return;
+    // this workgroup's row descriptors live in LDS, 8 bytes each: {2y + emit, x0}; every wave reads one (or two) per step
+    {
+        const uint4* const grows = a.rows + (size_t)blockIdx.x * a.max_rows;
+        for (int i = threadIdx.x; i < nrows; i += 64 * S10_NL) {
+            const uint4 e = grows[i];
+            L.rows[i] = make_int2((int)e.x * 2 + (int)(e.z & 1), (int)e.y);
+        }
+    }
+    // rings start as zeros (margins and pipeline fill are never written: no NaN patterns may sit there)
+    for (int i = threadIdx.x; i < ((S10_NL - 1) * S10_RINGB + S10_URINGB) / 16; i += 64 * S10_NL)
+        ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);
+    if (lane < 32) {
+        const float b = a.bias[stage][lane];
+        const float sl = stage + 1 < S10_NL ? a.slope[stage][lane] : 0.f;
+        L.prm[stage * 96 + lane] = b;
+        L.prm[stage * 96 + 32 + lane] = sl;
+    }
+    __syncthreads();
+    // every wave runs the same number of steps = barriers, whatever code it sits in
+    const int nsteps = (nrows + S10_DRAIN + 1) & ~1;
+    // the two light waves go first on their SIMDs: their long scalar-ish epilogues (u8 conversion, byte stores) then
+    // run under the other waves' MFMAs instead of after them
+    if (stage == 0 || stage == S10_NL - 1) __builtin_amdgcn_s_setprio(3);
+    if (stage == 0) sub10_head(a, L, lane, nrows, nsteps);
+    else if (stage == S10_NL - 1) sub10_body<true>(a, L, stage, lane, nrows, nsteps);
+    else sub10_body<false>(a, L, stage, lane, nrows, nsteps);
 }
 
 // ----------------------------------------------------------------------------------------------

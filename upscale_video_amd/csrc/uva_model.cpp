@@ -306,7 +306,8 @@ void pack_head(const ConvWeights& c, std::vector<uint16_t>& out, int* mf_out)
     if (mf_out) *mf_out = mf;
 }
 
-void pack_sub16(const ConvWeights& c, std::vector<uint16_t>& out, int* ks_out, int* mb_out)
+void pack_sub16(const ConvWeights& c, std::vector<uint16_t>& out, int* ks_out, int* mb_out, const float* in_sign,
+                const float* out_sign)
 {
     const bool head = c.cin == 3;
     const int ks_n = head ? 2 : 7, mbn = (c.cout + 15) / 16;
@@ -314,14 +315,19 @@ void pack_sub16(const ConvWeights& c, std::vector<uint16_t>& out, int* ks_out, i
     for (int ks = 0; ks < ks_n; ++ks)
         for (int mb = 0; mb < mbn; ++mb)
             for (int lane = 0; lane < 64; ++lane) {
-                const int co = 16 * mb + (lane & 15), ko = 4 * ks + (lane >> 4);
-                if (co >= c.cout) continue;
+                const int i = lane & 15, o = lane >> 4, ko = 4 * ks + o;
+                // 24 output channels: block 1 holds channels 16..23 in rows 4q, 4q+1 (q = 0..3), so that every lane of
+                // the MFMA result (rows 4q..4q+3) owns two real channels instead of four or none
+                int co = 16 * mb + i;
+                if (c.cout == 24 && mb == 1) co = (i & 3) < 2 ? 16 + 2 * (i >> 2) + (i & 3) : -1;
+                if (co < 0 || co >= c.cout) continue;
                 for (int e = 0; e < 8; ++e) {
                     int tap, ci;
                     if (head) { tap = 2 * ko + (e >> 2); ci = e & 3; if (ci >= 3) continue; }
-                    else { tap = ko / 3; ci = 8 * (ko % 3) + e; }
+                    else { const int oct = SUB16_OCTET[ks][o]; tap = oct / 3; ci = 8 * (oct % 3) + e; }
                     if (tap >= 9) continue;
-                    out[(((size_t)ks * mbn + mb) * 64 + lane) * 8 + e] = f32_to_f16_bits(c.w[((size_t)co * c.cin + ci) * 9 + tap]);
+                    const float sg = (in_sign ? in_sign[ci] : 1.f) * (out_sign ? out_sign[co] : 1.f);   // +-1: exact
+                    out[(((size_t)ks * mbn + mb) * 64 + lane) * 8 + e] = f32_to_f16_bits(sg * c.w[((size_t)co * c.cin + ci) * 9 + tap]);
                 }
             }
     if (ks_out) *ks_out = ks_n;

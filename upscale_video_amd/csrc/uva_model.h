@@ -51,9 +51,18 @@ void pack_tail64(const ConvWeights& c, std::vector<uint16_t>& out);
 void pack_head(const ConvWeights& c, std::vector<uint16_t>& out, int* mf_out);
 
 // sub10_kernel (the whole 24-feature 1x net in one launch, v_mfma_f32_16x16x32_f16): image [k-step][m-block][64 lanes][8],
-// lane = (o << 4) | i supplies output channel 16*mb + i and K octet ko = 4*ks + o.
-//   cin = 24 (trunk, tail): ko = 3*tap + channel octet, 27 octets -> 7 k-steps; cout padded to 16*mbn;
-//   cin = 3  (head):        octet ko holds taps 2ko and 2ko+1 as [B, G, R, 0] each, 5 octets -> 2 k-steps.
-void pack_sub16(const ConvWeights& c, std::vector<uint16_t>& out, int* ks_out, int* mb_out);
+// lane = (o << 4) | i supplies output row i of block mb and the K octet of slot (ks, o):
+//   cin = 24 (trunk, tail): octet id = 3*tap + channel octet, 27 octets in 7 k-steps as SUB16_OCTET[ks][o] (27 = none);
+//   cin = 3  (head):        slot 4ks + o holds taps 2(4ks+o) and 2(4ks+o)+1 as [B, G, R, 0] each, 5 octets -> 2 k-steps;
+//   cout = 24: block 1 holds channels 16..23 in rows 4q, 4q+1 (channel 16 + 2q + j), rows 4q+2, 4q+3 are zero.
+// SUB16_OCTET pairs, in the lanes o = 0,1 and o = 2,3 of a k-step, octets whose (column + channel octet) parity is the
+// same: the kernel's 16-byte LDS reads of 48-byte pixels are then conflict-free (csrc/uva_kernels.hip.h sub10_body).
+// in_sign[cin] / out_sign[cout] (+-1, may be null) flip the sign of input / output channels: the kernel computes PReLU
+// as max(x, slope*x), which is PReLU only for slope <= 1 -- a channel with a larger slope is computed negated
+// (max(-x, -slope*x) = -PReLU(x), every step exact) and the next layer's weights take the sign back.
+constexpr unsigned char SUB16_OCTET[7][4] = {{0, 2, 4, 6},     {8, 9, 11, 13},   {15, 17, 18, 20}, {22, 24, 26, 27},
+                                             {1, 3, 5, 7},     {10, 12, 14, 16}, {19, 21, 23, 25}};
+void pack_sub16(const ConvWeights& c, std::vector<uint16_t>& out, int* ks_out, int* mb_out, const float* in_sign = nullptr,
+                const float* out_sign = nullptr);
 
 }  // namespace uva
