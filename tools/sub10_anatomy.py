@@ -16,13 +16,13 @@ cap = 4096
 buf = np.zeros(cap * 8, np.uint64)
 n, ms = ctypes.c_int(), ctypes.c_float()
 _lib.check(_lib.load().uva_net_debug_trunk_stamps(net._h, buf.ctypes.data, cap, n, 7, ms))
-s = buf[:40 * n.value].reshape(-1, 10, 4).astype(np.int64)
+s = buf[:48 * n.value].reshape(-1, 12, 4).astype(np.int64)
 s = s[s[:, 0, 0] > 0]
 print(f"sub10_kernel: {ms.value * 1e3:.1f} us per launch, workgroup 0: {len(s)} steps; {(s[-1,:,2].max()-s[0,:,0].min())/len(s):.0f} ticks per step")
 mid = s[30:-30]
 period = np.diff(mid[:, 0, 0])
 print(f"  step period: median {np.median(period):.0f} min {period.min()} max {period.max()}")
 print("  wave: start skew | start->MFMAs done | ->barrier | barrier wait (next start - barrier)   [medians over the steady part]")
-for w in range(10):
+for w in range(12):
     st = mid[:-1, w, 0]; mf = mid[:-1, w, 1]; br = mid[:-1, w, 2]; nx = mid[1:, w, 0]
     print(f"  {w}: {np.median(st - mid[:-1, :, 0].min(axis=1)):6.0f} | {np.median(mf - st):6.0f} | {np.median(br - mf):6.0f} | {np.median(nx - br):6.0f}")

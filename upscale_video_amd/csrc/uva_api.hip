@@ -522,7 +522,7 @@ int launch_sub10(uva_net* n, Workspace* ws, const void* src, size_t src_stride, 
         HIP_TRY(hipFuncSetAttribute((const void*)sub10_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         n->attr_set[10] = true;
     }
-    hipLaunchKernelGGL(sub10_kernel, dim3(ws->grid10), dim3(64 * S10_NL), lds, n->stream, a);
+    hipLaunchKernelGGL(sub10_kernel, dim3(ws->grid10), dim3(64 * S10_NW), lds, n->stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1709,11 +1709,11 @@ int uva_net_debug_trunk_stamps(uva_net* n, unsigned long long* out, int max_tile
         return rc3;
     }
     if (ablate == 7) {
-        // sub10_kernel (the whole 1x net): out[(step*10 + wave)*4 + {0 step start, 1 MFMAs done, 2 at the barrier}] of
+        // sub10_kernel (the whole 1x net): out[(step*12 + wave)*4 + {0 step start, 1 MFMAs done, 2 at the barrier}] of
         // workgroup 0 (max_tiles*8 words must hold 40 per step); *tiles = steps
         if (n->last.f32 || !n->last.dst || ws->planes.size() != 1) { (void)hipFree(d); return fail("sub10 stamps need a previous whole-frame uva_net_process_u8 call"); }
         int rc7 = launch_sub10(n, ws, n->last.src, n->last.src_stride, n->last.dst, n->last.dst_stride);
-        if (rc7 == 0 && (size_t)(ws->max_rows10 + S10_DRAIN + 2) * 40 > (size_t)max_tiles * 8) { (void)hipFree(d); return fail("max_tiles too small"); }
+        if (rc7 == 0 && (size_t)(ws->max_rows10 + S10_DRAIN + 2) * 4 * S10_NW > (size_t)max_tiles * 8) { (void)hipFree(d); return fail("max_tiles too small"); }
         HIP_TRY(hipEventRecord(e0, n->stream));
         for (int r = 0; r < 50 && !rc7; ++r) rc7 = launch_sub10(n, ws, n->last.src, n->last.src_stride, n->last.dst, n->last.dst_stride);
         HIP_TRY(hipEventRecord(e1, n->stream));

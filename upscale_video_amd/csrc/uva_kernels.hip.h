@@ -996,7 +996,8 @@ __global__ __launch_bounds__(256, 2) void pair24_kernel(ConvArgs a)
 // the tail wave adds the input pixel, *255, rounds half-even, saturates and stores 3 bytes per pixel.
 // ----------------------------------------------------------------------------------------------
 constexpr int S10_WC = 80;                       // computed columns per strip (five 16-pixel fragments)
-constexpr int S10_NL = 10;                       // layers = pipeline stages = waves
+constexpr int S10_NL = 10;                       // layers = pipeline stages
+constexpr int S10_NW = 12;                       // waves: 8 trunk layers, the first and the last layer on two waves each
 constexpr int S10_VALID = S10_WC - 2 * S10_NL;   // columns of the strip the last layer gets right
 constexpr int S10_ROWPX = S10_WC + 2;            // ring row: one margin pixel either side (never written)
 constexpr int S10_PIXB = 48;
@@ -1046,17 +1047,10 @@ __device__ __forceinline__ Sub10Lds sub10_lds(char* smem)
     l.rows = (int2*)(l.resring + S10_RESB);
     return l;
 }
-#ifndef S10_ABLATE
-#define S10_ABLATE 0
-#endif
-#if S10_ABLATE == 4
-__device__ __forceinline__ void sub10_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-#else
 __device__ __forceinline__ void sub10_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-#endif
 
 #ifdef UVA_INSTRUMENT
-#define S10_STAMP(k) do { if (stamp) a.dbg[(t * S10_NL + stage) * 4 + (k)] = UVA_MEMTIME(); } while (0)
+#define S10_STAMP(k) do { if (stamp) a.dbg[(t * S10_NW + wave) * 4 + (k)] = UVA_MEMTIME(); } while (0)
 #else
 #define S10_STAMP(k) do { } while (0)
 #endif
@@ -1093,21 +1087,20 @@ __device__ __forceinline__ void sub10_store(const f32x4 x0, const f32x4 x1, cons
     w0.y = __builtin_bit_cast(unsigned, __builtin_convertvector(vb, half2v));
     unsigned w1 = __builtin_bit_cast(unsigned, __builtin_convertvector(vc, half2v));
     if (MASKED && !inside) { w0 = make_uint2(0, 0); w1 = 0; }
-#if S10_ABLATE == 3
-    asm volatile("" :: "v"(x0), "v"(x1));
-#else
     *(uint2*)px0 = w0;
     *(unsigned*)px1 = w1;
-#endif
 }
 
-// ---- wave 0: u8 rows in, conv 3 -> 24 (+bias, PReLU) ----
-__device__ __forceinline__ void sub10_head(const Sub10Args& a, const Sub10Lds L, const int lane, const int nrows, const int nsteps)
+// ---- two waves: u8 rows in, conv 3 -> 24 (+bias, PReLU); HALF 0: ring columns 0..40, fragments 0..2; HALF 1: the rest ----
+template <int HALF>
+__device__ __forceinline__ void sub10_head(const Sub10Args& a, const Sub10Lds L, const int wave, const int lane, const int nrows,
+                                           const int nsteps)
 {
-    constexpr int stage = 0;
+    constexpr int F0 = HALF ? 3 : 0, F1 = HALF ? 5 : 3, NF = F1 - F0;
+    constexpr int Q0 = HALF ? S10_ROWPX / 2 : 0, QN = S10_ROWPX / 2;     // one ring column per lane (41 lanes)
     const int p = lane & 15, o = lane >> 4;
     const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && lane == 0;
-    (void)stamp; (void)stage;
+    (void)stamp;
     half8 wgt[2][2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -1128,22 +1121,19 @@ __device__ __forceinline__ void sub10_head(const Sub10Args& a, const Sub10Lds L,
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     // the u8 row of descriptor r (two pixels per lane: ring columns lane and lane + 64), packed B | G<<8 | R<<16;
     // outside the plane: 0.  Fetched one step before it is needed so that HBM latency has a whole step to pass.
-    auto fetch_row = [&](int r, unsigned (&px)[2]) {
-        px[0] = 0; px[1] = 0;
+    auto fetch_row = [&](int r, unsigned& px) {
+        px = 0;
         if (r < nrows) {
             const int2 e = L.rows[r];
             const int y = e.x >> 1, x0c = e.y;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int qq = lane + 64 * k, X = x0c - 1 + qq;
-                if (qq < S10_ROWPX && y >= 0 && y < a.h && X >= 0 && X < a.w) {
-                    const uint8_t* sp = a.src + (size_t)y * a.src_stride + (size_t)X * 3;
-                    px[k] = (unsigned)sp[0] | ((unsigned)sp[1] << 8) | ((unsigned)sp[2] << 16);
-                }
+            const int qq = Q0 + lane, X = x0c - 1 + qq;
+            if (lane < QN && y >= 0 && y < a.h && X >= 0 && X < a.w) {
+                const uint8_t* sp = a.src + (size_t)y * a.src_stride + (size_t)X * 3;
+                px = (unsigned)sp[0] | ((unsigned)sp[1] << 8) | ((unsigned)sp[2] << 16);
             }
         }
     };
-    auto step = [&](const int t, const unsigned (&upx)[2], unsigned (&upx_next)[2]) {
+    auto step = [&](const int t, const unsigned upx, unsigned& upx_next) {
         S10_STAMP(0);
         fetch_row(t + 1, upx_next);
         const int d = t - 2;
@@ -1155,53 +1145,51 @@ __device__ __forceinline__ void sub10_head(const Sub10Args& a, const Sub10Lds L,
             unsigned rb[3];
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) rb[dy] = (unsigned)(L.uring - L.smem) + ((d + dy - 1) & 3) * S10_UROWB;
-            f32x4 acc[5][2];
+            f32x4 acc[NF][2];
 #pragma unroll
-            for (int f = 0; f < 5; ++f) {
+            for (int f = 0; f < NF; ++f) {
                 acc[f][0] = zero4; acc[f][1] = zero4;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const int ra = sel_lo[ks] >> 16, rh = sel_hi[ks] >> 16;
-                    const uint2 lo = *(const uint2*)(L.smem + (ra == 0 ? rb[0] : ra == 1 ? rb[1] : rb[2]) + (sel_lo[ks] & 0xffff) + f * 16 * 8);
-                    const uint2 hi = *(const uint2*)(L.smem + (rh == 0 ? rb[0] : rh == 1 ? rb[1] : rb[2]) + (sel_hi[ks] & 0xffff) + f * 16 * 8);
+                    const uint2 lo = *(const uint2*)(L.smem + (ra == 0 ? rb[0] : ra == 1 ? rb[1] : rb[2]) + (sel_lo[ks] & 0xffff) + (F0 + f) * 16 * 8);
+                    const uint2 hi = *(const uint2*)(L.smem + (rh == 0 ? rb[0] : rh == 1 ? rb[1] : rb[2]) + (sel_hi[ks] & 0xffff) + (F0 + f) * 16 * 8);
                     const half8 b = __builtin_bit_cast(half8, make_uint4(lo.x, lo.y, hi.x, hi.y));
                     acc[f][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wgt[ks][0], b, acc[f][0], 0, 0, 0);
                     acc[f][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wgt[ks][1], b, acc[f][1], 0, 0, 0);
                 }
             }
             S10_STAMP(1);
-            char* const px0 = L.smem + (d & 3) * S10_ROWB + (p + 1) * S10_PIXB + 8 * o;
-            char* const px1 = L.smem + (d & 3) * S10_ROWB + (p + 1) * S10_PIXB + 32 + 4 * o;
+            char* const px0 = L.smem + (d & 3) * S10_ROWB + (p + 1 + 16 * F0) * S10_PIXB + 8 * o;
+            char* const px1 = L.smem + (d & 3) * S10_ROWB + (p + 1 + 16 * F0) * S10_PIXB + 32 + 4 * o;
+            auto epi = [&](auto masked) {
 #pragma unroll
-            for (int f = 0; f < 5; ++f) {
-                const int X = x0c + 16 * f + p;
-                const bool inside = row_in && X >= 0 && X < a.w;
-                const f32x4 x0 = __builtin_elementwise_fma(acc[f][0], f32x4{norm, norm, norm, norm}, hb0);
-                const f32x2 x1h = __builtin_elementwise_fma(f32x2{acc[f][1][0], acc[f][1][1]}, f32x2{norm, norm}, hb1);
-                const f32x4 x1 = {x1h[0], x1h[1], 0.f, 0.f};
-                sub10_store<true>(x0, x1, q, px0 + f * 16 * S10_PIXB, px1 + f * 16 * S10_PIXB, inside);
-            }
-        }
-        if (t < nrows) {
-            // the fetched u8 row -> [B, G, R, 0] fp16 in ring row t (outside the plane: zeros, already in upx), and as it
-            // is for the last layer's residual add
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int qq = lane + 64 * k;
-                if (qq < S10_ROWPX) {
-                    const half2v bg = {(_Float16)(float)(upx[k] & 0xff), (_Float16)(float)((upx[k] >> 8) & 0xff)};
-                    const half2v r0 = {(_Float16)(float)((upx[k] >> 16) & 0xff), (_Float16)0.f};
-                    *(uint2*)(L.uring + (t & 3) * S10_UROWB + qq * 8) =
-                        make_uint2(__builtin_bit_cast(unsigned, bg), __builtin_bit_cast(unsigned, r0));
-                    *(unsigned*)(L.resring + ((t & (S10_RES_ROWS - 1)) * S10_ROWPX + qq) * 4) = upx[k];
+                for (int f = 0; f < NF; ++f) {
+                    const int X = x0c + 16 * (F0 + f) + p;
+                    const f32x4 x0 = __builtin_elementwise_fma(acc[f][0], f32x4{norm, norm, norm, norm}, hb0);
+                    const f32x2 x1h = __builtin_elementwise_fma(f32x2{acc[f][1][0], acc[f][1][1]}, f32x2{norm, norm}, hb1);
+                    const f32x4 x1 = {x1h[0], x1h[1], 0.f, 0.f};
+                    sub10_store<decltype(masked)::value>(x0, x1, q, px0 + f * 16 * S10_PIXB, px1 + f * 16 * S10_PIXB,
+                                                         row_in && X >= 0 && X < a.w);
                 }
-            }
+            };
+            if (row_in && x0c >= 0 && x0c + S10_WC <= a.w) epi(std::false_type{});
+            else epi(std::true_type{});
+        }
+        if (t < nrows && lane < QN) {
+            // the fetched u8 pixel -> [B, G, R, 0] fp16 in ring row t (outside the plane: zeros, already in upx), and as it
+            // is for the last layer's residual add
+            const int qq = Q0 + lane;
+            const half2v bg = {(_Float16)(float)(upx & 0xff), (_Float16)(float)((upx >> 8) & 0xff)};
+            const half2v r0 = {(_Float16)(float)((upx >> 16) & 0xff), (_Float16)0.f};
+            *(uint2*)(L.uring + (t & 3) * S10_UROWB + qq * 8) = make_uint2(__builtin_bit_cast(unsigned, bg), __builtin_bit_cast(unsigned, r0));
+            *(unsigned*)(L.resring + ((t & (S10_RES_ROWS - 1)) * S10_ROWPX + qq) * 4) = upx;
         }
         S10_STAMP(2);
         sub10_barrier();
     };
     // two steps per trip: the row fetched during one step is converted at the end of the next
-    unsigned pxa[2], pxb[2];
+    unsigned pxa, pxb;
     fetch_row(0, pxa);
     for (int t = 0; t < nsteps; t += 2) {
         step(t, pxa, pxb);
@@ -1209,21 +1197,101 @@ __device__ __forceinline__ void sub10_head(const Sub10Args& a, const Sub10Lds L,
     }
 }
 
-// ---- waves 1..8: conv 24 -> 24 (+bias, PReLU);  wave 9 (TAIL): conv 24 -> 3, + input pixel, -> u8 ----
+// ---- eight waves: conv 24 -> 24 (+bias, PReLU);  two waves (TAIL): conv 24 -> 3, + input pixel, -> u8 ----
 // LDS reads: a B fragment is one ds_read_b128 per lane (16 pixels x the K octet of the lane's group o).  The hardware
 // serves such a read in groups of 8 lanes of one o and 8 lanes of o^1 ({0-3,12-15} with {20-27}, ...), and 48-byte
-// pixels would make those collide.  Two choices make every read conflict-free: MFMA column p holds pixel S10_PIX(p) --
+// pixels would make those collide.  Two choices make every read conflict-free: MFMA column p holds pixel sub10_pix(p) --
 // even pixels in the lanes {0-3,12-15}, odd ones in {4-11} -- and the two octets a k-step gives to o, o^1 differ by an
 // even number of 16-byte units (uva_model.h SUB16_OCTET): one half of a group then touches even units only, the other
 // odd ones.
-//
-// Software pipeline: fragment f's epilogue (PReLU, conversion, LDS stores: VALU work) is written after fragment f+1's
-// MFMAs so that the scheduler runs the one under the other.
 __device__ __forceinline__ int sub10_pix(int p) { return p < 4 ? 2 * p : p >= 12 ? 2 * (p - 8) : 2 * (p - 4) + 1; }
 
-template <bool TAIL>
-__device__ __forceinline__ void sub10_body(const Sub10Args& a, const Sub10Lds L, const int stage, const int lane, const int nrows,
-                                           const int nsteps)
+// One row of one layer, fragments F0..F1-1.  The rings are handed over as __restrict__ pointers -- `rin` (plus the
+// per-k-step offsets adr[]) is only read, `px0` / `px1` (this lane's 8 + 4 bytes of fragment 0's pixel in the output ring
+// row) only written -- so that LDS reads may move above the previous fragment's LDS stores.
+//
+// LDS reads run seven k-steps ahead of their MFMAs: bq[ks] holds the B operand of k-step ks and is refilled for the next
+// fragment as soon as it has been used (sched_group_barrier pins "two MFMAs, one read"; left to itself the scheduler
+// either waits for every read right after issuing it or hoists all of them and spills).  Epilogues (PReLU, conversion,
+// stores) follow one fragment behind and pile up behind the last MFMAs; the SIMD's other waves fill the matrix pipe
+// meanwhile.  Measured and dropped (profiles/r02_sub10_experiments.txt): epilogue arithmetic pinned between the MFMAs,
+// the first operands of the next row fetched before the barrier, a half-step phase shift between the SIMD's two trunk
+// waves, 8-byte reads with swapped halves instead of the conflict-free 16-byte ones.
+template <bool TAIL, int F0, int F1, bool MASKED, int KS, int MB>
+__device__ __forceinline__ void sub10_row(const char* __restrict__ rin, char* __restrict__ px0, char* __restrict__ px1,
+                                          const char* __restrict__ res, uint8_t* __restrict__ dst, const unsigned (&adr)[KS],
+                                          const half8 (&wgt)[KS][MB], const f32x4 (&binit)[2], const Sub10Prm& q, const int x0c,
+                                          const int w, const bool row_in, const bool emit, const int pix, const int o)
+{
+    const float norm = (float)(1 / 255.0);
+    half8 bq[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) bq[ks] = *(const half8*)(rin + adr[ks] + F0 * 16 * S10_PIXB);
+    __builtin_amdgcn_sched_group_barrier(0x100, KS, 0);
+    auto mma = [&](const int f, f32x4 (&acc)[MB]) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wgt[ks][m], bq[ks], ks == 0 ? binit[m] : acc[m], 0, 0, 0);
+            if (f + 1 < F1) bq[ks] = *(const half8*)(rin + adr[ks] + (f + 1) * 16 * S10_PIXB);
+            __builtin_amdgcn_sched_group_barrier(0x008, MB, 0);
+            if (f + 1 < F1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+    };
+    auto epi = [&](const int f, const f32x4 (&acc)[MB]) {
+        const int c = 16 * f + pix, X = x0c + c;
+        if constexpr (!TAIL) {
+            // PReLU, zero outside the plane, fp16 -> this layer's ring row (ring column = computed column + 1)
+            sub10_store<MASKED>(acc[0], acc[MB - 1], q, px0 + f * 16 * S10_PIXB, px1 + f * 16 * S10_PIXB, row_in && X >= 0 && X < w);
+        } else {
+            // + input pixel (Interp x1 = identity, BinaryOp add; left in LDS by the head waves), *255, cv2 convertTo(CV_8U);
+            // only rows that are written out and only the columns this strip gets right
+            if (emit && row_in && o == 0 && c >= S10_NL && c < S10_WC - S10_NL && X >= 0 && X < w) {
+                const unsigned r8 = *(const unsigned*)(res + f * 16 * 4);
+                uint8_t* dp = dst + f * 16 * 3;
+                // v_cvt_pk_u8_f32 rounds half to even and saturates: cv2's convertTo(CV_8U) in one instruction
+                unsigned out = 0;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float r = (float)((r8 >> (8 * j)) & 0xff) * norm;
+                    const float v = acc[0][j] + r;
+                    out = __builtin_amdgcn_cvt_pk_u8_f32(v * 255.0f, j, out);
+                }
+                dp[0] = (uint8_t)out; dp[1] = (uint8_t)(out >> 8); dp[2] = (uint8_t)(out >> 16);
+            }
+        }
+    };
+    f32x4 a0[MB], a1[MB];
+    if constexpr (F1 - F0 == 5) {
+        mma(0, a0);
+        mma(1, a1);
+        epi(0, a0);
+        mma(2, a0);
+        epi(1, a1);
+        mma(3, a1);
+        epi(2, a0);
+        mma(4, a0);
+        epi(3, a1);
+        epi(4, a0);
+    } else if constexpr (F1 - F0 == 3) {
+        mma(F0, a0);
+        mma(F0 + 1, a1);
+        epi(F0, a0);
+        mma(F0 + 2, a0);
+        epi(F0 + 1, a1);
+        epi(F0 + 2, a0);
+    } else {
+        mma(F0, a0);
+        mma(F0 + 1, a1);
+        epi(F0, a0);
+        epi(F0 + 1, a1);
+    }
+}
+
+template <bool TAIL, int F0, int F1>
+__device__ __forceinline__ void sub10_body(const Sub10Args& a, const Sub10Lds L, const int wave, const int stage, const int lane,
+                                           const int nrows, const int nsteps)
 {
     constexpr int KS = 7, MB = TAIL ? 1 : 2;
     const int p = lane & 15, o = lane >> 4, pix = sub10_pix(p);
@@ -1234,8 +1302,8 @@ __device__ __forceinline__ void sub10_body(const Sub10Args& a, const Sub10Lds L,
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int m = 0; m < MB; ++m) wgt[ks][m] = a.wpk[stage][(ks * MB + m) * 64 + lane];
-    // per k-step: the LDS address this lane's K octet is read from.  They are kept for the row the wave works on and move
-    // one ring row per step.
+    // per k-step: the LDS address this lane's K octet is read from.  They are kept for the row the wave works on next and
+    // move one ring row per step.
     const int lag = sub10_lag(stage);
     const unsigned in_ring = (unsigned)(stage - 1) * S10_RINGB;
     unsigned adr[KS];
@@ -1250,77 +1318,24 @@ __device__ __forceinline__ void sub10_body(const Sub10Args& a, const Sub10Lds L,
     const Sub10Prm q = sub10_params(myprm, o);
     const f32x4 binit[2] = {*(const f32x4*)(myprm + 4 * o), f32x4{myprm[16 + 2 * o], myprm[17 + 2 * o], 0.f, 0.f}};
     char* const out_ring = L.smem + stage * S10_RINGB;
-    const float norm = (float)(1 / 255.0);
 
-    auto mma = [&](const int f, f32x4 (&acc)[MB]) {
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-#if S10_ABLATE == 1
-            const half8 b = wgt[(ks + f) % KS][0];
-#else
-            const half8 b = *(const half8*)(L.smem + adr[ks] + f * 16 * S10_PIXB);
-#endif
-#if S10_ABLATE == 2
-            if (ks == 0) for (int m = 0; m < MB; ++m) acc[m] = binit[m];
-            asm volatile("" :: "v"(b));
-#else
-#pragma unroll
-            for (int m = 0; m < MB; ++m)
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wgt[ks][m], b, ks == 0 ? binit[m] : acc[m], 0, 0, 0);
-#endif
-        }
-    };
+    int2 desc = make_int2(0, 0);        // the descriptor of the next step's row, fetched a step ahead
     for (int t = 0; t < nsteps; ++t) {
         S10_STAMP(0);
         const int d = t - lag;
         if (d >= 0 && d < nrows) {
-            const int2 e = L.rows[d];
-            const int ye = __builtin_amdgcn_readfirstlane(e.x), x0c = __builtin_amdgcn_readfirstlane(e.y);
+            const int ye = __builtin_amdgcn_readfirstlane(desc.x), x0c = __builtin_amdgcn_readfirstlane(desc.y);
             const int yy = ye >> 1;
             const bool row_in = yy >= 0 && yy < a.h;
-            // epilogue of fragment f from acc
-            auto epi = [&](const int f, const f32x4 (&acc)[MB], auto masked) {
-                const int c = 16 * f + pix, X = x0c + c;
-                if constexpr (!TAIL) {
-                    // PReLU, zero outside the plane, fp16 -> this layer's ring row d (ring column = computed column + 1)
-                    char* const px = out_ring + (d & 3) * S10_ROWB + (pix + 1 + 16 * f) * S10_PIXB;
-                    sub10_store<decltype(masked)::value>(acc[0], acc[MB - 1], q, px + 8 * o, px + 32 + 4 * o, row_in && X >= 0 && X < a.w);
-                } else {
-                    // + input pixel (Interp x1 = identity, BinaryOp add; left in LDS by the head wave), *255, cv2
-                    // convertTo(CV_8U); only rows that are written out and only the columns this strip gets right
-                    if ((ye & 1) && row_in && o == 0 && c >= S10_NL && c < S10_WC - S10_NL && X >= 0 && X < a.w) {
-                        const unsigned res = *(const unsigned*)(L.resring + ((d & (S10_RES_ROWS - 1)) * S10_ROWPX + c + 1) * 4);
-                        uint8_t* dp = a.dst + (size_t)yy * a.dst_stride + (size_t)X * 3;
-                        // v_cvt_pk_u8_f32 rounds half to even and saturates: cv2's convertTo(CV_8U) in one instruction
-                        unsigned out = 0;
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) {
-                            const float r = (float)((res >> (8 * j)) & 0xff) * norm;
-                            const float v = acc[0][j] + r;
-                            out = __builtin_amdgcn_cvt_pk_u8_f32(v * 255.0f, j, out);
-                        }
-                        dp[0] = (uint8_t)out; dp[1] = (uint8_t)(out >> 8); dp[2] = (uint8_t)(out >> 16);
-                    }
-                }
-            };
-            auto row = [&](auto masked) {
-                f32x4 a0[MB], a1[MB];
-                mma(0, a0);
-                mma(1, a1);
-                epi(0, a0, masked);
-                mma(2, a0);
-                epi(1, a1, masked);
-                mma(3, a1);
-                epi(2, a0, masked);
-                mma(4, a0);
-                epi(3, a1, masked);
-                epi(4, a0, masked);
-            };
-            if (!TAIL && row_in && x0c >= 0 && x0c + S10_WC <= a.w) row(std::false_type{});
-            else row(std::true_type{});
-        }
-        S10_STAMP(1);
-        if (d >= 0) {
+            char* const px = out_ring + (d & 3) * S10_ROWB + (pix + 1) * S10_PIXB;
+            const char* const res = L.resring + ((d & (S10_RES_ROWS - 1)) * S10_ROWPX + pix + 1) * 4;
+            uint8_t* const dst = a.dst + (size_t)yy * a.dst_stride + (size_t)(x0c + pix) * 3;
+            if (!TAIL && row_in && x0c >= 0 && x0c + S10_WC <= a.w)
+                sub10_row<TAIL, F0, F1, false, KS, MB>(L.smem, px + 8 * o, px + 32 + 4 * o, res, dst, adr, wgt, binit, q, x0c, a.w,
+                                                       row_in, (ye & 1) != 0, pix, o);
+            else
+                sub10_row<TAIL, F0, F1, true, KS, MB>(L.smem, px + 8 * o, px + 32 + 4 * o, res, dst, adr, wgt, binit, q, x0c, a.w,
+                                                      row_in, (ye & 1) != 0, pix, o);
             // next row: every address one ring row on, wrapping after the fourth
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -1329,44 +1344,46 @@ __device__ __forceinline__ void sub10_body(const Sub10Args& a, const Sub10Lds L,
             }
         }
         S10_STAMP(2);
+        if (d + 1 >= 0 && d + 1 < nrows) desc = L.rows[d + 1];
         sub10_barrier();
     }
 }
 
-__global__ __launch_bounds__(64 * S10_NL, 1) void sub10_kernel(Sub10Args a)
+__global__ __launch_bounds__(64 * S10_NW, 1) void sub10_kernel(Sub10Args a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Sub10Lds L = sub10_lds(smem);
-    const int stage = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int nrows = __builtin_amdgcn_readfirstlane(a.nrows[blockIdx.x]);
     if (nrows <= 0) return;
     // this workgroup's row descriptors live in LDS, 8 bytes each: {2y + emit, x0}; every wave reads one (or two) per step
     {
         const uint4* const grows = a.rows + (size_t)blockIdx.x * a.max_rows;
-        for (int i = threadIdx.x; i < nrows; i += 64 * S10_NL) {
+        for (int i = threadIdx.x; i < nrows; i += 64 * S10_NW) {
             const uint4 e = grows[i];
             L.rows[i] = make_int2((int)e.x * 2 + (int)(e.z & 1), (int)e.y);
         }
     }
     // rings start as zeros (margins and pipeline fill are never written: no NaN patterns may sit there)
-    for (int i = threadIdx.x; i < ((S10_NL - 1) * S10_RINGB + S10_URINGB) / 16; i += 64 * S10_NL)
+    for (int i = threadIdx.x; i < ((S10_NL - 1) * S10_RINGB + S10_URINGB) / 16; i += 64 * S10_NW)
         ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);
-    if (lane < 32) {
-        const float b = a.bias[stage][lane];
-        const float sl = stage + 1 < S10_NL ? a.slope[stage][lane] : 0.f;
-        L.prm[stage * 96 + lane] = b;
-        L.prm[stage * 96 + 32 + lane] = sl;
+    if (wave < S10_NL && lane < 32) {
+        L.prm[wave * 96 + lane] = a.bias[wave][lane];
+        L.prm[wave * 96 + 32 + lane] = wave + 1 < S10_NL ? a.slope[wave][lane] : 0.f;
     }
     __syncthreads();
     // every wave runs the same number of steps = barriers, whatever code it sits in
     const int nsteps = (nrows + S10_DRAIN + 1) & ~1;
-    // the two light waves go first on their SIMDs: their long scalar-ish epilogues (u8 conversion, byte stores) then
-    // run under the other waves' MFMAs instead of after them
-    if (stage == 0 || stage == S10_NL - 1) __builtin_amdgcn_s_setprio(3);
-    if (stage == 0) sub10_head(a, L, lane, nrows, nsteps);
-    else if (stage == S10_NL - 1) sub10_body<true>(a, L, stage, lane, nrows, nsteps);
-    else sub10_body<false>(a, L, stage, lane, nrows, nsteps);
+    // Waves w, w+4, w+8 share a SIMD: two trunk layers and one half of the first or the last layer each -- the same
+    // MFMA and VALU load on all four.  The light waves go first on their SIMD: their long scalar-ish epilogues (u8
+    // conversion, byte stores) then run under the trunk waves' MFMAs instead of after them.
+    if (wave >= 8) __builtin_amdgcn_s_setprio(3);
+    if (wave < 8) sub10_body<false, 0, 5>(a, L, wave, wave + 1, lane, nrows, nsteps);
+    else if (wave == 8) sub10_head<0>(a, L, wave, lane, nrows, nsteps);
+    else if (wave == 9) sub10_head<1>(a, L, wave, lane, nrows, nsteps);
+    else if (wave == 10) sub10_body<true, 0, 3>(a, L, wave, S10_NL - 1, lane, nrows, nsteps);
+    else sub10_body<true, 3, 5>(a, L, wave, S10_NL - 1, lane, nrows, nsteps);
 }
 
 // ----------------------------------------------------------------------------------------------
