@@ -25,10 +25,12 @@
 extern "C" {
 #endif
 
-#define UVA_ABI_VERSION 5   /* 2: + uva_net_submit_u8 / uva_net_collect_u8 / uva_host_alloc / uva_host_free;
+#define UVA_ABI_VERSION 6   /* 2: + uva_net_submit_u8 / uva_net_collect_u8 / uva_host_alloc / uva_host_free;
                                3: + uva_get_gpu_pci_bus_id, uva_debug_trunk2_schedule;
                                4: + uva_denoise_u8, uva_debug_denoise_stage; generic graphs (4x_Valar_v1) load;
-                               5: + uva_debug_sub10_rows */
+                               5: + uva_debug_sub10_rows;
+                               6: + uva_net_submit_u8_png, uva_png_workspace_bytes, uva_png_assemble, uva_png_deflate_u8,
+                                  uva_debug_png_deflate_host */
 
 typedef struct uva_net uva_net;
 
@@ -102,6 +104,28 @@ int uva_net_collect_u8(uva_net* net, long long ticket);
 /* Page-locked host memory for frames handed to the two calls above (no staging copy). */
 void* uva_host_alloc(size_t bytes);
 void uva_host_free(void* p);
+
+/* ---- the imwrite side on the device (csrc/uva_png.hip.h) -------------------------------- */
+
+/* cv2.imwrite(frame.png) of the result frame (upscale_processing.py:288, :519), with the deflate work done on the GPU:
+ * like uva_net_submit_u8, but the result frame stays in HBM, a kernel behind the net compresses it (Sub filter, fixed
+ * Huffman tables, one deflate block per group of rows) and writes the compressed blocks straight into `png_ws`:
+ * page-locked memory (uva_host_alloc) of uva_png_workspace_bytes(h*scale, w*scale) bytes that must stay untouched until
+ * uva_net_collect_u8(ticket) has returned.  uva_png_assemble() -- host only, any thread -- then turns the workspace into
+ * the bytes of the PNG file: *len receives the size; out may be NULL to ask for it (the call then fails after setting
+ * *len).  h, w there are the RESULT frame's.  Any PNG reader decodes the file to exactly the frame
+ * uva_net_submit_u8 would have returned.  uva_png_workspace_bytes() returns 0 for frames the encoder does not take
+ * (wider than 16 383 pixels). */
+long long uva_net_submit_u8_png(uva_net* net, const uint8_t* in, int h, int w, size_t in_stride, void* png_ws,
+                                size_t png_ws_bytes, int tile_size, int border);
+size_t uva_png_workspace_bytes(int h, int w);
+int uva_png_assemble(const void* png_ws, int h, int w, uint8_t* out, size_t cap, size_t* len);
+/* The same encoder for a frame in host memory (synchronous: H2D copy, kernel, wait): imwrite for frames that did not
+ * come out of a net of this library, e.g. the denoise pass (upscale_processing.py:336-338). */
+int uva_png_deflate_u8(int gpu, const uint8_t* bgr, int h, int w, size_t stride, void* png_ws, size_t png_ws_bytes);
+/* Test hook (host only): the kernel's arithmetic restated on the host, block for block and bit for bit, into an
+ * ordinary buffer of uva_png_workspace_bytes(h, w) bytes. */
+int uva_debug_png_deflate_host(const uint8_t* bgr, int h, int w, size_t stride, void* png_ws, size_t png_ws_bytes);
 
 /* Same, with in/out already resident in this device's HBM (dense rows: in_stride = 3*w,
  * out_stride = 3*w*s unless stated).  Asynchronous on the net's stream; follow with

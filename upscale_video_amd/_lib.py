@@ -6,11 +6,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UVA_LIB_PATH") or os.path.join(_HERE, "libuva.so")   # override: A/B builds
 
 # every symbol include/uva.h declares
-ABI_VERSION = 5   # include/uva.h UVA_ABI_VERSION
+ABI_VERSION = 6   # include/uva.h UVA_ABI_VERSION
 
 SYMBOLS = [
     "uva_get_gpu_count", "uva_get_default_gpu_index", "uva_get_gpu_info", "uva_get_gpu_pci_bus_id",
-    "uva_debug_trunk2_schedule", "uva_debug_sub10_rows", "uva_denoise_u8", "uva_debug_denoise_stage", "uva_destroy_gpu_instance",
+    "uva_debug_trunk2_schedule", "uva_debug_sub10_rows", "uva_net_submit_u8_png", "uva_png_workspace_bytes",
+    "uva_png_assemble", "uva_png_deflate_u8", "uva_debug_png_deflate_host", "uva_denoise_u8", "uva_debug_denoise_stage", "uva_destroy_gpu_instance",
     "uva_net_create", "uva_net_set_device", "uva_net_load_param", "uva_net_load_model",
     "uva_net_destroy", "uva_net_scale", "uva_net_num_features", "uva_net_num_convs",
     "uva_net_extract_f32", "uva_net_process_u8", "uva_net_process_u8_device", "uva_net_synchronize",
@@ -47,6 +48,14 @@ def load():
         _lib = L
         return L
     L.uva_get_gpu_pci_bus_id.argtypes = [c_i, ctypes.c_char_p, c_sz]
+    if hasattr(L, "uva_png_assemble"):
+        L.uva_net_submit_u8_png.restype = ctypes.c_longlong
+        L.uva_net_submit_u8_png.argtypes = [c_p, c_p, c_i, c_i, c_sz, c_p, c_sz, c_i, c_i]
+        L.uva_png_workspace_bytes.restype = c_sz
+        L.uva_png_workspace_bytes.argtypes = [c_i, c_i]
+        L.uva_png_assemble.argtypes = [c_p, c_i, c_i, c_p, c_sz, ctypes.POINTER(c_sz)]
+        L.uva_png_deflate_u8.argtypes = [c_i, c_p, c_i, c_i, c_sz, c_p, c_sz]
+        L.uva_debug_png_deflate_host.argtypes = [c_p, c_i, c_i, c_sz, c_p, c_sz]
     if hasattr(L, "uva_debug_sub10_rows"):
         L.uva_debug_sub10_rows.argtypes = [c_i, c_i, c_i, c_p, c_sz, ctypes.POINTER(c_sz), c_p, ctypes.POINTER(c_i)]
     L.uva_debug_trunk2_schedule.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_sz, ctypes.POINTER(c_sz), c_p,

@@ -10,6 +10,7 @@
 #include "uva_generic.hip.h"
 #include "uva_kernels.hip.h"
 #include "uva_model.h"
+#include "uva_png.hip.h"
 
 #include <hip/hip_runtime.h>
 
@@ -1145,6 +1146,77 @@ int check_dims(const uva_net* n, int h, int w)
 // ---- `-m n=K`: non-local-means denoise (upscale/upscale_processing.py:350-361) -------------------------
 namespace {
 
+// ---- PNG encoding on the device (uva_png.hip.h) ---------------------------------------------------
+struct PngDev {
+    uint32_t* d_code = nullptr;
+    uint8_t* d_hdr = nullptr;
+    bool attr_set = false;
+    // the synchronous utility's own buffers
+    hipStream_t stream = nullptr;
+    uint8_t* d_frame = nullptr;
+    size_t d_frame_cap = 0;
+};
+std::mutex g_png_mu;          // the table uploads
+std::mutex g_png_util_mu;     // uva_png_deflate_u8's stream and frame buffer (never taken inside g_png_mu, or the reverse)
+PngDev g_png[16];
+
+void png_release_all()
+{
+    std::lock_guard<std::mutex> lk2(g_png_util_mu);
+    std::lock_guard<std::mutex> lk(g_png_mu);
+    for (int d = 0; d < 16; ++d) {
+        PngDev& c = g_png[d];
+        if (!c.d_code && !c.stream) continue;
+        (void)hipSetDevice(d);
+        if (c.stream) { (void)hipStreamSynchronize(c.stream); (void)hipStreamDestroy(c.stream); }
+        if (c.d_code) (void)hipFree(c.d_code);
+        if (c.d_hdr) (void)hipFree(c.d_hdr);
+        if (c.d_frame) (void)hipFree(c.d_frame);
+        c = PngDev();
+    }
+}
+
+// the code tables of this device (uploaded on first use); the caller holds no lock
+int png_dev(int device, PngDev** out)
+{
+    if (device < 0 || device >= 16) return fail("bad device");
+    std::lock_guard<std::mutex> lk(g_png_mu);
+    PngDev& c = g_png[device];
+    if (!c.d_code) {
+        const PngTables& T = png_tables();
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipMalloc((void**)&c.d_code, sizeof T.code));
+        HIP_TRY(hipMalloc((void**)&c.d_hdr, sizeof T.hdr));
+        HIP_TRY(hipMemcpy(c.d_code, T.code, sizeof T.code, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c.d_hdr, T.hdr, sizeof T.hdr, hipMemcpyHostToDevice));
+        HIP_TRY(hipFuncSetAttribute((const void*)png_deflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, png_lds_bytes()));
+        c.attr_set = true;
+    }
+    *out = &c;
+    return 0;
+}
+
+// deflate the h x w u8 BGR frame at d_frame (HBM) into the page-locked workspace `ws`, on `stream`
+int png_launch(int device, hipStream_t stream, const uint8_t* d_frame, size_t stride, int h, int w, void* ws, size_t ws_bytes)
+{
+    if (h <= 0 || w <= 0 || 3 * (long long)w + 1 > PNG_FILT_CAP) return fail("PNG encoder: frame width out of range");
+    if (!ws || ws_bytes < png_workspace_bytes(h, w)) return fail("PNG workspace too small");
+    PngDev* c = nullptr;
+    if (png_dev(device, &c)) return 1;
+    PngArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.src = d_frame; a.stride = stride; a.h = h; a.w = w;
+    a.rows_per_block = png_rows_per_block(w);
+    a.nblocks = png_num_blocks(h, w);
+    a.code = c->d_code; a.hdr = c->d_hdr;
+    for (int t = 0; t < PNG_TABLES; ++t) a.hdr_bits[t] = png_tables().hdr_bits[t];
+    a.meta = (uint32_t*)ws;
+    a.slots = (uint8_t*)ws + png_meta_bytes(h, w);
+    hipLaunchKernelGGL(png_deflate_kernel, dim3(a.nblocks), dim3(PNG_THREADS), png_lds_bytes(), stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 struct DenoiseCtx {
     hipStream_t stream = nullptr;
     uint8_t *d_in = nullptr, *d_out = nullptr, *d_l = nullptr, *d_l2 = nullptr, *d_ab = nullptr, *d_ab2 = nullptr;
@@ -1345,6 +1417,7 @@ void uva_destroy_gpu_instance(void)
         for (uva_net* n : g_nets) n->free_device();
     }
     denoise_release_all();
+    png_release_all();
 }
 
 uva_net* uva_net_create(void)
@@ -1489,15 +1562,21 @@ void uva_host_free(void* p)
     if (p) (void)hipHostFree(p);
 }
 
-long long uva_net_submit_u8(uva_net* n, const uint8_t* in, int h, int w, size_t in_stride, uint8_t* out,
-                            size_t out_stride, int tile_size, int border)
+}  // extern "C"
+namespace {
+// uva_net_submit_u8 (png_ws == nullptr: the result frame goes to `out`) and uva_net_submit_u8_png (the result frame stays
+// in HBM, its PNG deflate blocks go to the page-locked workspace png_ws)
+long long submit_u8(uva_net* n, const uint8_t* in, int h, int w, size_t in_stride, uint8_t* out, size_t out_stride,
+                    int tile_size, int border, void* png_ws, size_t png_ws_bytes)
 {
     if (check_dims(n, h, w)) return -1;
-    if (!in || !out) { fail("null frame pointer"); return -1; }
+    if (!in || (!out && !png_ws)) { fail("null frame pointer"); return -1; }
+    if (png_ws && !is_pinned_host(png_ws)) { fail("PNG workspace must be page-locked host memory (uva_host_alloc)"); return -1; }
     if (ensure_device(n)) return -1;
     auto tryhip = [](hipError_t e, const char* what) { return e == hipSuccess ? 0 : fail(std::string(what) + ": " + hipGetErrorString(e)); };
     const int s = uva_net_scale(n);
     const size_t in_row = (size_t)w * 3, out_row = (size_t)w * s * 3;
+    if (png_ws) out_stride = out_row;
     if (in_stride < in_row || out_stride < out_row) { fail("row stride too small"); return -1; }
     const size_t in_bytes = in_row * h, out_bytes = out_row * (size_t)h * s;
     uva_net::PipeSlot* free_slot = nullptr;
@@ -1530,6 +1609,15 @@ long long uva_net_submit_u8(uva_net* n, const uint8_t* in, int h, int w, size_t 
     if (uva_net_process_u8_device(n, ps.d_in, h, w, in_row, ps.d_out, out_row, tile_size, border)) return -1;
     if (tryhip(hipEventRecord(ps.ev_done, n->stream), "hipEventRecord") ||
         tryhip(hipStreamWaitEvent(n->s_d2h, ps.ev_done, 0), "hipStreamWaitEvent")) return -1;
+    if (png_ws) {
+        // the deflate kernel follows the net on its stream and writes straight into the caller's page-locked workspace
+        if (png_launch(n->device, n->stream, ps.d_out, out_row, h * s, w * s, png_ws, png_ws_bytes)) return -1;
+        if (tryhip(hipEventRecord(ps.ev_d2h, n->stream), "hipEventRecord")) return -1;
+        ps.user_out = nullptr;
+        ps.busy = true;
+        ps.ticket = n->next_ticket;
+        return n->next_ticket++;
+    }
     uint8_t* dst = out;
     size_t dst_stride = out_stride;
     ps.user_out = nullptr;
@@ -1543,6 +1631,61 @@ long long uva_net_submit_u8(uva_net* n, const uint8_t* in, int h, int w, size_t 
     ps.busy = true;
     ps.ticket = n->next_ticket;
     return n->next_ticket++;
+}
+}  // namespace
+extern "C" {
+
+long long uva_net_submit_u8(uva_net* n, const uint8_t* in, int h, int w, size_t in_stride, uint8_t* out,
+                            size_t out_stride, int tile_size, int border)
+{
+    return submit_u8(n, in, h, w, in_stride, out, out_stride, tile_size, border, nullptr, 0);
+}
+
+long long uva_net_submit_u8_png(uva_net* n, const uint8_t* in, int h, int w, size_t in_stride, void* png_ws, size_t png_ws_bytes,
+                                int tile_size, int border)
+{
+    if (!png_ws) { fail("null PNG workspace"); return -1; }
+    return submit_u8(n, in, h, w, in_stride, nullptr, 0, tile_size, border, png_ws, png_ws_bytes);
+}
+
+size_t uva_png_workspace_bytes(int h, int w)
+{
+    if (h <= 0 || w <= 0 || 3 * (long long)w + 1 > PNG_FILT_CAP) return 0;
+    return png_workspace_bytes(h, w);
+}
+
+int uva_png_assemble(const void* png_ws, int h, int w, uint8_t* out, size_t cap, size_t* len)
+{
+    if (!png_ws || uva_png_workspace_bytes(h, w) == 0) return fail("bad argument");
+    std::string err;
+    if (png_assemble((const uint8_t*)png_ws, h, w, out, cap, len, err)) return fail(err);
+    return 0;
+}
+
+int uva_png_deflate_u8(int device, const uint8_t* bgr, int h, int w, size_t stride, void* png_ws, size_t png_ws_bytes)
+{
+    if (!bgr || stride < (size_t)w * 3) return fail("bad frame");
+    if (uva_png_workspace_bytes(h, w) == 0) return fail("PNG encoder: frame width out of range");
+    if (!is_pinned_host(png_ws)) return fail("PNG workspace must be page-locked host memory (uva_host_alloc)");
+    PngDev* c = nullptr;
+    if (png_dev(device, &c)) return 1;
+    std::lock_guard<std::mutex> lk(g_png_util_mu);
+    HIP_TRY(hipSetDevice(device));
+    if (!c->stream) HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const size_t row = (size_t)w * 3;
+    if (grow_dev(&c->d_frame, &c->d_frame_cap, row * h)) return 1;
+    HIP_TRY(hipMemcpy2DAsync(c->d_frame, row, bgr, stride, row, h, hipMemcpyHostToDevice, c->stream));
+    if (png_launch(device, c->stream, c->d_frame, row, h, w, png_ws, png_ws_bytes)) return 1;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int uva_debug_png_deflate_host(const uint8_t* bgr, int h, int w, size_t stride, void* png_ws, size_t png_ws_bytes)
+{
+    if (!bgr || !png_ws || stride < (size_t)w * 3 || uva_png_workspace_bytes(h, w) == 0 || png_ws_bytes < png_workspace_bytes(h, w))
+        return fail("bad argument");
+    png_deflate_host(bgr, stride, h, w, (uint8_t*)png_ws);
+    return 0;
 }
 
 int uva_net_collect_u8(uva_net* n, long long ticket)

@@ -1,0 +1,445 @@
+// uva_png.hip.h -- PNG encoding of the result frame ON the MI355X: the `imwrite` side of the reference's per-frame hop
+// (cv2.imwrite(frame.png), upscale/upscale_processing.py:288 and :519).
+//
+// The reference's pipeline is file to file, and after the net itself the PNG encoder is its largest per-frame cost: zlib
+// at cv2's own settings needs ~170 ms of one core for a 3840x2160 frame, 70 times the 2.4 ms the net takes here.  The
+// frame is already in HBM, the work is byte-wise and embarrassingly parallel, so it is done there:
+//
+//   * every block of R rows (R*(3w+1) <= 48 KiB) is one workgroup and one deflate block of its own;
+//   * scanlines are filtered with Sub (what cv2 uses by default for 8-bit RGB at IMWRITE_PNG_STRATEGY_RLE), BGR -> RGB;
+//   * the filtered bytes are Huffman-coded as literals with one of four FIXED code tables (Laplacian residual models of
+//     different widths, built once on the host and written into each block as a dynamic-Huffman header); the workgroup
+//     costs all four and takes the cheapest.  No LZ77 matches: on filtered video frames nearly all of zlib's gain at
+//     level 1 / Z_RLE comes from the entropy code;
+//   * every block ends with an empty stored block, which byte-aligns it (zlib's Z_SYNC_FLUSH): blocks are concatenated
+//     by plain byte copies, the last one carries BFINAL;
+//   * the workgroup also returns the Adler-32 of its stretch of filtered bytes; the host combines them.
+//
+// The kernel writes each block's bytes straight into page-locked host memory (only the bytes it produced cross PCIe,
+// about half of the raw frame), the host concatenates, adds the zlib / PNG framing and the chunk CRC
+// (uva_png_assemble: any thread, no GPU call).  The stream is plain RFC 1950/1951: every PNG reader decodes it to the
+// same pixels cv2.imwrite's file gives.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <queue>
+#include <string>
+#include <vector>
+
+namespace uva {
+
+constexpr int PNG_TABLES = 4;
+constexpr int PNG_FILT_CAP = 48 * 1024;                 // filtered bytes per block
+constexpr int PNG_HDR_CAP = 256;                        // bytes reserved for a block's dynamic-Huffman header
+constexpr int PNG_STAGE_BYTES = PNG_FILT_CAP * 9 / 8 + PNG_HDR_CAP + 64;   // the flattest table costs <= 9 bits per byte
+constexpr int PNG_SLOT_BYTES = (PNG_STAGE_BYTES + 255) / 256 * 256;
+constexpr int PNG_META_WORDS = 4;                       // per block: compressed bytes, Adler s1, Adler s2, filtered bytes
+constexpr uint32_t PNG_ADLER_BASE = 65521;
+
+struct PngTables {
+    uint32_t code[PNG_TABLES][260];                     // [symbol 0..256]: (bit-reversed code << 5) | length
+    uint8_t hdr[PNG_TABLES][PNG_HDR_CAP];               // block header bits (BFINAL = 0, BTYPE = 2, the code lengths), LSB first
+    int hdr_bits[PNG_TABLES];
+};
+
+// ---- host: code construction ------------------------------------------------------------------------------------
+namespace png_detail {
+
+// Huffman code lengths of at most maxlen bits: plain Huffman, frequencies halved (floor 1) until it fits
+inline std::vector<int> huff_lengths(std::vector<uint64_t> freq, int maxlen)
+{
+    const int n = (int)freq.size();
+    std::vector<int> len(n, 0);
+    for (;;) {
+        struct Node { uint64_t f; int l, r; };
+        std::vector<Node> nodes;
+        typedef std::pair<uint64_t, int> QE;
+        std::priority_queue<QE, std::vector<QE>, std::greater<QE>> q;
+        for (int i = 0; i < n; ++i)
+            if (freq[i]) { nodes.push_back({freq[i], -1 - i, -1 - i}); q.push({freq[i], (int)nodes.size() - 1}); }
+        if (nodes.size() == 1) { len[-1 - nodes[0].l] = 1; return len; }
+        while (q.size() > 1) {
+            const QE a = q.top(); q.pop();
+            const QE b = q.top(); q.pop();
+            nodes.push_back({a.first + b.first, a.second, b.second});
+            q.push({a.first + b.first, (int)nodes.size() - 1});
+        }
+        int worst = 0;
+        std::vector<std::pair<int, int>> st{{q.top().second, 0}};
+        while (!st.empty()) {
+            const std::pair<int, int> t = st.back(); st.pop_back();
+            const Node& nd = nodes[t.first];
+            if (nd.l < 0 && nd.l == nd.r) { len[-1 - nd.l] = t.second; worst = std::max(worst, t.second); continue; }
+            st.push_back({nd.l, t.second + 1});
+            st.push_back({nd.r, t.second + 1});
+        }
+        if (worst <= maxlen) return len;
+        for (auto& f : freq)
+            if (f) f = std::max<uint64_t>(1, f / 2);
+    }
+}
+
+// RFC 1951 3.2.2: canonical codes from lengths; returned bit-reversed (deflate packs Huffman codes MSB first into an
+// LSB-first bit stream)
+inline std::vector<uint32_t> canonical_reversed(const std::vector<int>& len)
+{
+    int bl_count[16] = {0};
+    for (int l : len) bl_count[l]++;
+    bl_count[0] = 0;
+    uint32_t next[16] = {0}, c = 0;
+    for (int b = 1; b < 16; ++b) { c = (c + bl_count[b - 1]) << 1; next[b] = c; }
+    std::vector<uint32_t> out(len.size(), 0);
+    for (size_t i = 0; i < len.size(); ++i) {
+        if (!len[i]) continue;
+        uint32_t v = next[len[i]]++, r = 0;
+        for (int b = 0; b < len[i]; ++b) r |= ((v >> b) & 1u) << (len[i] - 1 - b);
+        out[i] = r;
+    }
+    return out;
+}
+
+struct BitWriter {
+    std::vector<uint8_t> bytes;
+    int nbits = 0;
+    void put(uint32_t v, int n)
+    {
+        for (int i = 0; i < n; ++i, ++nbits) {
+            if ((nbits & 7) == 0) bytes.push_back(0);
+            bytes.back() |= (uint8_t)(((v >> i) & 1u) << (nbits & 7));
+        }
+    }
+};
+
+}  // namespace png_detail
+
+// The four literal codes and their block headers.  Model: filtered byte v is the residual r = (int8)v with
+// P(r) ~ exp(-|r| / sigma) (+ a floor so that every byte value has a code); sigma = 1, 3, 8 and "flat".
+inline const PngTables& png_tables()
+{
+    static const PngTables T = [] {
+        PngTables t;
+        std::memset(&t, 0, sizeof t);
+        const double sigmas[PNG_TABLES] = {1.0, 3.0, 8.0, 0.0};
+        for (int k = 0; k < PNG_TABLES; ++k) {
+            std::vector<uint64_t> f(257);
+            for (int v = 0; v < 256; ++v) {
+                const int m = std::min(v, 256 - v);
+                f[v] = sigmas[k] > 0 ? (uint64_t)std::llround(1e7 * std::exp(-m / sigmas[k])) + 200 : 1000;
+            }
+            f[256] = 1;                                                  // end of block: once per 48 KiB
+            const std::vector<int> len = png_detail::huff_lengths(f, k == PNG_TABLES - 1 ? 9 : 15);
+            const std::vector<uint32_t> code = png_detail::canonical_reversed(len);
+            for (int v = 0; v < 257; ++v) t.code[k][v] = (code[v] << 5) | (uint32_t)len[v];
+            // header: BFINAL 0, BTYPE 10, HLIT = 0 (257 codes), HDIST = 0 (one distance code, of length 0: literals only),
+            // the code lengths themselves coded one symbol each (no repeat codes) with their own Huffman code
+            std::vector<int> seq(len.begin(), len.end());
+            seq.push_back(0);
+            std::vector<uint64_t> cf(19, 0);
+            for (int l : seq) cf[l]++;
+            const std::vector<int> clen = png_detail::huff_lengths(cf, 7);
+            const std::vector<uint32_t> ccode = png_detail::canonical_reversed(clen);
+            static const int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+            int hclen = 19;
+            while (hclen > 4 && clen[order[hclen - 1]] == 0) --hclen;
+            png_detail::BitWriter w;
+            w.put(0, 1); w.put(2, 2); w.put(0, 5); w.put(0, 5); w.put((uint32_t)(hclen - 4), 4);
+            for (int i = 0; i < hclen; ++i) w.put((uint32_t)clen[order[i]], 3);
+            for (int l : seq) w.put(ccode[l], clen[l]);
+            if ((int)w.bytes.size() > PNG_HDR_CAP) std::abort();
+            std::memcpy(t.hdr[k], w.bytes.data(), w.bytes.size());
+            t.hdr_bits[k] = w.nbits;
+        }
+        return t;
+    }();
+    return T;
+}
+
+inline int png_rows_per_block(int w) { return std::max(1, PNG_FILT_CAP / (3 * w + 1)); }
+inline int png_num_blocks(int h, int w) { const int r = png_rows_per_block(w); return (h + r - 1) / r; }
+// bytes of the page-locked workspace a frame needs: [meta: nblocks x 16 B, padded to 4 KiB][nblocks slots]
+inline size_t png_meta_bytes(int h, int w) { return ((size_t)png_num_blocks(h, w) * PNG_META_WORDS * 4 + 4095) / 4096 * 4096; }
+inline size_t png_workspace_bytes(int h, int w) { return png_meta_bytes(h, w) + (size_t)png_num_blocks(h, w) * PNG_SLOT_BYTES; }
+
+// ---- device ------------------------------------------------------------------------------------------------------
+struct PngArgs {
+    const uint8_t* src;           // u8 HWC BGR frame in HBM
+    size_t stride;
+    int h, w, rows_per_block, nblocks;
+    const uint32_t* code;         // [PNG_TABLES][260]
+    const uint8_t* hdr;           // [PNG_TABLES][PNG_HDR_CAP]
+    int hdr_bits[PNG_TABLES];
+    uint32_t* meta;               // [nblocks][4]  (page-locked host memory)
+    uint8_t* slots;               // [nblocks][PNG_SLOT_BYTES]
+};
+
+constexpr int PNG_THREADS = 256;
+constexpr int png_lds_bytes() { return PNG_FILT_CAP + PNG_STAGE_BYTES + 260 * 4 + PNG_TABLES * 260 + 1024 * 8; }
+static_assert(png_lds_bytes() <= 160 * 1024, "PNG kernel LDS budget");
+
+__device__ __forceinline__ void png_or_bits(uint32_t* stage, unsigned long long pos, unsigned long long v, int n)
+{
+    // n <= 32 bits of v at bit position pos
+    const unsigned sh = (unsigned)(pos & 31);
+    const unsigned long long x = v << sh;
+    uint32_t* p = stage + (pos >> 5);
+    atomicOr(p, (uint32_t)x);
+    if (sh + n > 32) atomicOr(p + 1, (uint32_t)(x >> 32));
+}
+
+__global__ __launch_bounds__(PNG_THREADS) void png_deflate_kernel(PngArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char png_smem[];
+    uint8_t* const filt = (uint8_t*)png_smem;
+    uint32_t* const stage = (uint32_t*)(png_smem + PNG_FILT_CAP);
+    uint32_t* const tbl = (uint32_t*)(png_smem + PNG_FILT_CAP + PNG_STAGE_BYTES);
+    uint8_t* const lens = (uint8_t*)(tbl + 260);                                   // [PNG_TABLES][260]
+    unsigned long long* const red = (unsigned long long*)(lens + PNG_TABLES * 260);  // reductions and the scan
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int r0 = b * a.rows_per_block, nr = min(a.rows_per_block, a.h - r0);
+    const int rowb = 3 * a.w + 1, n = nr * rowb;
+
+    for (int i = tid; i < PNG_TABLES * 260; i += PNG_THREADS) lens[i] = (uint8_t)(a.code[i] & 31u);
+    for (int i = tid; i < PNG_STAGE_BYTES / 4; i += PNG_THREADS) stage[i] = 0;
+    if (tid < 8) red[tid] = 0;
+    __syncthreads();
+
+    // ---- filter (Sub, BGR -> RGB), cost under each table, Adler-32 sums ----
+    unsigned long long cost[PNG_TABLES] = {0, 0, 0, 0}, s1 = 0, s2 = 0;
+    for (int row = 0; row < nr; ++row) {
+        const uint8_t* const sp = a.src + (size_t)(r0 + row) * a.stride;
+        uint8_t* const fp = filt + row * rowb;
+        for (int k = tid; k < rowb; k += PNG_THREADS) {
+            unsigned v = 1;                                               // filter type 1
+            if (k > 0) {
+                const int x = (k - 1) / 3, c = (k - 1) - 3 * x;
+                const unsigned cur = sp[3 * x + 2 - c], left = x > 0 ? sp[3 * x - 1 - c] : 0;
+                v = (cur - left) & 0xffu;
+            }
+            fp[k] = (uint8_t)v;
+#pragma unroll
+            for (int t = 0; t < PNG_TABLES; ++t) cost[t] += lens[t * 260 + v];
+            s1 += v;
+            s2 += (unsigned long long)(n - (row * rowb + k)) * v;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < PNG_TABLES; ++t) atomicAdd(&red[t], cost[t]);
+    atomicAdd(&red[4], s1);
+    atomicAdd(&red[5], s2);
+    __syncthreads();
+    int best = 0;
+#pragma unroll
+    for (int t = 1; t < PNG_TABLES; ++t)
+        if (red[t] + (unsigned long long)a.hdr_bits[t] < red[best] + (unsigned long long)a.hdr_bits[best]) best = t;
+    for (int i = tid; i < 257; i += PNG_THREADS) tbl[i] = a.code[best * 260 + i];
+    const int hb = a.hdr_bits[best];
+    for (int i = tid; i < (hb + 7) / 8; i += PNG_THREADS) atomicOr(stage + (i >> 2), (uint32_t)a.hdr[best * PNG_HDR_CAP + i] << (8 * (i & 3)));
+    __syncthreads();
+
+    // ---- bit offsets: every thread owns a contiguous span of the filtered bytes ----
+    const int span = (n + PNG_THREADS - 1) / PNG_THREADS, sb = min(n, tid * span), se = min(n, sb + span);
+    unsigned long long bits = 0;
+    for (int i = sb; i < se; ++i) bits += tbl[filt[i]] & 31u;
+    unsigned long long* const scan = red + 8;
+    scan[tid] = bits;
+    __syncthreads();
+    for (int d = 1; d < PNG_THREADS; d <<= 1) {
+        const unsigned long long v = tid >= d ? scan[tid - d] : 0;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    unsigned long long pos = (unsigned long long)hb + scan[tid] - bits;
+    const unsigned long long body_end = (unsigned long long)hb + scan[PNG_THREADS - 1];
+
+    // ---- encode the span ----
+    unsigned long long acc = 0;
+    int nacc = 0;
+    for (int i = sb; i < se; ++i) {
+        const uint32_t e = tbl[filt[i]];
+        acc |= (unsigned long long)(e >> 5) << nacc;
+        nacc += (int)(e & 31u);
+        if (nacc >= 32) {
+            png_or_bits(stage, pos, acc & 0xffffffffull, 32);
+            pos += 32; acc >>= 32; nacc -= 32;
+        }
+    }
+    if (nacc) png_or_bits(stage, pos, acc, nacc);
+    // end of block, then the empty stored block that byte-aligns the stream (BFINAL on the frame's last block)
+    unsigned long long total_bytes = 0;
+    {
+        const uint32_t eob = tbl[256];
+        const unsigned long long p1 = body_end + (eob & 31u), p2 = (p1 + 3 + 7) / 8 * 8;
+        total_bytes = p2 / 8 + 4;
+        if (tid == 0) {
+            png_or_bits(stage, body_end, eob >> 5, (int)(eob & 31u));
+            png_or_bits(stage, p1, b == a.nblocks - 1 ? 1u : 0u, 3);
+            png_or_bits(stage, p2, 0xffff0000ull, 32);                    // LEN = 0, NLEN = 0xffff
+        }
+    }
+    __syncthreads();
+
+    // ---- out: this block's bytes to its slot in page-locked host memory ----
+    uint32_t* const out = (uint32_t*)(a.slots + (size_t)b * PNG_SLOT_BYTES);
+    const int nw = (int)((total_bytes + 3) / 4);
+    for (int i = tid; i < nw; i += PNG_THREADS) out[i] = stage[i];
+    if (tid == 0) {
+        uint32_t* const m = a.meta + (size_t)b * PNG_META_WORDS;
+        m[0] = (uint32_t)total_bytes;
+        m[1] = (uint32_t)((1 + red[4]) % PNG_ADLER_BASE);                 // Adler-32 of the block on its own
+        m[2] = (uint32_t)((red[5] + (unsigned long long)n) % PNG_ADLER_BASE);
+        m[3] = (uint32_t)n;
+    }
+}
+
+// ---- host: framing -----------------------------------------------------------------------------------------------
+namespace png_detail {
+
+inline const uint32_t (*crc_tables())[256]
+{
+    static uint32_t T[8][256];
+    static const bool init = [] {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            T[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int t = 1; t < 8; ++t) T[t][i] = (T[t - 1][i] >> 8) ^ T[0][T[t - 1][i] & 0xff];
+        return true;
+    }();
+    (void)init;
+    return T;
+}
+
+// CRC-32 (ISO 3309, the PNG chunk CRC), slicing by 8; crc is the running value (start 0)
+inline uint32_t crc32(uint32_t crc, const uint8_t* p, size_t n)
+{
+    const uint32_t (*T)[256] = crc_tables();
+    uint32_t c = ~crc;
+    while (n && ((uintptr_t)p & 7)) { c = T[0][(c ^ *p++) & 0xff] ^ (c >> 8); --n; }
+    while (n >= 8) {
+        uint32_t a, b;
+        std::memcpy(&a, p, 4);
+        std::memcpy(&b, p + 4, 4);
+        a ^= c;
+        c = T[7][a & 0xff] ^ T[6][(a >> 8) & 0xff] ^ T[5][(a >> 16) & 0xff] ^ T[4][a >> 24] ^
+            T[3][b & 0xff] ^ T[2][(b >> 8) & 0xff] ^ T[1][(b >> 16) & 0xff] ^ T[0][b >> 24];
+        p += 8; n -= 8;
+    }
+    while (n--) c = T[0][(c ^ *p++) & 0xff] ^ (c >> 8);
+    return ~c;
+}
+
+// zlib's adler32_combine: Adler-32 of A||B from Adler(A), Adler(B) and len(B)
+inline uint32_t adler_combine(uint32_t a1, uint32_t a2, uint64_t len2)
+{
+    const uint32_t B = PNG_ADLER_BASE;
+    const uint32_t rem = (uint32_t)(len2 % B);
+    uint32_t s1 = a1 & 0xffff, s2 = (uint32_t)(((uint64_t)rem * s1) % B);
+    s1 += (a2 & 0xffff) + B - 1;
+    s2 += (a1 >> 16) + (a2 >> 16) + B - rem;
+    if (s1 >= B) s1 -= B;
+    if (s1 >= B) s1 -= B;
+    if (s2 >= (B << 1)) s2 -= (B << 1);
+    if (s2 >= B) s2 -= B;
+    return s1 | (s2 << 16);
+}
+
+inline void be32(uint8_t* p, uint32_t v) { p[0] = (uint8_t)(v >> 24); p[1] = (uint8_t)(v >> 16); p[2] = (uint8_t)(v >> 8); p[3] = (uint8_t)v; }
+
+}  // namespace png_detail
+
+// The PNG file image of an h x w frame from the workspace the kernel filled.  Returns 0 and *len, or non-zero with
+// `err` set (workspace inconsistent, out too small).
+inline int png_assemble(const uint8_t* workspace, int h, int w, uint8_t* out, size_t cap, size_t* len, std::string& err)
+{
+    using namespace png_detail;
+    const int nb = png_num_blocks(h, w);
+    const uint32_t* meta = (const uint32_t*)workspace;
+    const uint8_t* slots = workspace + png_meta_bytes(h, w);
+    size_t total = 0;
+    uint64_t filtered = 0;
+    for (int b = 0; b < nb; ++b) {
+        if (meta[4 * b] == 0 || meta[4 * b] > (uint32_t)PNG_SLOT_BYTES) { err = "PNG workspace: block size out of range (kernel not run?)"; return 1; }
+        total += meta[4 * b];
+        filtered += meta[4 * b + 3];
+    }
+    if (filtered != (uint64_t)h * (3 * (uint64_t)w + 1)) { err = "PNG workspace: block lengths do not add up to the frame"; return 1; }
+    const size_t idat = 2 + total + 4, need = 8 + 25 + 12 + idat + 12;
+    if (len) *len = need;
+    if (!out || cap < need) { err = "PNG output buffer too small"; return 1; }
+    uint8_t* p = out;
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    std::memcpy(p, sig, 8); p += 8;
+    be32(p, 13); std::memcpy(p + 4, "IHDR", 4);
+    be32(p + 8, (uint32_t)w); be32(p + 12, (uint32_t)h);
+    p[16] = 8; p[17] = 2; p[18] = 0; p[19] = 0; p[20] = 0;               // 8-bit RGB, deflate, adaptive filtering, no interlace
+    be32(p + 21, crc32(0, p + 4, 17)); p += 25;
+    be32(p, (uint32_t)idat); std::memcpy(p + 4, "IDAT", 4);
+    uint8_t* const data = p + 8;
+    data[0] = 0x78; data[1] = 0x01;                                       // zlib: deflate, 32 KiB window, fastest
+    uint8_t* q = data + 2;
+    uint32_t adler = 1;
+    for (int b = 0; b < nb; ++b) {
+        std::memcpy(q, slots + (size_t)b * PNG_SLOT_BYTES, meta[4 * b]);
+        q += meta[4 * b];
+        adler = adler_combine(adler, meta[4 * b + 1] | (meta[4 * b + 2] << 16), meta[4 * b + 3]);
+    }
+    be32(q, adler); q += 4;
+    be32(q, crc32(0, p + 4, 4 + idat)); q += 4;
+    be32(q, 0); std::memcpy(q + 4, "IEND", 4); be32(q + 8, crc32(0, q + 4, 4));
+    return 0;
+}
+
+// Host restatement of png_deflate_kernel, block for block and bit for bit (test hook: the CPU suite checks tables, headers
+// and framing with it against a PNG reader, the GPU suite checks the kernel against it).  Not a product path.
+inline void png_deflate_host(const uint8_t* src, size_t stride, int h, int w, uint8_t* workspace)
+{
+    const PngTables& T = png_tables();
+    const int R = png_rows_per_block(w), nb = png_num_blocks(h, w), rowb = 3 * w + 1;
+    uint32_t* meta = (uint32_t*)workspace;
+    uint8_t* slots = workspace + png_meta_bytes(h, w);
+    std::vector<uint8_t> filt;
+    for (int b = 0; b < nb; ++b) {
+        const int r0 = b * R, nr = std::min(R, h - r0), n = nr * rowb;
+        filt.assign(n, 0);
+        uint64_t cost[PNG_TABLES] = {0}, s1 = 0, s2 = 0;
+        for (int row = 0; row < nr; ++row)
+            for (int k = 0; k < rowb; ++k) {
+                unsigned v = 1;
+                if (k > 0) {
+                    const int x = (k - 1) / 3, c = (k - 1) - 3 * x;
+                    const uint8_t* sp = src + (size_t)(r0 + row) * stride;
+                    v = ((unsigned)sp[3 * x + 2 - c] - (x > 0 ? (unsigned)sp[3 * x - 1 - c] : 0u)) & 0xffu;
+                }
+                filt[row * rowb + k] = (uint8_t)v;
+                for (int t = 0; t < PNG_TABLES; ++t) cost[t] += T.code[t][v] & 31u;
+                s1 += v;
+                s2 += (uint64_t)(n - (row * rowb + k)) * v;
+            }
+        int best = 0;
+        for (int t = 1; t < PNG_TABLES; ++t)
+            if (cost[t] + (uint64_t)T.hdr_bits[t] < cost[best] + (uint64_t)T.hdr_bits[best]) best = t;
+        png_detail::BitWriter bw;
+        for (int i = 0; i < T.hdr_bits[best]; ++i) bw.put((T.hdr[best][i >> 3] >> (i & 7)) & 1u, 1);
+        for (int i = 0; i < n; ++i) bw.put(T.code[best][filt[i]] >> 5, (int)(T.code[best][filt[i]] & 31u));
+        bw.put(T.code[best][256] >> 5, (int)(T.code[best][256] & 31u));
+        bw.put(b == nb - 1 ? 1u : 0u, 3);
+        while (bw.nbits & 7) bw.put(0, 1);
+        bw.put(0xffff0000u, 32);
+        uint8_t* slot = slots + (size_t)b * PNG_SLOT_BYTES;
+        std::memset(slot, 0, (bw.bytes.size() + 3) / 4 * 4);
+        std::memcpy(slot, bw.bytes.data(), bw.bytes.size());
+        meta[4 * b] = (uint32_t)bw.bytes.size();
+        meta[4 * b + 1] = (uint32_t)((1 + s1) % PNG_ADLER_BASE);
+        meta[4 * b + 2] = (uint32_t)((s2 + (uint64_t)n) % PNG_ADLER_BASE);
+        meta[4 * b + 3] = (uint32_t)n;
+    }
+}
+
+}  // namespace uva

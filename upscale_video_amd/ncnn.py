@@ -74,6 +74,44 @@ def pinned_empty(shape, dtype=np.uint8):
     return arr
 
 
+class PngWorkspace:
+    """Page-locked memory the GPU's PNG encoder writes an h x w frame's deflate blocks into (include/uva.h
+    uva_png_workspace_bytes); file_bytes() frames them as a PNG file on the host (zlib / PNG headers, Adler-32, chunk
+    CRC: include/uva.h uva_png_assemble -- no GPU call, the GIL is released)."""
+
+    def __init__(self, h, w):
+        L = _lib.load()
+        n = L.uva_png_workspace_bytes(h, w)
+        if n == 0:
+            raise ValueError("the GPU PNG encoder does not take %dx%d frames" % (w, h))
+        self.h, self.w = h, w
+        self.buf = pinned_empty((n,), np.uint8)
+        self._out = None
+
+    def file_bytes(self):
+        """-> memoryview of the PNG file image (valid until the next file_bytes() of this workspace)."""
+        L = _lib.load()
+        cap = 1024 + 2 * (self.h * (3 * self.w + 1)) if self._out is None else len(self._out)
+        if self._out is None:
+            self._out = bytearray(cap)
+        n = ctypes.c_size_t(0)
+        dst = (ctypes.c_ubyte * len(self._out)).from_buffer(self._out)
+        _lib.check(L.uva_png_assemble(self.buf.ctypes.data, self.h, self.w, dst, len(self._out), ctypes.byref(n)))
+        return memoryview(self._out)[:n.value]
+
+
+def png_encode_u8(img_bgr, gpu=0, workspace=None):
+    """cv2.imwrite's encoder for a frame in host memory, run on the GPU (include/uva.h uva_png_deflate_u8): -> bytes
+    of the PNG file."""
+    img = np.ascontiguousarray(img_bgr, dtype=np.uint8)
+    if img.ndim != 3 or img.shape[2] != 3:
+        raise ValueError("frame must be u8 [h][w][3]")
+    h, w, _ = img.shape
+    ws = workspace or PngWorkspace(h, w)
+    _lib.check(_lib.load().uva_png_deflate_u8(int(gpu), img.ctypes.data, h, w, w * 3, ws.buf.ctypes.data, ws.buf.nbytes))
+    return bytes(ws.file_bytes())
+
+
 class Ticket:
     """One frame in flight on the pipelined host route; keeps its buffers alive."""
 
@@ -236,9 +274,32 @@ class Net:
         return Ticket(t, img, out)
 
     def collect_u8(self, ticket):
-        """Waits for the frame of `ticket` and returns its u8 result array."""
+        """Waits for the frame of `ticket` and returns its u8 result array (submit_u8) or its PNG workspace
+        (submit_u8_png)."""
         _lib.check(self._L.uva_net_collect_u8(self._h, ticket.id))
         return ticket.out
+
+    def submit_u8_png(self, img_bgr, workspace=None, tile_size=0, border=0):
+        """Pipelined like submit_u8, but the result frame stays on the GPU and is deflated there (include/uva.h
+        uva_net_submit_u8_png): collect_u8(ticket) returns a PngWorkspace whose .file_bytes() is the PNG file
+        cv2.imwrite would have been asked for (upscale_processing.py:288, :519).  `workspace`: a PngWorkspace of the
+        result's size to reuse (they are page-locked; allocate a few and cycle them)."""
+        img = np.ascontiguousarray(img_bgr, dtype=np.uint8)
+        if img.ndim != 3 or img.shape[2] != 3:
+            raise ValueError("frame must be u8 [h][w][3]")
+        s = self.scale
+        if s <= 0:
+            raise _lib.UvaError("net has no graph: load_param/load_model failed or were not called")
+        h, w, _ = img.shape
+        if workspace is None:
+            workspace = PngWorkspace(h * s, w * s)
+        if (workspace.h, workspace.w) != (h * s, w * s):
+            raise ValueError("PNG workspace is for %dx%d frames, the result is %dx%d" % (workspace.w, workspace.h, w * s, h * s))
+        t = self._L.uva_net_submit_u8_png(self._h, img.ctypes.data, h, w, w * 3, workspace.buf.ctypes.data, workspace.buf.nbytes,
+                                          int(tile_size), int(border))
+        if t < 0:
+            raise _lib.UvaError(self._L.uva_last_error().decode(errors="replace"))
+        return Ticket(t, img, workspace)
 
     def process_u8_device(self, d_in, h, w, d_out, tile_size=0, border=0, in_stride=None, out_stride=None):
         """Asynchronous: raw device pointers (ints) of dense u8 HWC frames in this GPU's HBM."""
