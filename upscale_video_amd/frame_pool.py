@@ -12,8 +12,11 @@ output has been written, :295-296/:521-522), but
   * the workers live as long as the pool: nets, packed weights, activation workspaces and the
     page-locked result ring are built once per (worker, model) and reused by every later batch;
   * inside a worker, PNG decode, the GPU and PNG encode are three overlapped stages: a pool of
-    decode threads feeds the GPU thread (pipelined `submit_u8` / `collect_u8`, three frames in
-    flight), whose results go to a pool of encode threads (zlib releases the GIL);
+    decode threads feeds the GPU thread (pipelined `submit_u8_png` / `collect_u8`, three frames in
+    flight): the result frame never leaves HBM, a kernel behind the net deflates it (csrc/uva_png.hip.h)
+    and only the compressed blocks cross PCIe; a pool of encode threads frames them as a PNG file
+    (zlib header, Adler-32, chunk CRC) and writes it.  UVA_GPU_PNG=0 keeps the frame route instead
+    (`submit_u8`, zlib on the host's cores: ~180 ms of a core per 3840x2160 frame);
   * every finished frame is reported to the caller's thread as the reference's log-item list, so
     `logging_callback`'s "any error item ends the run" (:40-51) happens in the main thread.
 
@@ -31,14 +34,27 @@ from concurrent.futures import ThreadPoolExecutor
 from ._imageio import imread, imwrite
 
 PIPE_DEPTH = 3            # include/uva.h: frames in flight per net on the pipelined route
-DEFAULT_DECODE_THREADS = int(os.environ.get("UVA_DECODE_THREADS", "4"))
-DEFAULT_ENCODE_THREADS = int(os.environ.get("UVA_ENCODE_THREADS", "0"))     # 0: the host's cores shared out over the workers
+DEFAULT_DECODE_THREADS = int(os.environ.get("UVA_DECODE_THREADS", "0"))     # 0: the host's cores shared out over the workers
+DEFAULT_ENCODE_THREADS = int(os.environ.get("UVA_ENCODE_THREADS", "0"))     # 0: likewise
+GPU_PNG = os.environ.get("UVA_GPU_PNG", "1") != "0"        # imwrite's deflate work on the GPU (ncnn.Net.submit_u8_png)
+
+
+def default_decode_threads(n_workers):
+    """With the result frames deflated on the GPU, PNG decode of the inputs (~23 ms of a core per 1080p frame) is the
+    host's main job: every worker gets its share of the cores, between 4 and 16 threads (measured on a 16-core
+    quota: -g 0 best with 16, -g 0,0 with 8, profiles/r02_g_png_gpu_route.txt).  On the zlib route: 4."""
+    if not GPU_PNG:
+        return 4
+    return max(4, min(16, usable_cpus() // max(1, n_workers)))
 
 
 def default_encode_threads(n_workers, decode_threads):
-    """PNG encode of a 4K result is ~100x the GPU time of the frame: give every worker its share of the host's
-    cores (minus its decode threads and its GPU thread), between 4 and 48 threads."""
+    """zlib route: PNG encode of a 4K result is ~100x the GPU time of the frame, so every worker gets its share of the
+    host's cores (minus its decode threads and its GPU thread), between 4 and 48 threads.  GPU route: the encode
+    threads only frame the file (concatenate, CRC-32: ~5 ms) and write it -- 2 to 4."""
     cores = usable_cpus()
+    if GPU_PNG:
+        return max(2, min(4, cores // max(1, 2 * n_workers)))
     return max(4, min(48, cores // max(1, n_workers) - decode_threads - 1))
 
 
@@ -97,6 +113,7 @@ class _Worker:
         self.nbuf = PIPE_DEPTH + encode_threads       # result buffers: frames on the GPU or being encoded
         self.ready = queue.Queue()      # decoded frames, in completion order
         self.stop = False
+        self.gpu_png = GPU_PNG
 
     # ---- stage 1: pull tasks, decode --------------------------------------------------------
     def puller(self):
@@ -143,6 +160,22 @@ class _Worker:
             self.rings[(key, shape)] = ring
         return ring, ring["free"].get()
 
+    def png_ring(self, key, h, w):
+        """Ring of page-locked PNG workspaces for h x w result frames (ncnn.PngWorkspace), or None when the GPU encoder
+        does not take such frames."""
+        rk = (key, "png", h, w)
+        if rk not in self.rings:
+            from .ncnn import PngWorkspace
+            try:
+                ring = {"bufs": [PngWorkspace(h, w) for _ in range(self.nbuf)], "free": queue.Queue()}
+            except ValueError:
+                ring = None
+            else:
+                for i in range(self.nbuf):
+                    ring["free"].put(i)
+            self.rings[rk] = ring
+        return self.rings[rk]
+
     def gpu_loop(self):
         inflight = []   # (task, ticket, net, ring, idx)
         eof = False
@@ -164,9 +197,16 @@ class _Worker:
                 try:
                     key, net = self.net_for(task)
                     s = net.scale
-                    ring, idx = self.out_buffer(key, (img.shape[0] * s, img.shape[1] * s, 3))
                     tile = task["tile_size"]
-                    ticket = net.submit_u8(img, out=ring["bufs"][idx], tile_size=tile, border=task["border"] if tile else 0)
+                    ring = None
+                    if self.gpu_png and task["dst"] and str(task["dst"]).lower().endswith(".png") and hasattr(net, "submit_u8_png"):
+                        ring = self.png_ring(key, img.shape[0] * s, img.shape[1] * s)
+                    if ring is not None:
+                        idx = ring["free"].get()
+                        ticket = net.submit_u8_png(img, workspace=ring["bufs"][idx], tile_size=tile, border=task["border"] if tile else 0)
+                    else:
+                        ring, idx = self.out_buffer(key, (img.shape[0] * s, img.shape[1] * s, 3))
+                        ticket = net.submit_u8(img, out=ring["bufs"][idx], tile_size=tile, border=task["border"] if tile else 0)
                     inflight.append((task, ticket, net, ring, idx))
                 except Exception as e:  # noqa: BLE001
                     self.gpu_failed(task, e)
@@ -194,7 +234,11 @@ class _Worker:
         err = None
         try:
             if task["dst"]:
-                imwrite(task["dst"], out)
+                if hasattr(out, "file_bytes"):      # a PNG workspace the GPU filled: frame it and write it
+                    with open(task["dst"], "wb") as f:
+                        f.write(out.file_bytes())
+                else:
+                    imwrite(task["dst"], out)
             if task["remove"]:
                 os.remove(task["src"])
         except Exception as e:  # noqa: BLE001
@@ -239,6 +283,8 @@ class FramePool:
         if not gpus:
             raise ValueError("FramePool needs at least one -g entry")
         self.gpus = list(gpus)
+        if not decode_threads:
+            decode_threads = default_decode_threads(len(self.gpus))
         if not encode_threads:
             encode_threads = default_encode_threads(len(self.gpus), decode_threads)
         self.decode_threads, self.encode_threads = decode_threads, encode_threads
