@@ -25,12 +25,13 @@
 extern "C" {
 #endif
 
-#define UVA_ABI_VERSION 6   /* 2: + uva_net_submit_u8 / uva_net_collect_u8 / uva_host_alloc / uva_host_free;
+#define UVA_ABI_VERSION 7   /* 2: + uva_net_submit_u8 / uva_net_collect_u8 / uva_host_alloc / uva_host_free;
                                3: + uva_get_gpu_pci_bus_id, uva_debug_trunk2_schedule;
                                4: + uva_denoise_u8, uva_debug_denoise_stage; generic graphs (4x_Valar_v1) load;
                                5: + uva_debug_sub10_rows;
                                6: + uva_net_submit_u8_png, uva_png_workspace_bytes, uva_png_assemble, uva_png_deflate_u8,
-                                  uva_debug_png_deflate_host */
+                                  uva_debug_png_deflate_host;
+                               7: + uva_png_decode_bgr, uva_debug_zlib_decompress */
 
 typedef struct uva_net uva_net;
 
@@ -123,6 +124,14 @@ int uva_png_assemble(const void* png_ws, int h, int w, uint8_t* out, size_t cap,
 /* The same encoder for a frame in host memory (synchronous: H2D copy, kernel, wait): imwrite for frames that did not
  * come out of a net of this library, e.g. the denoise pass (upscale_processing.py:336-338). */
 int uva_png_deflate_u8(int gpu, const uint8_t* bgr, int h, int w, size_t stride, void* png_ws, size_t png_ws_bytes);
+/* cv2.imread(path) (upscale_processing.py:263, :487) for a file image already in memory, host only, any thread: a
+ * from-scratch inflate + PNG un-filter straight into cv2's u8 HWC BGR layout, 2-3x a zlib-based reader.  8-bit RGB,
+ * RGBA (alpha dropped), grey (replicated), non-interlaced.  out == NULL: only *h, *w are set.  Returns 0, 1 for a
+ * corrupt file (chunk CRC, Adler-32 and stream length are all checked; uva_last_error says what), 2 for a PNG of
+ * another kind (16-bit, palette, interlaced): use a general reader for those. */
+int uva_png_decode_bgr(const uint8_t* file, size_t len, uint8_t* out, size_t cap, int* h, int* w);
+/* Test hook: the inflate alone on a zlib-wrapped stream that must expand to exactly out_len bytes. */
+int uva_debug_zlib_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t out_len);
 /* Test hook (host only): the kernel's arithmetic restated on the host, block for block and bit for bit, into an
  * ordinary buffer of uva_png_workspace_bytes(h, w) bytes. */
 int uva_debug_png_deflate_host(const uint8_t* bgr, int h, int w, size_t stride, void* png_ws, size_t png_ws_bytes);

@@ -12,6 +12,11 @@
 #include "uva_model.h"
 #include "uva_png.hip.h"
 
+namespace uva {   // uva_pngread.cpp
+int png_read_bgr(const uint8_t* file, size_t len, uint8_t* out, size_t cap, int* h_out, int* w_out, std::string& err);
+int zlib_decompress_exact(const uint8_t* in, size_t n, uint8_t* out, size_t out_len, std::string& err);
+}
+
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -1677,6 +1682,24 @@ int uva_png_deflate_u8(int device, const uint8_t* bgr, int h, int w, size_t stri
     HIP_TRY(hipMemcpy2DAsync(c->d_frame, row, bgr, stride, row, h, hipMemcpyHostToDevice, c->stream));
     if (png_launch(device, c->stream, c->d_frame, row, h, w, png_ws, png_ws_bytes)) return 1;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int uva_png_decode_bgr(const uint8_t* file, size_t len, uint8_t* out, size_t cap, int* h, int* w)
+{
+    if (!file) return fail("null file image");
+    std::string err;
+    const int rc = png_read_bgr(file, len, out, cap, h, w, err);
+    if (rc == 1) return fail(err);
+    if (rc == 2) { fail("PNG of a kind the fast reader does not take (16-bit, palette or interlaced)"); return 2; }
+    return 0;
+}
+
+int uva_debug_zlib_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t out_len)
+{
+    if (!in || (!out && out_len)) return fail("null argument");
+    std::string err;
+    if (zlib_decompress_exact(in, n, out, out_len, err)) return fail(err);
     return 0;
 }
 
