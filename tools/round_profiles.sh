@@ -13,7 +13,11 @@ for wl in 4x_compact_1080p 1x_hurrdeblur_1080p chain_1x_2x_1080p 2x_compact_2160
 done
 python bench.py --tile 0 --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_2x_whole_frame.json" 2>> "$OUT/bench.err"
 UVA_TRUNK_FUSION=0 python bench.py --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_unfused_trunk_kernel.json" 2>> "$OUT/bench.err"
+UVA_SUB10=0 python bench.py --workload 1x_hurrdeblur_1080p --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_1x_per_pair_kernels.json" 2>> "$OUT/bench.err"
+(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d /tmp/prof1x_$TAG -o p --output-format csv -- python $REPO/bench.py --workload 1x_hurrdeblur_1080p --tile 0 --steps 50 --warmup 5 --no-cpu-baseline > /dev/null 2>&1; cp $(find /tmp/prof1x_$TAG -name "*kernel_stats.csv" | head -1) "$OUT/${TAG}_kernel_stats_1x_rocprofv3.csv")
+bash tools/pmc_sub10.sh /tmp/pmc_sub10_$TAG > "$OUT/${TAG}_sub10_pmc.txt" 2>&1
 python tools/png_route_bench.py 384 > "$OUT/${TAG}_png_route_bench.txt" 2>&1
+python tools/png_gpu_route_bench.py 240 > "$OUT/${TAG}_png_gpu_route_bench.txt" 2>&1
 python tools/rawvideo_bench.py 600 > "$OUT/${TAG}_rawvideo_bench.txt" 2>&1
 python test_gpus.py -g 0,0,0,0 -s 2 -r 16 > "$OUT/${TAG}_test_gpus_harness.txt" 2>&1
 # package power and shader clock while the bench runs (sustained state)
@@ -24,4 +28,5 @@ wait
 sleep 8
 python -c "import json; d=json.load(open('$OUT/power_bench.json')); print('bench --steps 6000:', d['value'], 'fps, trunk', d['config']['kernel_ms_per_frame']['trunk'], 'ms/frame, frac', d['roofline']['frac'])" >> "$OUT/${TAG}_power_during_bench.txt" 2>&1
 UVA_LIB_PATH=$REPO/upscale_video_amd/libuva_instr.so python tools/trunk2_anatomy.py > "$OUT/${TAG}_trunk2_anatomy.txt" 2>&1
+UVA_LIB_PATH=$REPO/upscale_video_amd/libuva_instr.so python tools/sub10_anatomy.py > "$OUT/${TAG}_sub10_anatomy.txt" 2>&1
 ls -la "$OUT"

@@ -203,10 +203,16 @@ class _Worker:
                         ring = self.png_ring(key, img.shape[0] * s, img.shape[1] * s)
                     if ring is not None:
                         idx = ring["free"].get()
-                        ticket = net.submit_u8_png(img, workspace=ring["bufs"][idx], tile_size=tile, border=task["border"] if tile else 0)
                     else:
                         ring, idx = self.out_buffer(key, (img.shape[0] * s, img.shape[1] * s, 3))
-                        ticket = net.submit_u8(img, out=ring["bufs"][idx], tile_size=tile, border=task["border"] if tile else 0)
+                    try:
+                        if hasattr(ring["bufs"][idx], "file_bytes"):
+                            ticket = net.submit_u8_png(img, workspace=ring["bufs"][idx], tile_size=tile, border=task["border"] if tile else 0)
+                        else:
+                            ticket = net.submit_u8(img, out=ring["bufs"][idx], tile_size=tile, border=task["border"] if tile else 0)
+                    except BaseException:
+                        ring["free"].put(idx)           # the buffer goes back: a failed frame must not shrink the ring
+                        raise
                     inflight.append((task, ticket, net, ring, idx))
                 except Exception as e:  # noqa: BLE001
                     self.gpu_failed(task, e)

@@ -91,12 +91,15 @@ class PngWorkspace:
     def file_bytes(self):
         """-> memoryview of the PNG file image (valid until the next file_bytes() of this workspace)."""
         L = _lib.load()
-        cap = 1024 + 2 * (self.h * (3 * self.w + 1)) if self._out is None else len(self._out)
-        if self._out is None:
-            self._out = bytearray(cap)
         n = ctypes.c_size_t(0)
+        L.uva_png_assemble(self.buf.ctypes.data, self.h, self.w, None, 0, ctypes.byref(n))      # size query (fails by design)
+        if n.value == 0:
+            raise _lib.UvaError(L.uva_last_error().decode(errors="replace"))
+        if self._out is None or len(self._out) < n.value:
+            self._out = bytearray(n.value + n.value // 8)          # the next frame of the stream is about the same size
         dst = (ctypes.c_ubyte * len(self._out)).from_buffer(self._out)
         _lib.check(L.uva_png_assemble(self.buf.ctypes.data, self.h, self.w, dst, len(self._out), ctypes.byref(n)))
+        del dst
         return memoryview(self._out)[:n.value]
 
 
