@@ -139,6 +139,7 @@ struct uva_net {
     _Float16* d_sink = nullptr;   // where out-of-image lanes of the trunk kernel store to
     bool attr_set[16] = {false};  // hipFuncAttributeMaxDynamicSharedMemorySize done for kernel slot k on this net's device
     int last_act_buf = 0;         // which ping-pong buffer the last run_graph() left its last trunk activation in
+    bool generic_lds_conv = true; // generic graphs: 3x3 convolutions through g_conv3_lds (UVA_GENERIC_LDS=0: the plain g_conv<3>)
     bool fuse_all = true;         // 24-feature 1x net: all ten convolutions in one launch (sub10_kernel); UVA_SUB10=0 turns it off
     bool fuse_pairs = true;       // 64-feature nets: trunk layers run two per launch (trunk2_kernel); UVA_TRUNK_FUSION=0 turns it off
     LastCall last;
@@ -590,6 +591,7 @@ int ensure_device(uva_net* n)
     HIP_TRY(hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking));
     if (const char* e = std::getenv("UVA_TRUNK_FUSION")) n->fuse_pairs = std::atoi(e) != 0;
     if (const char* e = std::getenv("UVA_SUB10")) n->fuse_all = std::atoi(e) != 0;
+    if (const char* e = std::getenv("UVA_GENERIC_LDS")) n->generic_lds_conv = std::atoi(e) != 0;
     HIP_TRY(hipMalloc((void**)&n->d_sink, 64 * 128 + 256));
     if (n->generic) {
         // generic graph: every convolution's MFMA image ([tap][cin/32][cout/16][lane][8]) and padded bias
@@ -604,6 +606,12 @@ int ensure_device(uva_net* n)
             std::vector<uint16_t> pk;
             pack_generic(c, gl.ksize, cd.cin_pad, cd.cout_pad, pk);
             if (upload(&cd.wpk, pk.data(), pk.size() * 2, n->stream)) return 1;
+            if (gl.ksize == 3 && cd.cout_pad <= 64 && cd.cin_pad <= 192 && g_conv3_lds_bytes(cd.cin_pad, cd.cout_pad / 16) <= 160 * 1024) {
+                std::vector<uint16_t> pkl;
+                pack_generic(c, 3, cd.cin_pad, cd.cout_pad, pkl, true);
+                if (upload(&cd.wpk_lds, pkl.data(), pkl.size() * 2, n->stream)) return 1;
+                HIP_TRY(hipStreamSynchronize(n->stream));
+            }
             std::vector<float> b((size_t)cd.cout_pad, 0.f);
             std::copy(c.bias.begin(), c.bias.end(), b.begin());
             if (upload(&cd.bias, b.data(), b.size() * 4, n->stream)) return 1;
@@ -1043,20 +1051,45 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
     std::vector<int> left(g.blobs.size(), 0);
     auto root = [&](int b) { while (g.blobs[b].alias_of >= 0) b = g.blobs[b].alias_of; return b; };
     for (size_t b = 0; b < g.blobs.size(); ++b) left[b] = g.blobs[b].consumers;
+    // dense chains (uva_generic.h plan_concat_groups): the blobs of a chain are channel ranges of one shared array, which
+    // goes back to the pool when the last of them has been read.  Needs g_conv3_lds (prefix reads, strided writes).
+    const bool use_groups = n->generic_lds_conv;
+    std::vector<GBuf> garr(g.group_channels.size());
+    std::vector<int> glive(g.group_blobs.begin(), g.group_blobs.end());
+    auto group_of = [&](int b) { return use_groups ? g.blobs[b].group : -1; };
     auto done_with = [&](int b) {
         b = root(b);
-        if (--left[b] == 0) { generic_release(n, buf[b]); buf[b].p = nullptr; }
+        if (--left[b] != 0) return;
+        const int gi = group_of(b);
+        if (gi >= 0) {
+            buf[b].p = nullptr;
+            if (--glive[gi] == 0) { generic_release(n, garr[gi]); garr[gi].p = nullptr; }
+        } else {
+            generic_release(n, buf[b]);
+            buf[b].p = nullptr;
+        }
     };
     struct Cleanup {
-        uva_net* n; std::vector<GBuf>* bufs;
-        ~Cleanup() { for (auto& b : *bufs) if (b.p) generic_release(n, b); }
-    } cleanup{n, &buf};
+        uva_net* n; std::vector<GBuf>* bufs; std::vector<GBuf>* groups; const GenericGraph* g; bool use_groups;
+        ~Cleanup()
+        {
+            for (size_t b = 0; b < bufs->size(); ++b)
+                if ((*bufs)[b].p && !(use_groups && g->blobs[b].group >= 0)) generic_release(n, (*bufs)[b]);
+            for (auto& a : *groups) if (a.p) generic_release(n, a);
+        }
+    } cleanup{n, &buf, &garr, &g, use_groups};
     const int T = 256;
     for (const GLayer& gl : g.layers) {
         if (gl.kind == GLayer::SPLIT) continue;
         const GBlob& ob = g.blobs[gl.out[0]];
         GBuf o;
-        if (generic_acquire(n, h * ob.scale, w * ob.scale, ob.channels, &o)) return 1;
+        if (group_of(gl.out[0]) >= 0) {
+            GBuf& ga = garr[ob.group];
+            if (!ga.p && generic_acquire(n, h * ob.scale, w * ob.scale, g.group_channels[ob.group], &ga)) return 1;
+            o = ga;                                   // same geometry and pixel stride (cpad) ...
+            o.p = ga.p + ob.group_off;                // ... starting at the blob's first channel
+            o.c = ob.channels;
+        } else if (generic_acquire(n, h * ob.scale, w * ob.scale, ob.channels, &o)) return 1;
         buf[gl.out[0]] = o;
         auto in = [&](int k) -> const GBuf& { return buf[root(gl.in[k])]; };
         switch (gl.kind) {
@@ -1067,6 +1100,33 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
         case GLayer::CONV: {
             const GenericDevice::ConvDev& cd = n->gd.convs[gl.conv];
             const GBuf& a = in(0);
+            if ((group_of(gl.out[0]) >= 0 || group_of(root(gl.in[0])) >= 0) && !(gl.ksize == 3 && cd.wpk_lds))
+                return fail("generic executor: a dense-chain convolution without the LDS kernel (plan_concat_groups and ensure_device disagree)");
+            if (gl.ksize == 3 && cd.wpk_lds && n->generic_lds_conv) {
+                GConvArgs ga;
+                std::memset(&ga, 0, sizeof ga);
+                ga.in = a.p; ga.in_stride = a.cpad; ga.cin_pad = cd.cin_pad;
+                ga.wpk = cd.wpk_lds; ga.bias = cd.bias;
+                ga.out = o.p; ga.out_stride = o.cpad; ga.out_coff = 0; ga.cout = o.c;
+                ga.h = a.h; ga.w = a.w;
+                ga.has_act = gl.has_act ? 1 : 0; ga.slope = gl.act_slope;
+                const int mbn = cd.cout_pad / 16;
+                const size_t lds = g_conv3_lds_bytes(cd.cin_pad, mbn);
+                const dim3 g3((a.w + GC_TW - 1) / GC_TW, (a.h + GC_TH - 1) / GC_TH);
+                auto launch = [&](auto kern, int slot) -> int {
+                    if (!n->attr_set[slot]) {
+                        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                        n->attr_set[slot] = true;
+                    }
+                    hipLaunchKernelGGL(kern, g3, dim3(256), lds, n->stream, ga);
+                    return 0;
+                };
+                if (mbn == 1) { if (launch(g_conv3_lds<1>, 11)) return 1; }
+                else if (mbn == 2) { if (launch(g_conv3_lds<2>, 12)) return 1; }
+                else if (mbn == 3) { if (launch(g_conv3_lds<3>, 13)) return 1; }
+                else { if (launch(g_conv3_lds<4>, 14)) return 1; }
+                break;
+            }
             const dim3 grid((a.w + 63) / 64, (a.h + 3) / 4, (cd.cout_pad + 63) / 64);
             if (gl.ksize == 3)
                 hipLaunchKernelGGL(g_conv<3>, grid, dim3(256), 0, n->stream, a.p, a.cpad, cd.wpk, cd.bias, o.p, o.c, cd.cout_pad, o.cpad, a.h, a.w, gl.has_act ? 1 : 0, gl.act_slope);
@@ -1076,6 +1136,14 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
         }
         case GLayer::ADD:
         case GLayer::ELTWISE_SUM: {
+            if (group_of(root(gl.in[0])) >= 0 || group_of(root(gl.in[1])) >= 0 || group_of(gl.out[0]) >= 0) {
+                // an operand or the result is a channel range of a wider array (dense chain): per-pixel strides
+                if (o.c % 8) return fail("generic executor: strided add needs a multiple of 8 channels");
+                const size_t npix = (size_t)(o.h + 3) * (o.w + 2), work = npix * (o.c / 8);
+                hipLaunchKernelGGL(g_axpby_strided, dim3((unsigned)((work + T - 1) / T)), dim3(T), 0, n->stream, in(0).p, in(0).cpad,
+                                   gl.coeffs[0], in(1).p, in(1).cpad, gl.coeffs[1], o.p, o.cpad, o.c / 8, npix);
+                break;
+            }
             const size_t n8 = o.elems() / 8;
             hipLaunchKernelGGL(g_axpby, dim3((unsigned)((n8 + T - 1) / T)), dim3(T), 0, n->stream, (const half8*)in(0).p, gl.coeffs[0],
                                (const half8*)in(1).p, gl.coeffs[1], (half8*)o.p, n8);
@@ -1084,7 +1152,9 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
         case GLayer::CONCAT: {
             const size_t npix = (size_t)(o.h + 3) * (o.w + 2);
             int c_off = 0;
-            for (size_t k = 0; k < gl.in.size(); ++k) {
+            const int mode = use_groups ? gl.concat_mode : 0;
+            if (mode == 2) break;                     // every input already sits in its channel range of the shared array
+            for (size_t k = 0; k < (mode == 1 ? 1 : gl.in.size()); ++k) {
                 const GBuf& a = in((int)k);
                 const size_t work = npix * (a.c / 8);
                 hipLaunchKernelGGL(g_concat_part, dim3((unsigned)((work + T - 1) / T)), dim3(T), 0, n->stream, a.p, a.cpad, a.c, o.p, o.cpad, c_off, npix);

@@ -4,6 +4,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <fstream>
 #include <map>
 #include <sstream>
@@ -199,8 +200,90 @@ bool parse_param_generic(const std::string& path, GenericGraph& g, std::string& 
     g.blobs[root(g.out_blob)].consumers += 1;            // the caller reads it
     g.scale = g.blobs[g.out_blob].scale;
     for (const auto& b : g.blobs) g.max_channels = b.channels > g.max_channels ? b.channels : g.max_channels;
+    plan_concat_groups(g);
     g.param_loaded = true;
     return true;
+}
+
+void plan_concat_groups(GenericGraph& g)
+{
+    const int nb = (int)g.blobs.size(), nl = (int)g.layers.size();
+    auto root = [&](int b) { while (g.blobs[b].alias_of >= 0) b = g.blobs[b].alias_of; return b; };
+    std::vector<int> producer(nb, -1);
+    std::vector<std::vector<int>> readers(nb);
+    for (int li = 0; li < nl; ++li) {
+        const GLayer& gl = g.layers[li];
+        if (gl.kind == GLayer::SPLIT) continue;
+        for (int b : gl.out) producer[b] = li;
+        for (int b : gl.in) readers[root(b)].push_back(li);
+    }
+    // a convolution g_conv3_lds takes (csrc/uva_generic.hip.h): 3x3, <= 64 output channels, <= 192 input channels
+    auto lds_conv = [&](int li, int cin) {
+        const GLayer& gl = g.layers[li];
+        return gl.kind == GLayer::CONV && gl.ksize == 3 && g.blobs[gl.out[0]].channels <= 64 && cin <= 192 && cin % 32 == 0;
+    };
+    std::vector<char> used(nl, 0);
+    for (int l0 = 0; l0 < nl; ++l0) {
+        if (g.layers[l0].kind != GLayer::CONCAT || used[l0] || g.layers[l0].in.size() != 2) continue;
+        std::vector<int> chain{l0}, cur;
+        for (int b : g.layers[l0].in) cur.push_back(root(b));
+        for (;;) {      // the next Concat that extends `cur` by one blob
+            int next = -1;
+            for (int lj = chain.back() + 1; lj < nl && next < 0; ++lj) {
+                const GLayer& c = g.layers[lj];
+                if (c.kind != GLayer::CONCAT || used[lj] || c.in.size() != cur.size() + 1) continue;
+                bool same = true;
+                for (size_t k = 0; k < cur.size() && same; ++k) same = root(c.in[k]) == cur[k];
+                if (same) next = lj;
+            }
+            if (next < 0) break;
+            chain.push_back(next);
+            cur.push_back(root(g.layers[next].in.back()));
+        }
+        // validation.  A member is written by a convolution g_conv3_lds takes or by an element-wise sum (both can write
+        // a channel range of a wider array) and read by the chain's Concats, element-wise sums, or such convolutions.
+        bool ok = g.blobs[cur[0]].channels % 8 == 0;
+        const int scale = g.blobs[cur[0]].scale;
+        for (size_t k = 1; k < cur.size() && ok; ++k) {
+            const int y = cur[k], pl = producer[y];
+            ok = pl >= 0 && g.blobs[y].alias_of < 0 && g.blobs[y].group < 0 && g.blobs[y].scale == scale && g.blobs[y].channels % 8 == 0;
+            if (!ok) break;
+            const GLayer& pr = g.layers[pl];
+            ok = pr.kind == GLayer::ADD || pr.kind == GLayer::ELTWISE_SUM || lds_conv(pl, g.blobs[root(pr.in[0])].channels);
+            int in_chain = 0;
+            for (int r : readers[y]) {
+                const GLayer& rd = g.layers[r];
+                if (std::find(chain.begin(), chain.end(), r) != chain.end()) ++in_chain;
+                else ok = ok && (rd.kind == GLayer::ADD || rd.kind == GLayer::ELTWISE_SUM || lds_conv(r, g.blobs[y].channels));
+            }
+            // a member feeds every Concat of the chain from its own on, once each
+            ok = ok && in_chain == (int)chain.size() - (int)(k - 1);
+        }
+        for (size_t j = 0; j < chain.size() && ok; ++j) {
+            const int o = g.layers[chain[j]].out[0];
+            ok = g.blobs[o].alias_of < 0 && g.blobs[o].channels % 32 == 0 && g.blobs[o].channels <= 192 && o != g.out_blob;
+            for (int r : readers[o]) ok = ok && lds_conv(r, g.blobs[o].channels);
+        }
+        if (!ok) continue;
+        const int gid = (int)g.group_channels.size();
+        g.group_channels.push_back(g.blobs[g.layers[chain.back()].out[0]].channels);
+        int off = g.blobs[cur[0]].channels, count = 0;
+        for (size_t k = 1; k < cur.size(); ++k) {
+            g.blobs[cur[k]].group = gid;
+            g.blobs[cur[k]].group_off = off;
+            off += g.blobs[cur[k]].channels;
+            ++count;
+        }
+        for (size_t j = 0; j < chain.size(); ++j) {
+            GLayer& c = g.layers[chain[j]];
+            c.concat_mode = j == 0 ? 1 : 2;
+            g.blobs[c.out[0]].group = gid;
+            g.blobs[c.out[0]].group_off = 0;
+            used[chain[j]] = 1;
+            ++count;
+        }
+        g.group_blobs.push_back(count);
+    }
 }
 
 bool load_bin_generic(const std::string& path, GenericGraph& g, std::string& err)
@@ -257,9 +340,10 @@ bool load_bin_generic(const std::string& path, GenericGraph& g, std::string& err
     return true;
 }
 
-void pack_generic(const ConvWeights& c, int ksize, int cin_pad, int cout_pad, std::vector<uint16_t>& out)
+void pack_generic(const ConvWeights& c, int ksize, int cin_pad, int cout_pad, std::vector<uint16_t>& out, bool lds_order)
 {
     const int taps = ksize * ksize, c32n = cin_pad / 32, mbn = cout_pad / 16;
+    static const int unit_of_group[4] = {0, 2, 1, 3};       // g_conv3_lds: K-octet group o reads the 16-byte unit {0,2,1,3}[o]
     out.assign((size_t)taps * c32n * mbn * 64 * 8, 0);
     for (int tap = 0; tap < taps; ++tap)
         for (int c32 = 0; c32 < c32n; ++c32)
@@ -267,8 +351,9 @@ void pack_generic(const ConvWeights& c, int ksize, int cin_pad, int cout_pad, st
                 for (int lane = 0; lane < 64; ++lane) {
                     const int co = 16 * mb + (lane & 15);
                     if (co >= c.cout) continue;
+                    const int oct = lds_order ? unit_of_group[lane >> 4] : (lane >> 4);
                     for (int e = 0; e < 8; ++e) {
-                        const int ci = 32 * c32 + 8 * (lane >> 4) + e;
+                        const int ci = 32 * c32 + 8 * oct + e;
                         if (ci >= c.cin) continue;
                         out[((((size_t)tap * c32n + c32) * mbn + mb) * 64 + lane) * 8 + e] =
                             f32_to_f16_bits(c.w[((size_t)co * c.cin + ci) * taps + tap]);

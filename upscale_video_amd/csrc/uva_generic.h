@@ -32,6 +32,9 @@ struct GLayer {
     int factor = 1;
     // PRELU
     int slopes = -1;              // index into GenericGraph::prelu
+    // CONCAT: 0 copy every input; 1 first Concat of a dense chain: only input 0 is copied (into the chain's shared
+    // array), 2 later Concat of the chain: nothing to do (plan_concat_groups)
+    int concat_mode = 0;
 };
 
 struct GBlob {
@@ -40,6 +43,9 @@ struct GBlob {
     int scale = 1;                // spatial size relative to the input
     int alias_of = -1;            // Split outputs alias their input
     int consumers = 0;
+    // dense-chain plan (plan_concat_groups): the blob lives in channels [group_off, group_off + channels) of the shared
+    // array of group `group`
+    int group = -1, group_off = 0;
 };
 
 struct GenericGraph {
@@ -53,7 +59,17 @@ struct GenericGraph {
     int scale = 1;                // of the output blob
     int max_channels = 0;
     double flops_per_input_px = 0;
+    std::vector<int> group_channels;      // per dense chain: channels of its shared array
+    std::vector<int> group_blobs;         // ... and how many blobs live in it
 };
+
+// Dense blocks (RRDB: x1 = conv(x), x2 = conv(cat(x, x1)), x3 = conv(cat(x, x1, x2)), ...) concatenate a growing
+// prefix over and over.  Where every Concat of such a chain extends the previous one by one convolution output, the
+// outputs are only read by convolutions that can read a channel prefix of a wider array (g_conv3_lds) and the new
+// members are only read by the chain's Concats, the whole chain shares ONE array: convolutions write their output
+// into their channel range, the first Concat copies x, the others cost nothing.  Fills GLayer::concat_mode,
+// GBlob::group / group_off, GenericGraph::group_*.  Pure analysis: the executor may ignore it.
+void plan_concat_groups(GenericGraph& g);
 
 bool parse_param_generic(const std::string& path, GenericGraph& g, std::string& err);
 bool load_bin_generic(const std::string& path, GenericGraph& g, std::string& err);
@@ -61,6 +77,7 @@ bool load_bin_generic(const std::string& path, GenericGraph& g, std::string& err
 // MFMA A-operand image of a generic convolution for v_mfma_f32_16x16x32_f16:
 // [tap][cin_pad/32][cout_pad/16][64 lanes][8] fp16; lane = (octet << 4) | i supplies output channel
 // 16*mb + i and input channels 32*c32 + 8*octet .. +7 of that tap; out-of-range -> 0.
-void pack_generic(const ConvWeights& c, int ksize, int cin_pad, int cout_pad, std::vector<uint16_t>& out);
+// lds_order: the image g_conv3_lds reads -- the lane groups (lane >> 4) = 0..3 hold the octets {0, 2, 1, 3} of the 32.
+void pack_generic(const ConvWeights& c, int ksize, int cin_pad, int cout_pad, std::vector<uint16_t>& out, bool lds_order = false);
 
 }  // namespace uva

@@ -103,6 +103,172 @@ __global__ __launch_bounds__(256) void g_conv(const _Float16* in, int cin_pad, c
     }
 }
 
+// ---- g_conv3_lds: the 3x3 convolution of the generic executor with both operands through LDS ---------------------
+// g_conv<3> above fetches every B fragment nine times from L2 (once per tap) and every weight fragment once per wave:
+// it runs at ~6 % of the MFMA peak.  Here a workgroup (4 waves) owns an 8 x 32 output tile:
+//   * its 10 x 34 halo tile of the input array goes to LDS once (all cin channels; pixel stride cin*2 + 16 bytes: an odd
+//     number of 16-byte units, so that the 16 pixels of a fragment land on 16 different units);
+//   * the weights go through LDS one tap at a time (cin/32 k-steps x 1 KiB per 16 output channels), the next tap's
+//     already on their way from L2 in registers while this tap's k-steps run: two workgroup barriers per tap;
+//   * a wave computes 2 rows x 32 pixels x all output channels (4 fragments x MBN blocks of v_mfma_f32_16x16x32_f16).
+// LDS reads are conflict-free for the same reason as in sub10_kernel: MFMA column p holds pixel gpix(p) (even pixels in
+// the lanes {0-3,12-15}, odd ones in {4-11}: `ds_read_b128` is served in groups of 8 lanes of K-octet group o and 8 of
+// o^1), and the octet groups o = 0..3 of a k-step read the 16-byte units {0, 2, 1, 3} of the 64 bytes of their 32
+// channels -- o and o^1 two units apart (pack_generic(..., lds_order = true) arranges the weights to match).
+// The output goes to channels [out_coff, out_coff + cout) of an array whose pixel stride may be larger (a dense block's
+// concatenation buffer: the Concat layers of an RRDB then cost nothing).
+struct GConvArgs {
+    const _Float16* in;           // zero-bordered array, pixel stride in_stride elements
+    int in_stride, cin_pad;       // channels read: [0, cin_pad), a multiple of 32
+    const half8* wpk;             // pack_generic(lds_order) image: [tap][cin_pad/32][cout_pad/16][64][8]
+    const float* bias;            // [cout_pad] (zero padded) or nullptr
+    _Float16* out;
+    int out_stride, out_coff, cout;
+    int h, w;
+    int has_act;
+    float slope;
+};
+constexpr int GC_TH = 8, GC_TW = 32, GC_PH = GC_TH + 2, GC_PW = GC_TW + 2, GC_NPIX = GC_PH * GC_PW;
+inline size_t g_conv3_lds_bytes(int cin_pad, int mbn) { return (size_t)GC_NPIX * (cin_pad * 2 + 16) + (size_t)(cin_pad / 32) * mbn * 1024; }
+__device__ __forceinline__ int gpix(int p) { return p < 4 ? 2 * p : p >= 12 ? 2 * (p - 8) : 2 * (p - 4) + 1; }
+
+template <int MBN>
+__global__ __launch_bounds__(256) void g_conv3_lds(GConvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char gsm[];
+    const int pstride = a.cin_pad * 2 + 16;                     // bytes per pixel in the LDS tile
+    char* const tile = gsm;
+    char* const wbuf = gsm + (size_t)GC_NPIX * pstride;          // one tap: cin/32 x MBN KiB
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int p = lane & 15, o = lane >> 4, pix = gpix(p);
+    const int x0 = blockIdx.x * GC_TW, y0 = blockIdx.y * GC_TH;
+    const int c32n = a.cin_pad / 32;
+    const int units = a.cin_pad / 8;                            // 16-byte units per pixel
+
+    // Weights: one TAP at a time (cin/32 k-steps x MBN KiB) through a single LDS buffer; the next tap's travel from L2 in
+    // registers while this tap's k-steps run -- a whole tap of MFMAs (>= 1 000 cycles) to cover the latency.
+    constexpr int WMAX = 6 * MBN * 64 / 256 + 1;                 // 16-byte units per thread and tap, cin <= 192
+    const int wunits = c32n * MBN * 64;                          // units per tap
+    half8 wreg[WMAX];
+    auto wfetch = [&](int tap) {
+#pragma unroll
+        for (int k = 0; k < WMAX; ++k)
+            if (tid + 256 * k < wunits) wreg[k] = a.wpk[(size_t)tap * wunits + tid + 256 * k];
+    };
+    auto wstore = [&]() {
+#pragma unroll
+        for (int k = 0; k < WMAX; ++k)
+            if (tid + 256 * k < wunits) *(half8*)(wbuf + (size_t)(tid + 256 * k) * 16) = wreg[k];
+    };
+    wfetch(0);
+    // halo tile: array rows y0 .. y0+9, columns x0 .. x0+33 (the array carries a one-pixel zero border: pixel (y, x) sits
+    // at row y+1, column x+1); outside the array: zeros
+    // (a tile row is 34 consecutive pixels of the array; the pixel of unit j is j / units by a multiplication, exact for
+    // j < 34 * 24).  One workgroup per CU means nobody else keeps the memory pipe busy: five rows' worth of loads -- 20
+    // per thread, 68 KiB per CU -- are in flight before the first is stored (Valar: 3.41 frames/s; all ten rows at once
+    // 3.26; a plain load-store loop 2.6).
+    {
+        const unsigned inv = (65536u + units - 1) / units;
+        const int row_units = GC_PW * units;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            uint4 v[5][4];
+#pragma unroll
+            for (int rr = 0; rr < 5; ++rr) {
+                const int r = 5 * half + rr, ay = y0 + r;
+                const _Float16* const grow = a.in + ((size_t)ay * (a.w + 2) + x0) * a.in_stride;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int j = tid + 256 * k;
+                    const int c = (int)(((unsigned)j * inv) >> 16), u = j - c * units;
+                    v[rr][k] = make_uint4(0, 0, 0, 0);
+                    if (j < row_units && ay <= a.h + 1 && x0 + c <= a.w + 1) v[rr][k] = *(const uint4*)(grow + (size_t)c * a.in_stride + 8 * u);
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 5; ++rr) {
+                char* const lrow = tile + (size_t)(5 * half + rr) * GC_PW * pstride;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int j = tid + 256 * k;
+                    const int c = (int)(((unsigned)j * inv) >> 16), u = j - c * units;
+                    if (j < row_units) *(uint4*)(lrow + (size_t)c * pstride + 16 * u) = v[rr][k];
+                }
+            }
+        }
+    }
+    wstore();
+    __syncthreads();
+
+    f32x4 acc[4][MBN];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int m = 0; m < MBN; ++m) acc[f][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // fragment f = 2*n + c: row 2*wave + n, columns 16*c .. 16*c + 15 of the tile's interior
+    const int unit_of_o = o == 0 ? 0 : o == 1 ? 2 : o == 2 ? 1 : 3;
+    unsigned fbase[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) fbase[f] = (unsigned)(((2 * wave + (f >> 1)) * GC_PW + 16 * (f & 1) + pix) * pstride + unit_of_o * 16);
+    for (int tap = 0; tap < 9; ++tap) {
+        if (tap + 1 < 9) wfetch(tap + 1);
+        const unsigned toff = (unsigned)(((tap / 3) * GC_PW + tap % 3) * pstride);
+        // operands of k-step c32+1 are read while k-step c32's MFMAs run (one wave per SIMD: nobody else hides the latency)
+        half8 wa[2][MBN], bf[2][4];
+        auto rd = [&](int c32, half8 (&wv)[MBN], half8 (&bv)[4]) {
+            const char* const wcur = wbuf + (size_t)c32 * MBN * 1024;
+#pragma unroll
+            for (int m = 0; m < MBN; ++m) wv[m] = *(const half8*)(wcur + m * 1024 + lane * 16);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) bv[f] = *(const half8*)(tile + fbase[f] + toff + c32 * 64);
+        };
+        auto mm = [&](const half8 (&wv)[MBN], const half8 (&bv)[4]) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int m = 0; m < MBN; ++m) acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[m], bv[f], acc[f][m], 0, 0, 0);
+        };
+        rd(0, wa[0], bf[0]);
+        int c32 = 0;
+        for (; c32 + 2 <= c32n; c32 += 2) {
+            rd(c32 + 1, wa[1], bf[1]);
+            mm(wa[0], bf[0]);
+            if (c32 + 2 < c32n) rd(c32 + 2, wa[0], bf[0]);
+            mm(wa[1], bf[1]);
+        }
+        if (c32 < c32n) mm(wa[0], bf[0]);
+        if (tap + 1 < 9) {
+            __syncthreads();            // everybody is done with this tap's weights
+            wstore();
+            __syncthreads();
+        }
+    }
+    // bias, LeakyReLU (ncnn activation_type 2), fp16; lane (o, p): channels 16m + 4o .. +3 of pixel gpix(p)
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int y = y0 + 2 * wave + (f >> 1), x = x0 + 16 * (f & 1) + pix;
+        if (y >= a.h || x >= a.w) continue;
+        _Float16* const op = a.out + ((size_t)(y + 1) * (a.w + 2) + (x + 1)) * a.out_stride + a.out_coff;
+#pragma unroll
+        for (int m = 0; m < MBN; ++m) {
+            const int ch = 16 * m + 4 * o;
+            if (ch >= a.cout) continue;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = acc[f][m][j] + (a.bias ? a.bias[ch + j] : 0.f);
+                if (a.has_act) v[j] = v[j] > 0.f ? v[j] : v[j] * a.slope;
+            }
+            if (ch + 4 <= a.cout) {
+                half4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                *(half4*)(op + ch) = hv;
+            } else {
+                for (int j = 0; j < 4 && ch + j < a.cout; ++j) op[ch + j] = (_Float16)v[j];
+            }
+        }
+    }
+}
+
 // BinaryOp ADD (ca = cb = 1) and Eltwise SUM with coefficients: whole arrays (0*ca + 0*cb keeps the border zero)
 __global__ void g_axpby(const half8* a, float ca, const half8* b, float cb, half8* out, size_t n8)
 {
@@ -113,6 +279,22 @@ __global__ void g_axpby(const half8* a, float ca, const half8* b, float cb, half
 #pragma unroll
     for (int e = 0; e < 8; ++e) r[e] = (_Float16)((float)x[e] * ca + (float)y[e] * cb);
     out[i] = r;
+}
+
+// the same on channel ranges of arrays with different pixel strides (operands or result inside a dense chain's shared
+// array): c8 octets of channels per pixel, every pixel of the bordered array
+__global__ void g_axpby_strided(const _Float16* a, int sa, float ca, const _Float16* b, int sb, float cb, _Float16* out, int so, int c8,
+                                size_t npix)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix * c8) return;
+    const size_t pix = i / c8;
+    const int k = (int)(i - pix * c8);
+    const half8 x = *(const half8*)(a + pix * sa + 8 * k), y = *(const half8*)(b + pix * sb + 8 * k);
+    half8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (_Float16)((float)x[e] * ca + (float)y[e] * cb);
+    *(half8*)(out + pix * so + 8 * k) = r;
 }
 
 // Concat along channels: one input's c_in channels (a multiple of 8) into [c_off, c_off + c_in) of the output
@@ -188,7 +370,12 @@ __global__ void g_output_f32(const _Float16* in, int ho, int wo, int cpad, float
 
 // ---------------------------------------------------------------------------------------------------
 struct GenericDevice {
-    struct ConvDev { half8* wpk = nullptr; float* bias = nullptr; int cin_pad = 0, cout_pad = 0; };
+    struct ConvDev {
+        half8* wpk = nullptr;
+        half8* wpk_lds = nullptr;     // g_conv3_lds's image (3x3 convolutions with <= 64 output channels)
+        float* bias = nullptr;
+        int cin_pad = 0, cout_pad = 0;
+    };
     std::vector<ConvDev> convs;
     std::vector<float*> prelu;
     std::map<std::tuple<int, int, int>, std::vector<_Float16*>> pool;     // (h, w, channels) -> free zero-bordered arrays
@@ -200,6 +387,7 @@ struct GenericDevice {
     {
         for (auto& c : convs) {
             if (c.wpk) (void)hipFree(c.wpk);
+            if (c.wpk_lds) (void)hipFree(c.wpk_lds);
             if (c.bias) (void)hipFree(c.bias);
         }
         convs.clear();
