@@ -170,7 +170,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="2x_compact_1080p", choices=sorted(WORKLOADS))
-    ap.add_argument("--tile", type=int, default=960, help="reference tile size (960); 0 = whole frame")
+    ap.add_argument("--tile", type=int, default=None,
+                    help="reference tile size; 0 = whole frame.  Default: what the reference does for the workload's model -- "
+                         "960 (upscale_image, :499-516) for the 2x / 4x nets, 0 (apply_model, whole frame, :263-288) for the 1x net")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -206,6 +208,8 @@ def main():
 
     numa_cpus = pin_to_gpu_numa_node(local_rank)     # before any page-locked allocation of this rank
     key, stem, h, w = WORKLOADS[args.workload]
+    if args.tile is None:
+        args.tile = 0 if key == "1x" else 960
     net = ncnn.Net()
     net.set_vulkan_device(local_rank)
     base = os.path.join(ROOT, "models", stem)
@@ -286,6 +290,9 @@ def main():
         fused = layers_per_launch > 1.5
         kernel = "trunk2_kernel" if fused else ("trunk_kernel" if nf == 64 else "conv3x3_kernel")
         trunk_flops_per_launch = layers_per_launch * 2 * 9 * nf * nf * h * w        # algorithmic: un-tiled frame
+        whole_net = nf == 24 and layers_per_launch > nconv - 2.5    # sub10_kernel: all ten convolutions of the 1x net in one launch
+        if whole_net:
+            trunk_flops_per_launch = conv_flops_per_px(nf, nconv, s) * h * w
         avg_ms = trunk_ms / max(1, n_launch)
         achieved = trunk_flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         frame_flops = conv_flops_per_px(nf, nconv, s) * h * w
@@ -311,8 +318,9 @@ def main():
                 "numa_cpus_rank0": (len(numa_cpus) if numa_cpus else None),
             },
             "roofline": {
-                "kernel": (f"{kernel}<{nf}>" if nf == 64 else f"conv3x3_kernel<{nf},0,1>") +
-                          (f" ({int(round(layers_per_launch))} trunk layers {nf}->{nf} + PReLU per launch)"),
+                "kernel": ("sub10_kernel (the whole 1x net: 3->24, 8 x 24->24, 24->3, + input, one launch per frame)" if whole_net else
+                           (f"{kernel}<{nf}>" if nf == 64 else ("pair24_kernel" if fused else f"conv3x3_kernel<{nf},0,1>")) +
+                           (f" ({int(round(layers_per_launch))} trunk layers {nf}->{nf} + PReLU per launch)")),
                 "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "flops_per_launch": trunk_flops_per_launch, "avg_launch_ms": round(avg_ms, 4), "launches": n_launch,

@@ -14,6 +14,7 @@ done
 python bench.py --tile 0 --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_2x_whole_frame.json" 2>> "$OUT/bench.err"
 UVA_TRUNK_FUSION=0 python bench.py --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_unfused_trunk_kernel.json" 2>> "$OUT/bench.err"
 UVA_SUB10=0 python bench.py --workload 1x_hurrdeblur_1080p --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_1x_per_pair_kernels.json" 2>> "$OUT/bench.err"
+python bench.py --workload 1x_hurrdeblur_1080p --tile 960 --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_1x_tiled_960.json" 2>> "$OUT/bench.err"
 (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d /tmp/prof1x_$TAG -o p --output-format csv -- python $REPO/bench.py --workload 1x_hurrdeblur_1080p --tile 0 --steps 50 --warmup 5 --no-cpu-baseline > /dev/null 2>&1; cp $(find /tmp/prof1x_$TAG -name "*kernel_stats.csv" | head -1) "$OUT/${TAG}_kernel_stats_1x_rocprofv3.csv")
 bash tools/pmc_sub10.sh /tmp/pmc_sub10_$TAG > "$OUT/${TAG}_sub10_pmc.txt" 2>&1
 python tools/png_route_bench.py 384 > "$OUT/${TAG}_png_route_bench.txt" 2>&1
