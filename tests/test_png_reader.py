@@ -169,3 +169,17 @@ def test_png_reader_refuses_other_kinds_and_damage():
         pos += 12 + n
     assert decode(bytes(out))[0] == 1
     assert b"Adler" in _lib.load().uva_last_error()
+    # a header that claims a 16M x 16M image over a few hundred bytes of data: refused before anything is allocated
+    pos, out = 8, bytearray(png[:8])
+    while pos < len(png):
+        n, = struct.unpack(">I", png[pos:pos + 4])
+        kind, body = png[pos + 4:pos + 8], bytearray(png[pos + 8:pos + 8 + n])
+        if kind == b"IHDR":
+            body[0:8] = struct.pack(">II", 1 << 24, 1 << 24)
+        out += struct.pack(">I", n) + kind + body + struct.pack(">I", zlib.crc32(kind + bytes(body)) & 0xFFFFFFFF)
+        pos += 12 + n
+    L = _lib.load()
+    h, w = ctypes.c_int(0), ctypes.c_int(0)
+    buf = np.zeros(16, np.uint8)
+    assert L.uva_png_decode_bgr(bytes(out), len(out), buf.ctypes.data, 1 << 60, h, w) == 1
+    assert b"larger than its data" in L.uva_last_error()

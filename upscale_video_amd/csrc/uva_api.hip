@@ -1759,7 +1759,12 @@ int uva_png_decode_bgr(const uint8_t* file, size_t len, uint8_t* out, size_t cap
 {
     if (!file) return fail("null file image");
     std::string err;
-    const int rc = png_read_bgr(file, len, out, cap, h, w, err);
+    int rc;
+    try {
+        rc = png_read_bgr(file, len, out, cap, h, w, err);
+    } catch (const std::exception& e) {              // out of memory: an error, not a crash across the C ABI
+        return fail(std::string("PNG reader: ") + e.what());
+    }
     if (rc == 1) return fail(err);
     if (rc == 2) { fail("PNG of a kind the fast reader does not take (16-bit, palette or interlaced)"); return 2; }
     return 0;

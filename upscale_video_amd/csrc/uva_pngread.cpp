@@ -504,6 +504,9 @@ int png_read_bgr(const uint8_t* file, size_t len, uint8_t* out, size_t cap, int*
     if (!out) return 0;                                   // size query
     if (cap < need) { err = "PNG: output buffer too small"; return 1; }
     const int bpp = ctype == 0 ? 1 : ctype == 4 ? 2 : ctype == 2 ? 3 : 4;
+    // deflate cannot expand by more than 1032:1: a header that promises more than the IDAT data could hold is damage (or
+    // an attempt to make the reader allocate terabytes)
+    if ((size_t)h * ((size_t)w * bpp + 1) > idat.size() * 1032 + 1024) { err = "PNG: image larger than its data can be"; return 1; }
     raw.resize((size_t)h * ((size_t)w * bpp + 1) + 8);                    // + slack for the word-wise match copy
     if (!zlib_decompress(idat.data(), idat.size(), raw.data(), raw.size() - 8, err)) return 1;
     if (!unfilter(raw.data(), h, w, bpp, err)) return 1;
