@@ -129,7 +129,12 @@ struct GConvArgs {
     float slope;
 };
 constexpr int GC_TH = 8, GC_TW = 32, GC_PH = GC_TH + 2, GC_PW = GC_TW + 2, GC_NPIX = GC_PH * GC_PW;
-inline size_t g_conv3_lds_bytes(int cin_pad, int mbn) { return (size_t)GC_NPIX * (cin_pad * 2 + 16) + (size_t)(cin_pad / 32) * mbn * 1024; }
+inline size_t g_conv3_lds_bytes(int cin_pad, int mbn)
+{
+    const size_t work = (size_t)GC_NPIX * (cin_pad * 2 + 16) + (size_t)(cin_pad / 32) * mbn * 1024;   // halo tile + one tap of weights
+    const size_t stage = (size_t)GC_TH * GC_TW * (mbn * 32 + 16);                                      // the epilogue's output staging tile
+    return work > stage ? work : stage;
+}
 __device__ __forceinline__ int gpix(int p) { return p < 4 ? 2 * p : p >= 12 ? 2 * (p - 8) : 2 * (p - 4) + 1; }
 
 template <int MBN>
@@ -243,28 +248,42 @@ __global__ __launch_bounds__(256) void g_conv3_lds(GConvArgs a)
             __syncthreads();
         }
     }
-    // bias, LeakyReLU (ncnn activation_type 2), fp16; lane (o, p): channels 16m + 4o .. +3 of pixel gpix(p)
+    // bias, LeakyReLU (ncnn activation_type 2), fp16; lane (o, p): channels 16m + 4o .. +3 of pixel gpix(p).  Through LDS
+    // (the input tile is dead by now): every pixel's channels then leave as consecutive 16-byte units -- a whole tile row
+    // in one piece when the output array is dense -- instead of 8-byte pieces at a pixel stride.
+    __syncthreads();
+    constexpr int OUTB = MBN * 32 + 16;                           // bytes per pixel in the staging tile (odd number of units)
+    char* const stage = gsm;
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
-        const int y = y0 + 2 * wave + (f >> 1), x = x0 + 16 * (f & 1) + pix;
-        if (y >= a.h || x >= a.w) continue;
-        _Float16* const op = a.out + ((size_t)(y + 1) * (a.w + 2) + (x + 1)) * a.out_stride + a.out_coff;
+        const int px = (2 * wave + (f >> 1)) * GC_TW + 16 * (f & 1) + pix;
 #pragma unroll
         for (int m = 0; m < MBN; ++m) {
             const int ch = 16 * m + 4 * o;
-            if (ch >= a.cout) continue;
             float v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                v[j] = acc[f][m][j] + (a.bias ? a.bias[ch + j] : 0.f);
+                v[j] = acc[f][m][j] + (a.bias ? a.bias[min(ch + j, 16 * MBN - 1)] : 0.f);
                 if (a.has_act) v[j] = v[j] > 0.f ? v[j] : v[j] * a.slope;
             }
-            if (ch + 4 <= a.cout) {
-                half4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                *(half4*)(op + ch) = hv;
-            } else {
-                for (int j = 0; j < 4 && ch + j < a.cout; ++j) op[ch + j] = (_Float16)v[j];
-            }
+            *(half4*)(stage + px * OUTB + ch * 2) = half4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        }
+    }
+    __syncthreads();
+    if (a.cout % 8 == 0) {
+        const int upp = a.cout / 8;                               // 16-byte units per pixel
+        for (int i = tid; i < GC_TH * GC_TW * upp; i += 256) {
+            const int px = i / upp, u = i - px * upp;
+            const int y = y0 + px / GC_TW, x = x0 + px % GC_TW;
+            if (y < a.h && x < a.w)
+                *(uint4*)(a.out + ((size_t)(y + 1) * (a.w + 2) + (x + 1)) * a.out_stride + a.out_coff + 8 * u) = *(const uint4*)(stage + px * OUTB + 16 * u);
+        }
+    } else {
+        for (int i = tid; i < GC_TH * GC_TW * a.cout; i += 256) {
+            const int px = i / a.cout, c = i - px * a.cout;
+            const int y = y0 + px / GC_TW, x = x0 + px % GC_TW;
+            if (y < a.h && x < a.w)
+                a.out[((size_t)(y + 1) * (a.w + 2) + (x + 1)) * a.out_stride + a.out_coff + c] = *(const _Float16*)(stage + px * OUTB + 2 * c);
         }
     }
 }
