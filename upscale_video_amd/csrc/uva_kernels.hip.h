@@ -1376,9 +1376,8 @@ __global__ __launch_bounds__(64 * S10_NW, 1) void sub10_kernel(Sub10Args a)
     // every wave runs the same number of steps = barriers, whatever code it sits in
     const int nsteps = (nrows + S10_DRAIN + 1) & ~1;
     // Waves w, w+4, w+8 share a SIMD: two trunk layers and one half of the first or the last layer each -- the same
-    // MFMA and VALU load on all four.  The light waves go first on their SIMD: their long scalar-ish epilogues (u8
-    // conversion, byte stores) then run under the trunk waves' MFMAs instead of after them.
-    if (wave >= 8) __builtin_amdgcn_s_setprio(3);
+    // MFMA and VALU load on all four.  (No s_setprio: with the light waves halved, raising them or the trunk waves
+    // measured 2 % slower than leaving the arbiter alone, profiles/r02_sub10_experiments.txt.)
     if (wave < 8) sub10_body<false, 0, 5>(a, L, wave, wave + 1, lane, nrows, nsteps);
     else if (wave == 8) sub10_head<0>(a, L, wave, lane, nrows, nsteps);
     else if (wave == 9) sub10_head<1>(a, L, wave, lane, nrows, nsteps);
