@@ -1205,6 +1205,8 @@ __device__ __forceinline__ void sub10_head(const Sub10Args& a, const Sub10Lds L,
 // even number of 16-byte units (uva_model.h SUB16_OCTET): one half of a group then touches even units only, the other
 // odd ones.
 __device__ __forceinline__ int sub10_pix(int p) { return p < 4 ? 2 * p : p >= 12 ? 2 * (p - 8) : 2 * (p - 4) + 1; }
+// window row (0..2) of the octet that k-step ks gives to octet group o (octet 27 = none reads where 26 does)
+__host__ __device__ constexpr int sub10_dy(int ks, int o) { return ((SUB16_OCTET[ks][o] > 26 ? 26 : SUB16_OCTET[ks][o]) / 3) / 3; }
 
 // One row of one layer, fragments F0..F1-1.  The rings are handed over as __restrict__ pointers -- `rin` (plus the
 // per-k-step offsets adr[]) is only read, `px0` / `px1` (this lane's 8 + 4 bytes of fragment 0's pixel in the output ring
@@ -1336,11 +1338,17 @@ __device__ __forceinline__ void sub10_body(const Sub10Args& a, const Sub10Lds L,
             else
                 sub10_row<TAIL, F0, F1, true, KS, MB>(L.smem, px + 8 * o, px + 32 + 4 * o, res, dst, adr, wgt, binit, q, x0c, a.w,
                                                       row_in, (ye & 1) != 0, pix, o);
-            // next row: every address one ring row on, wrapping after the fourth
+            // Next row: every address one ring row on, wrapping after the fourth.  Whether an address wraps depends only
+            // on the window row dy its octet comes from -- ring row (d + dy - 1) & 3 now -- so the three increments are
+            // scalars; and in all but two k-steps (SUB16_OCTET) the four octet groups share one dy: one add each.
+            int inc[3];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) inc[dy] = ((d + dy - 1) & 3) == 3 ? -3 * S10_ROWB : S10_ROWB;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const unsigned n0 = adr[ks] + S10_ROWB;
-                adr[ks] = n0 >= in_ring + S10_RINGB ? n0 - S10_RINGB : n0;
+                const int d0 = sub10_dy(ks, 0), d1 = sub10_dy(ks, 1), d2 = sub10_dy(ks, 2), d3 = sub10_dy(ks, 3);
+                if (d0 == d1 && d1 == d2 && d2 == d3) adr[ks] += (unsigned)inc[d0];
+                else adr[ks] += (unsigned)(o == 0 ? inc[d0] : o == 1 ? inc[d1] : o == 2 ? inc[d2] : inc[d3]);
             }
         }
         S10_STAMP(2);
