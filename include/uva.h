@@ -25,13 +25,14 @@
 extern "C" {
 #endif
 
-#define UVA_ABI_VERSION 7   /* 2: + uva_net_submit_u8 / uva_net_collect_u8 / uva_host_alloc / uva_host_free;
+#define UVA_ABI_VERSION 8   /* 2: + uva_net_submit_u8 / uva_net_collect_u8 / uva_host_alloc / uva_host_free;
                                3: + uva_get_gpu_pci_bus_id, uva_debug_trunk2_schedule;
                                4: + uva_denoise_u8, uva_debug_denoise_stage; generic graphs (4x_Valar_v1) load;
                                5: + uva_debug_sub10_rows;
                                6: + uva_net_submit_u8_png, uva_png_workspace_bytes, uva_png_assemble, uva_png_deflate_u8,
                                   uva_debug_png_deflate_host;
-                               7: + uva_png_decode_bgr, uva_debug_zlib_decompress */
+                               7: + uva_png_decode_bgr, uva_debug_zlib_decompress;
+                               8: + uva_net_debug_generic_plan */
 
 typedef struct uva_net uva_net;
 
@@ -201,6 +202,11 @@ int uva_net_debug_packed_weights(uva_net* net, int conv_idx, uint16_t* out, size
 int uva_debug_trunk2_schedule(int h, int w, int tile_size, int border, int grid, uint32_t* steps_words,
                               size_t capacity_words, size_t* needed_words, int* nsteps, int* stride,
                               long long* plane_info, int max_planes, int* nplanes, long long* guard_bytes);
+
+/* Test hook (host only, after load_param of a generic graph such as 4x_Valar_v1): what the executor planned --
+ * info[0] dense chains sharing one array, [1] Concat layers, [2] of them free (every input already in place), [3] copying
+ * their first input only, [4] 3x3 convolutions that take the LDS-tiled kernel, [5] channels of the widest shared array. */
+int uva_net_debug_generic_plan(const uva_net* net, int* info);
 
 /* Test hook (host only): the row lists sub10_kernel (the whole 24-feature 1x net, one launch) walks for an h x w
  * frame on `grid` workgroups.  Every workgroup has `*stride` 16-byte entries of 4 words {y, x0, emit, 0}

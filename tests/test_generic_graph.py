@@ -59,6 +59,30 @@ def test_numpy_restatement_agrees_with_the_c_oracle_on_the_real_compact_weights(
         assert d.max() <= 1 and (d > 0).mean() < 1e-3          # exact .5 ties may fall either way
 
 
+def test_executor_plan_for_valar_and_the_mini_graph(uva, mini):
+    """The plan the executor derives from the graph alone (csrc/uva_generic.h plan_concat_groups): Valar's 23 RRDBs x 3
+    dense blocks become 69 chains of four Concats each -- three of them free, the first copying x only -- in arrays of
+    64 + 4 x 32 channels, and all but the 1x1 convolutions take the LDS-tiled kernel."""
+    import ctypes
+    from upscale_video_amd import _lib
+    L = _lib.load()
+    net = uva.Net()
+    assert net.load_param(VALAR) == 0, getattr(net, "last_error", "")
+    info = (ctypes.c_int * 8)()
+    assert L.uva_net_debug_generic_plan(net._h, info) == 0, L.uva_last_error()
+    groups, concats, free, first, lds_convs, widest = list(info)[:6]
+    assert (groups, concats, free, first, widest) == (69, 276, 207, 69, 192)
+    assert lds_convs == 420 - 69                         # the one 1x1 convolution of every dense block stays on the plain kernel
+    p, b, _ = mini
+    net2 = uva.Net()
+    assert net2.load_param(p) == 0 and net2.load_model(b) == 0
+    assert L.uva_net_debug_generic_plan(net2._h, info) == 0
+    assert info[0] >= 1 and info[2] + info[3] == info[1]         # the mini RRDB graph exercises the shared arrays too
+    compact = uva.Net()
+    assert compact.load_param(model_paths("2x")[0]) == 0
+    assert L.uva_net_debug_generic_plan(compact._h, info) != 0   # an SRVGGNetCompact graph never reaches this executor
+
+
 def test_loader_accepts_valar_and_checks_the_weight_stream(uva, tmp_path, mini):
     from oracle import generic_oracle as go
     net = uva.Net()

@@ -1569,6 +1569,28 @@ int uva_net_num_convs(const uva_net* n)
     return n->g.param_loaded ? (int)n->g.convs.size() : 0;
 }
 
+int uva_net_debug_generic_plan(const uva_net* n, int* info)
+{
+    if (!n || !info) return fail("null argument");
+    if (!n->generic || !n->gg.param_loaded) return fail("not a generic graph");
+    const GenericGraph& g = n->gg;
+    info[0] = (int)g.group_channels.size();
+    info[1] = info[2] = info[3] = 0;
+    for (const GLayer& l : g.layers)
+        if (l.kind == GLayer::CONCAT) { info[1]++; info[2] += l.concat_mode == 2; info[3] += l.concat_mode == 1; }
+    int lds = 0;
+    for (const GLayer& l : g.layers)
+        if (l.kind == GLayer::CONV && l.ksize == 3) {
+            const ConvWeights& c = g.convs[l.conv];
+            const int cin_pad = (c.cin + 31) / 32 * 32, cout_pad = (c.cout + 15) / 16 * 16;
+            lds += cout_pad <= 64 && cin_pad <= 192 && g_conv3_lds_bytes(cin_pad, cout_pad / 16) <= 160 * 1024;
+        }
+    info[4] = lds;
+    info[5] = 0;
+    for (int c : g.group_channels) info[5] = std::max(info[5], c);
+    return 0;
+}
+
 int uva_net_synchronize(uva_net* n)
 {
     if (!n) return fail("null net");
