@@ -137,7 +137,7 @@ struct uva_net {
     float *d_fin = nullptr, *d_fout = nullptr;
     size_t d_fin_cap = 0, d_fout_cap = 0;
     _Float16* d_sink = nullptr;   // where out-of-image lanes of the trunk kernel store to
-    bool attr_set[16] = {false};  // hipFuncAttributeMaxDynamicSharedMemorySize done for kernel slot k on this net's device
+    bool attr_set[24] = {false};  // hipFuncAttributeMaxDynamicSharedMemorySize done for kernel slot k on this net's device
     int last_act_buf = 0;         // which ping-pong buffer the last run_graph() left its last trunk activation in
     bool generic_lds_conv = true; // generic graphs: 3x3 convolutions through g_conv3_lds (UVA_GENERIC_LDS=0: the plain g_conv<3>)
     bool fuse_all = true;         // 24-feature 1x net: all ten convolutions in one launch (sub10_kernel); UVA_SUB10=0 turns it off
@@ -606,9 +606,9 @@ int ensure_device(uva_net* n)
             std::vector<uint16_t> pk;
             pack_generic(c, gl.ksize, cd.cin_pad, cd.cout_pad, pk);
             if (upload(&cd.wpk, pk.data(), pk.size() * 2, n->stream)) return 1;
-            if (gl.ksize == 3 && cd.cout_pad <= 64 && cd.cin_pad <= 192 && g_conv3_lds_bytes(cd.cin_pad, cd.cout_pad / 16) <= 160 * 1024) {
+            if (cd.cout_pad <= 64 && cd.cin_pad <= 192 && g_conv3_lds_bytes(cd.cin_pad, cd.cout_pad / 16, gl.ksize) <= 160 * 1024) {
                 std::vector<uint16_t> pkl;
-                pack_generic(c, 3, cd.cin_pad, cd.cout_pad, pkl, true);
+                pack_generic(c, gl.ksize, cd.cin_pad, cd.cout_pad, pkl, true);
                 if (upload(&cd.wpk_lds, pkl.data(), pkl.size() * 2, n->stream)) return 1;
                 HIP_TRY(hipStreamSynchronize(n->stream));
             }
@@ -1100,9 +1100,9 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
         case GLayer::CONV: {
             const GenericDevice::ConvDev& cd = n->gd.convs[gl.conv];
             const GBuf& a = in(0);
-            if ((group_of(gl.out[0]) >= 0 || group_of(root(gl.in[0])) >= 0) && !(gl.ksize == 3 && cd.wpk_lds))
+            if ((group_of(gl.out[0]) >= 0 || group_of(root(gl.in[0])) >= 0) && !cd.wpk_lds)
                 return fail("generic executor: a dense-chain convolution without the LDS kernel (plan_concat_groups and ensure_device disagree)");
-            if (gl.ksize == 3 && cd.wpk_lds && n->generic_lds_conv) {
+            if (cd.wpk_lds && n->generic_lds_conv) {
                 GConvArgs ga;
                 std::memset(&ga, 0, sizeof ga);
                 ga.in = a.p; ga.in_stride = a.cpad; ga.cin_pad = cd.cin_pad;
@@ -1111,7 +1111,7 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
                 ga.h = a.h; ga.w = a.w;
                 ga.has_act = gl.has_act ? 1 : 0; ga.slope = gl.act_slope;
                 const int mbn = cd.cout_pad / 16;
-                const size_t lds = g_conv3_lds_bytes(cd.cin_pad, mbn);
+                const size_t lds = g_conv3_lds_bytes(cd.cin_pad, mbn, gl.ksize);
                 const dim3 g3((a.w + GC_TW - 1) / GC_TW, (a.h + GC_TH - 1) / GC_TH);
                 auto launch = [&](auto kern, int slot) -> int {
                     if (!n->attr_set[slot]) {
@@ -1121,7 +1121,13 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
                     hipLaunchKernelGGL(kern, g3, dim3(256), lds, n->stream, ga);
                     return 0;
                 };
-                if (mbn == 1) { if (launch(g_conv3_lds<1>, 11)) return 1; }
+                if (gl.ksize == 1) {
+                    if (mbn == 1) { if (launch(g_conv3_lds<1, 1>, 16)) return 1; }
+                    else if (mbn == 2) { if (launch(g_conv3_lds<2, 1>, 17)) return 1; }
+                    else if (mbn == 3) { if (launch(g_conv3_lds<3, 1>, 18)) return 1; }
+                    else { if (launch(g_conv3_lds<4, 1>, 19)) return 1; }
+                }
+                else if (mbn == 1) { if (launch(g_conv3_lds<1>, 11)) return 1; }
                 else if (mbn == 2) { if (launch(g_conv3_lds<2>, 12)) return 1; }
                 else if (mbn == 3) { if (launch(g_conv3_lds<3>, 13)) return 1; }
                 else { if (launch(g_conv3_lds<4>, 14)) return 1; }

@@ -128,18 +128,22 @@ struct GConvArgs {
     int has_act;
     float slope;
 };
-constexpr int GC_TH = 8, GC_TW = 32, GC_PH = GC_TH + 2, GC_PW = GC_TW + 2, GC_NPIX = GC_PH * GC_PW;
-inline size_t g_conv3_lds_bytes(int cin_pad, int mbn)
+constexpr int GC_TH = 8, GC_TW = 32;
+// (ksize 1: the same kernel without the halo and with a single tap -- the RRDBs' 1x1 residual convolutions)
+inline size_t g_conv3_lds_bytes(int cin_pad, int mbn, int ksize = 3)
 {
-    const size_t work = (size_t)GC_NPIX * (cin_pad * 2 + 16) + (size_t)(cin_pad / 32) * mbn * 1024;   // halo tile + one tap of weights
+    const size_t npix = (size_t)(GC_TH + ksize - 1) * (GC_TW + ksize - 1);
+    const size_t work = npix * (cin_pad * 2 + 16) + (size_t)(cin_pad / 32) * mbn * 1024;              // halo tile + one tap of weights
     const size_t stage = (size_t)GC_TH * GC_TW * (mbn * 32 + 16);                                      // the epilogue's output staging tile
     return work > stage ? work : stage;
 }
 __device__ __forceinline__ int gpix(int p) { return p < 4 ? 2 * p : p >= 12 ? 2 * (p - 8) : 2 * (p - 4) + 1; }
 
-template <int MBN>
+template <int MBN, int KSZ = 3>
 __global__ __launch_bounds__(256) void g_conv3_lds(GConvArgs a)
 {
+    constexpr int GC_PH = GC_TH + KSZ - 1, GC_PW = GC_TW + KSZ - 1, GC_NPIX = GC_PH * GC_PW, NTAP = KSZ * KSZ, ORG = KSZ == 3 ? 0 : 1;
+    constexpr int RB = GC_PH / 2;                                // tile rows per load batch
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     const int pstride = a.cin_pad * 2 + 16;                     // bytes per pixel in the LDS tile
     char* const tile = gsm;
@@ -177,22 +181,22 @@ __global__ __launch_bounds__(256) void g_conv3_lds(GConvArgs a)
         const int row_units = GC_PW * units;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            uint4 v[5][4];
+            uint4 v[RB][4];
 #pragma unroll
-            for (int rr = 0; rr < 5; ++rr) {
-                const int r = 5 * half + rr, ay = y0 + r;
-                const _Float16* const grow = a.in + ((size_t)ay * (a.w + 2) + x0) * a.in_stride;
+            for (int rr = 0; rr < RB; ++rr) {
+                const int r = RB * half + rr, ay = y0 + ORG + r;
+                const _Float16* const grow = a.in + ((size_t)ay * (a.w + 2) + x0 + ORG) * a.in_stride;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int j = tid + 256 * k;
                     const int c = (int)(((unsigned)j * inv) >> 16), u = j - c * units;
                     v[rr][k] = make_uint4(0, 0, 0, 0);
-                    if (j < row_units && ay <= a.h + 1 && x0 + c <= a.w + 1) v[rr][k] = *(const uint4*)(grow + (size_t)c * a.in_stride + 8 * u);
+                    if (j < row_units && ay <= a.h + 1 && x0 + ORG + c <= a.w + 1) v[rr][k] = *(const uint4*)(grow + (size_t)c * a.in_stride + 8 * u);
                 }
             }
 #pragma unroll
-            for (int rr = 0; rr < 5; ++rr) {
-                char* const lrow = tile + (size_t)(5 * half + rr) * GC_PW * pstride;
+            for (int rr = 0; rr < RB; ++rr) {
+                char* const lrow = tile + (size_t)(RB * half + rr) * GC_PW * pstride;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int j = tid + 256 * k;
@@ -215,9 +219,9 @@ __global__ __launch_bounds__(256) void g_conv3_lds(GConvArgs a)
     unsigned fbase[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) fbase[f] = (unsigned)(((2 * wave + (f >> 1)) * GC_PW + 16 * (f & 1) + pix) * pstride + unit_of_o * 16);
-    for (int tap = 0; tap < 9; ++tap) {
-        if (tap + 1 < 9) wfetch(tap + 1);
-        const unsigned toff = (unsigned)(((tap / 3) * GC_PW + tap % 3) * pstride);
+    for (int tap = 0; tap < NTAP; ++tap) {
+        if (tap + 1 < NTAP) wfetch(tap + 1);
+        const unsigned toff = (unsigned)(((tap / KSZ) * GC_PW + tap % KSZ) * pstride);
         // operands of k-step c32+1 are read while k-step c32's MFMAs run (one wave per SIMD: nobody else hides the latency)
         half8 wa[2][MBN], bf[2][4];
         auto rd = [&](int c32, half8 (&wv)[MBN], half8 (&bv)[4]) {
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(256) void g_conv3_lds(GConvArgs a)
             mm(wa[1], bf[1]);
         }
         if (c32 < c32n) mm(wa[0], bf[0]);
-        if (tap + 1 < 9) {
+        if (tap + 1 < NTAP) {
             __syncthreads();            // everybody is done with this tap's weights
             wstore();
             __syncthreads();
