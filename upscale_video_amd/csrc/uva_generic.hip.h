@@ -129,11 +129,13 @@ struct GConvArgs {
     float slope;
 };
 constexpr int GC_TH = 8, GC_TW = 32;
+constexpr int GC_CH = 2;          // input channels go through LDS 64 at a time (two k-steps of 32)
 // (ksize 1: the same kernel without the halo and with a single tap -- the RRDBs' 1x1 residual convolutions)
 inline size_t g_conv3_lds_bytes(int cin_pad, int mbn, int ksize = 3)
 {
     const size_t npix = (size_t)(GC_TH + ksize - 1) * (GC_TW + ksize - 1);
-    const size_t work = npix * (cin_pad * 2 + 16) + (size_t)(cin_pad / 32) * mbn * 1024;              // halo tile + one tap of weights
+    const int cn = std::min(GC_CH, cin_pad / 32);
+    const size_t work = npix * (cn * 64 + 16) + (size_t)ksize * cn * mbn * 1024;                       // halo tile chunk + one row of taps
     const size_t stage = (size_t)GC_TH * GC_TW * (mbn * 32 + 16);                                      // the epilogue's output staging tile
     return work > stage ? work : stage;
 }
@@ -142,94 +144,115 @@ __device__ __forceinline__ int gpix(int p) { return p < 4 ? 2 * p : p >= 12 ? 2 
 template <int MBN, int KSZ = 3>
 __global__ __launch_bounds__(256) void g_conv3_lds(GConvArgs a)
 {
-    constexpr int GC_PH = GC_TH + KSZ - 1, GC_PW = GC_TW + KSZ - 1, GC_NPIX = GC_PH * GC_PW, NTAP = KSZ * KSZ, ORG = KSZ == 3 ? 0 : 1;
+    constexpr int GC_PH = GC_TH + KSZ - 1, GC_PW = GC_TW + KSZ - 1, GC_NPIX = GC_PH * GC_PW, ORG = KSZ == 3 ? 0 : 1;
     constexpr int RB = GC_PH / 2;                                // tile rows per load batch
     extern __shared__ __attribute__((aligned(16))) char gsm[];
-    const int pstride = a.cin_pad * 2 + 16;                     // bytes per pixel in the LDS tile
-    char* const tile = gsm;
-    char* const wbuf = gsm + (size_t)GC_NPIX * pstride;          // one tap: cin/32 x MBN KiB
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int p = lane & 15, o = lane >> 4, pix = gpix(p);
     const int x0 = blockIdx.x * GC_TW, y0 = blockIdx.y * GC_TH;
     const int c32n = a.cin_pad / 32;
-    const int units = a.cin_pad / 8;                            // 16-byte units per pixel
+    const int cn_max = min(GC_CH, c32n);
+    char* const tile = gsm;
+    char* const wbuf = gsm + (size_t)GC_NPIX * (cn_max * 64 + 16);   // one ROW of taps of the current channel chunk
 
-    // Weights: one TAP at a time (cin/32 k-steps x MBN KiB) through a single LDS buffer; the next tap's travel from L2 in
-    // registers while this tap's k-steps run -- a whole tap of MFMAs (>= 1 000 cycles) to cover the latency.
-    constexpr int WMAX = 6 * MBN * 64 / 256 + 1;                 // 16-byte units per thread and tap, cin <= 192
-    const int wunits = c32n * MBN * 64;                          // units per tap
+    // The input channels go through LDS in chunks of 64 (the tile of a 192-channel convolution would fill the LDS: one
+    // workgroup per CU, its load, compute and store phases in series -- with 57 KiB per workgroup two or three share a
+    // CU and overlap them), the weights one row of taps (KSZ taps x chunk) at a time, the next row's on their way in
+    // registers while this one is used.  Stage s = (chunk, tap row).
+    constexpr int WMAX = (KSZ * GC_CH * MBN * 64 + 255) / 256;   // 16-byte units per thread and weight stage
+    const int nstage = ((c32n + GC_CH - 1) / GC_CH) * KSZ;
     half8 wreg[WMAX];
-    auto wfetch = [&](int tap) {
+    auto wfetch = [&](int s) {
+        const int c0 = (s / KSZ) * GC_CH, cn = min(GC_CH, c32n - c0), tr = s % KSZ;
+        const int per_tap = cn * MBN * 64;                       // units per tap of this chunk
 #pragma unroll
-        for (int k = 0; k < WMAX; ++k)
-            if (tid + 256 * k < wunits) wreg[k] = a.wpk[(size_t)tap * wunits + tid + 256 * k];
-    };
-    auto wstore = [&]() {
-#pragma unroll
-        for (int k = 0; k < WMAX; ++k)
-            if (tid + 256 * k < wunits) *(half8*)(wbuf + (size_t)(tid + 256 * k) * 16) = wreg[k];
-    };
-    wfetch(0);
-    // halo tile: array rows y0 .. y0+9, columns x0 .. x0+33 (the array carries a one-pixel zero border: pixel (y, x) sits
-    // at row y+1, column x+1); outside the array: zeros
-    // (a tile row is 34 consecutive pixels of the array; the pixel of unit j is j / units by a multiplication, exact for
-    // j < 34 * 24).  One workgroup per CU means nobody else keeps the memory pipe busy: five rows' worth of loads -- 20
-    // per thread, 68 KiB per CU -- are in flight before the first is stored (Valar: 3.41 frames/s; all ten rows at once
-    // 3.26; a plain load-store loop 2.6).
-    {
-        const unsigned inv = (65536u + units - 1) / units;
-        const int row_units = GC_PW * units;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            uint4 v[RB][4];
-#pragma unroll
-            for (int rr = 0; rr < RB; ++rr) {
-                const int r = RB * half + rr, ay = y0 + ORG + r;
-                const _Float16* const grow = a.in + ((size_t)ay * (a.w + 2) + x0 + ORG) * a.in_stride;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int j = tid + 256 * k;
-                    const int c = (int)(((unsigned)j * inv) >> 16), u = j - c * units;
-                    v[rr][k] = make_uint4(0, 0, 0, 0);
-                    if (j < row_units && ay <= a.h + 1 && x0 + ORG + c <= a.w + 1) v[rr][k] = *(const uint4*)(grow + (size_t)c * a.in_stride + 8 * u);
-                }
-            }
-#pragma unroll
-            for (int rr = 0; rr < RB; ++rr) {
-                char* const lrow = tile + (size_t)(RB * half + rr) * GC_PW * pstride;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int j = tid + 256 * k;
-                    const int c = (int)(((unsigned)j * inv) >> 16), u = j - c * units;
-                    if (j < row_units) *(uint4*)(lrow + (size_t)c * pstride + 16 * u) = v[rr][k];
-                }
+        for (int k = 0; k < WMAX; ++k) {
+            const int j = tid + 256 * k;
+            if (j < KSZ * per_tap) {
+                const int t = j / per_tap, r = j - t * per_tap;
+                wreg[k] = a.wpk[((size_t)(tr * KSZ + t) * c32n + c0) * MBN * 64 + r];
             }
         }
-    }
-    wstore();
-    __syncthreads();
+    };
+    auto wstore = [&](int s) {
+        const int c0 = (s / KSZ) * GC_CH, cn = min(GC_CH, c32n - c0);
+        const int per_tap = cn * MBN * 64;
+#pragma unroll
+        for (int k = 0; k < WMAX; ++k) {
+            const int j = tid + 256 * k;
+            if (j < KSZ * per_tap) *(half8*)(wbuf + (size_t)j * 16) = wreg[k];
+        }
+    };
 
     f32x4 acc[4][MBN];
 #pragma unroll
     for (int f = 0; f < 4; ++f)
 #pragma unroll
         for (int m = 0; m < MBN; ++m) acc[f][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // fragment f = 2*n + c: row 2*wave + n, columns 16*c .. 16*c + 15 of the tile's interior
     const int unit_of_o = o == 0 ? 0 : o == 1 ? 2 : o == 2 ? 1 : 3;
-    unsigned fbase[4];
+
+    wfetch(0);
+    for (int s = 0; s < nstage; ++s) {
+        const int c0 = (s / KSZ) * GC_CH, cn = min(GC_CH, c32n - c0), tr = s % KSZ;
+        const int pstride = cn * 64 + 16;                        // bytes per pixel of this chunk's tile: an odd number of units
+        if (tr == 0) {
+            // halo tile of this chunk: array rows y0 .. y0+9, columns x0 .. x0+33 (the array carries a one-pixel zero
+            // border: pixel (y, x) sits at row y+1, column x+1), channels 32*c0 .. +32*cn; outside the array: zeros.  A
+            // tile row is GC_PW consecutive pixels of the array; the pixel of unit j is j / units by a multiplication
+            // (exact for j < 34 * 8); half the rows' loads are in flight before the first is stored.
+            if (s > 0) __syncthreads();                          // the previous chunk's tile has been used up
+            const int units = cn * 4;                            // 16-byte units per pixel of this chunk (32 channels = 4)
+            const unsigned inv = (65536u + units - 1) / units;
+            const int row_units = GC_PW * units;
 #pragma unroll
-    for (int f = 0; f < 4; ++f) fbase[f] = (unsigned)(((2 * wave + (f >> 1)) * GC_PW + 16 * (f & 1) + pix) * pstride + unit_of_o * 16);
-    for (int tap = 0; tap < NTAP; ++tap) {
-        if (tap + 1 < NTAP) wfetch(tap + 1);
-        const unsigned toff = (unsigned)(((tap / KSZ) * GC_PW + tap % KSZ) * pstride);
-        // operands of k-step c32+1 are read while k-step c32's MFMAs run (one wave per SIMD: nobody else hides the latency)
+            for (int half = 0; half < 2; ++half) {
+                uint4 v[RB][2];                                  // 34 pixels x 8 units = 272 per row: two per thread
+#pragma unroll
+                for (int rr = 0; rr < RB; ++rr) {
+                    const int r = RB * half + rr, ay = y0 + ORG + r;
+                    const _Float16* const grow = a.in + ((size_t)ay * (a.w + 2) + x0 + ORG) * a.in_stride + 32 * c0;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int j = tid + 256 * k;
+                        const int c = (int)(((unsigned)j * inv) >> 16), u = j - c * units;
+                        v[rr][k] = make_uint4(0, 0, 0, 0);
+                        if (j < row_units && ay <= a.h + 1 && x0 + ORG + c <= a.w + 1) v[rr][k] = *(const uint4*)(grow + (size_t)c * a.in_stride + 8 * u);
+                    }
+                }
+#pragma unroll
+                for (int rr = 0; rr < RB; ++rr) {
+                    char* const lrow = tile + (size_t)(RB * half + rr) * GC_PW * pstride;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int j = tid + 256 * k;
+                        const int c = (int)(((unsigned)j * inv) >> 16), u = j - c * units;
+                        if (j < row_units) *(uint4*)(lrow + (size_t)c * pstride + 16 * u) = v[rr][k];
+                    }
+                }
+            }
+        } else {
+            __syncthreads();                                     // everybody is done with the previous row of taps
+        }
+        wstore(s);
+        __syncthreads();
+        if (s + 1 < nstage) wfetch(s + 1);
+
+        // fragment f = 2*n + c: row 2*wave + n, columns 16*c .. 16*c + 15 of the tile's interior
+        unsigned fbase[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+            fbase[f] = (unsigned)(((2 * wave + (f >> 1) + tr) * GC_PW + 16 * (f & 1) + pix) * pstride + unit_of_o * 16);
+        // k-steps of this stage: (tap column t, 32-channel group c); operands of the next one are read while this one's
+        // MFMAs run
+        const int nk = KSZ * cn;
         half8 wa[2][MBN], bf[2][4];
-        auto rd = [&](int c32, half8 (&wv)[MBN], half8 (&bv)[4]) {
-            const char* const wcur = wbuf + (size_t)c32 * MBN * 1024;
+        auto rd = [&](int k, half8 (&wv)[MBN], half8 (&bv)[4]) {
+            const int t = k / cn, c = k - t * cn;
+            const char* const wcur = wbuf + (size_t)(t * cn + c) * MBN * 1024;
 #pragma unroll
             for (int m = 0; m < MBN; ++m) wv[m] = *(const half8*)(wcur + m * 1024 + lane * 16);
 #pragma unroll
-            for (int f = 0; f < 4; ++f) bv[f] = *(const half8*)(tile + fbase[f] + toff + c32 * 64);
+            for (int f = 0; f < 4; ++f) bv[f] = *(const half8*)(tile + fbase[f] + t * pstride + c * 64);
         };
         auto mm = [&](const half8 (&wv)[MBN], const half8 (&bv)[4]) {
 #pragma unroll
@@ -238,19 +261,14 @@ __global__ __launch_bounds__(256) void g_conv3_lds(GConvArgs a)
                 for (int m = 0; m < MBN; ++m) acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[m], bv[f], acc[f][m], 0, 0, 0);
         };
         rd(0, wa[0], bf[0]);
-        int c32 = 0;
-        for (; c32 + 2 <= c32n; c32 += 2) {
-            rd(c32 + 1, wa[1], bf[1]);
+        int k = 0;
+        for (; k + 2 <= nk; k += 2) {
+            rd(k + 1, wa[1], bf[1]);
             mm(wa[0], bf[0]);
-            if (c32 + 2 < c32n) rd(c32 + 2, wa[0], bf[0]);
+            if (k + 2 < nk) rd(k + 2, wa[0], bf[0]);
             mm(wa[1], bf[1]);
         }
-        if (c32 < c32n) mm(wa[0], bf[0]);
-        if (tap + 1 < NTAP) {
-            __syncthreads();            // everybody is done with this tap's weights
-            wstore();
-            __syncthreads();
-        }
+        if (k < nk) mm(wa[0], bf[0]);
     }
     // bias, LeakyReLU (ncnn activation_type 2), fp16; lane (o, p): channels 16m + 4o .. +3 of pixel gpix(p).  Through LDS
     // (the input tile is dead by now): every pixel's channels then leave as consecutive 16-byte units -- a whole tile row
