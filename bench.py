@@ -114,6 +114,13 @@ def pmc_traffic(args, nf, kernel):
     committed summary of the matching workload AND kernel is replayed (-> (bytes, file name)), or
     (None, None) when there is none."""
     import glob
+    if kernel == "sub10_kernel" and args.workload == "1x_hurrdeblur_1080p" and args.tile == 0:
+        for path in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sub10_pmc.json")))):
+            try:
+                return int(json.load(open(path))["hbm_bytes_per_launch"]), "profiles/" + os.path.basename(path)
+            except Exception:  # noqa: BLE001
+                pass
+        return None, None
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_trunk_pmc.json")))   # latest round/letter last
     if args.workload != "2x_compact_1080p" or args.tile != 960 or nf != 64:
         return None, None
@@ -298,7 +305,7 @@ def main():
         frame_flops = conv_flops_per_px(nf, nconv, s) * h * w
         if pre is not None:
             frame_flops += conv_flops_per_px(pre.num_features, pre.num_convs, 1) * h * w
-        traffic, traffic_source = pmc_traffic(args, nf, kernel)
+        traffic, traffic_source = pmc_traffic(args, nf, "sub10_kernel" if whole_net else kernel)
         result = {
             "metric": "frames/sec 1080p->2x Compact (SRVGGNetCompact per-frame SR hot path)" if args.workload == "2x_compact_1080p"
                       else "frames/sec " + args.workload,
