@@ -124,7 +124,8 @@ bool build_table(const uint8_t* lens, int n, int root, bool is_dist, Table& t)
         return sym < 286 ? mk(len, K_LENGTH, len_extra[sym - 257], len_base[sym - 257]) : mk(len, K_INVALID, 0, 0);
     };
     // sub-tables: one per distinct root-bit prefix of the long codes, sized for the longest code under it
-    std::vector<int> sub_bits((size_t)1 << root, 0);
+    static thread_local std::vector<int> sub_bits;             // (scratch reused from block to block: a 1080p frame has hundreds)
+    sub_bits.assign((size_t)1 << root, 0);
     {
         uint32_t nx[16];
         std::memcpy(nx, next, sizeof nx);
@@ -136,7 +137,8 @@ bool build_table(const uint8_t* lens, int n, int root, bool is_dist, Table& t)
             sub_bits[prefix] = std::max(sub_bits[prefix], l - root);
         }
     }
-    std::vector<uint32_t> sub_off((size_t)1 << root, 0);
+    static thread_local std::vector<uint32_t> sub_off;
+    sub_off.assign((size_t)1 << root, 0);
     for (size_t p = 0; p < sub_bits.size(); ++p)
         if (sub_bits[p]) {
             sub_off[p] = (uint32_t)t.e.size();
@@ -247,7 +249,7 @@ bool inflate_raw(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_len,
                 if (nlit > 286 || ndist > 30) { err = "inflate: too many length or distance codes"; return false; }
                 uint8_t cl[19] = {0};
                 for (int i = 0; i < ncl; ++i) { b.refill(); cl[clorder[i]] = (uint8_t)b.take(3); }
-                Table ct;
+                static thread_local Table ct;
                 if (!build_table(cl, 19, 7, false, ct)) { err = "inflate: bad code-length code"; return false; }
                 int i = 0;
                 while (i < nlit + ndist) {
