@@ -76,13 +76,18 @@ __global__ void nlm_lab2bgr(const uint8_t* L, const uint8_t* ab, int h, int w, u
 }
 
 // One workgroup = 16 x 16 output pixels; their 28 x 28 neighbourhood (reflect-101 at the image edge) is staged in
-// LDS once, then every thread walks its 81 search positions x 25 template pixels.  HBM traffic is one read and one
-// write of the plane; the arithmetic (2 025 x CN squared differences per pixel) is integer VALU work out of LDS.
+// LDS once.  The patch distance of a search offset is a 5 x 5 box sum of per-pixel squared differences, and the boxes of
+// neighbouring pixels overlap: per offset every thread adds up ONE column of five differences (320 column sums for the
+// 16 x 20 positions the block needs, through a double-buffered LDS array, one barrier per offset) and then five of its
+// neighbours' column sums -- 6.25 squared differences per pixel and offset instead of 25, the same integers.  HBM
+// traffic is one read and one write of the plane.
 template <int CN>
 __global__ __launch_bounds__(NLM_BLK * NLM_BLK) void nlm_plane(const uint8_t* src, int h, int w, const int* weight_table,
                                                                 int table_size, uint8_t* dst)
 {
+    constexpr int VW = NLM_BLK + 2 * NLM_T;                       // 20 column sums per output row
     __shared__ uint8_t tile[NLM_TILE * NLM_TILE * CN];
+    __shared__ int vsum[2][NLM_BLK * VW];
     const int bx = blockIdx.x * NLM_BLK, by = blockIdx.y * NLM_BLK;
     for (int i = threadIdx.x; i < NLM_TILE * NLM_TILE; i += NLM_BLK * NLM_BLK) {
         const int ty = i / NLM_TILE, tx = i - ty * NLM_TILE;
@@ -93,34 +98,48 @@ __global__ __launch_bounds__(NLM_BLK * NLM_BLK) void nlm_plane(const uint8_t* sr
     __syncthreads();
     const int lx = threadIdx.x % NLM_BLK, ly = threadIdx.x / NLM_BLK;
     const int x = bx + lx, y = by + ly;
-    if (x >= w || y >= h) return;
     const int cx = lx + NLM_B, cy = ly + NLM_B;
+    // column sum (r, c): rows cy(r) - 2 .. + 2 of tile column NLM_B - 2 + c
+    auto colsum = [&](int r, int c, int sy, int sx) {
+        const int tx = NLM_B - NLM_T + c;
+        int v = 0;
+#pragma unroll
+        for (int ty = -NLM_T; ty <= NLM_T; ++ty) {
+            const uint8_t* a = tile + ((r + NLM_B + ty) * NLM_TILE + tx) * CN;
+            const uint8_t* b = tile + ((r + NLM_B + ty + sy) * NLM_TILE + tx + sx) * CN;
+#pragma unroll
+            for (int c2 = 0; c2 < CN; ++c2) {
+                const int d = (int)a[c2] - (int)b[c2];
+                v += d * d;
+            }
+        }
+        return v;
+    };
     int est[CN];
 #pragma unroll
     for (int c = 0; c < CN; ++c) est[c] = 0;
-    int wsum = 0;
+    int wsum = 0, buf = 0;
     for (int sy = -NLM_S; sy <= NLM_S; ++sy)
         for (int sx = -NLM_S; sx <= NLM_S; ++sx) {
+            int* const vb = vsum[buf];
+            vb[ly * VW + lx] = colsum(ly, lx, sy, sx);
+            if (threadIdx.x < NLM_BLK * 2 * NLM_T) {              // the four extra columns of the 16 rows
+                const int r = threadIdx.x / (2 * NLM_T), c = NLM_BLK + threadIdx.x % (2 * NLM_T);
+                vb[r * VW + c] = colsum(r, c, sy, sx);
+            }
+            __syncthreads();                                      // (the other buffer is free again after the NEXT barrier)
             int dist = 0;
 #pragma unroll
-            for (int ty = -NLM_T; ty <= NLM_T; ++ty)
-#pragma unroll
-                for (int tx = -NLM_T; tx <= NLM_T; ++tx) {
-                    const uint8_t* a = tile + ((cy + ty) * NLM_TILE + cx + tx) * CN;
-                    const uint8_t* b = tile + ((cy + sy + ty) * NLM_TILE + cx + sx + tx) * CN;
-#pragma unroll
-                    for (int c = 0; c < CN; ++c) {
-                        const int d = (int)a[c] - (int)b[c];
-                        dist += d * d;
-                    }
-                }
+            for (int t = 0; t <= 2 * NLM_T; ++t) dist += vb[ly * VW + lx + t];
             const int idx = min(dist >> NLM_SHIFT, table_size - 1);
             const int wgt = weight_table[idx];
             const uint8_t* p = tile + ((cy + sy) * NLM_TILE + cx + sx) * CN;
 #pragma unroll
             for (int c = 0; c < CN; ++c) est[c] += wgt * (int)p[c];
             wsum += wgt;
+            buf ^= 1;
         }
+    if (x >= w || y >= h) return;
 #pragma unroll
     for (int c = 0; c < CN; ++c) {
         const unsigned q = ((unsigned)est[c] + (unsigned)wsum / 2) / (unsigned)wsum;     // divByWeightsSum
