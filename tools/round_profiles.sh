@@ -20,6 +20,8 @@ bash tools/pmc_sub10.sh /tmp/pmc_sub10_$TAG > "$OUT/${TAG}_sub10_pmc.txt" 2>&1
 python tools/png_route_bench.py 384 > "$OUT/${TAG}_png_route_bench.txt" 2>&1
 python tools/png_gpu_route_bench.py 240 > "$OUT/${TAG}_png_gpu_route_bench.txt" 2>&1
 python tools/rawvideo_bench.py 600 > "$OUT/${TAG}_rawvideo_bench.txt" 2>&1
+python tools/denoise_bench.py > "$OUT/${TAG}_denoise_bench_now.txt" 2>&1
+python tools/valar_bench.py 3 > "$OUT/${TAG}_bench_valar.txt" 2>&1
 python test_gpus.py -g 0,0,0,0 -s 2 -r 16 > "$OUT/${TAG}_test_gpus_harness.txt" 2>&1
 # package power and shader clock while the bench runs (sustained state)
 python bench.py --steps 6000 --warmup 50 --no-cpu-baseline > "$OUT/power_bench.json" 2>/dev/null &
