@@ -37,7 +37,8 @@ constexpr int PNG_FILT_CAP = 48 * 1024;                 // filtered bytes per bl
 constexpr int PNG_HDR_CAP = 256;                        // bytes reserved for a block's dynamic-Huffman header
 constexpr int PNG_STAGE_BYTES = PNG_FILT_CAP * 9 / 8 + PNG_HDR_CAP + 64;   // the flattest table costs <= 9 bits per byte
 constexpr int PNG_SLOT_BYTES = (PNG_STAGE_BYTES + 255) / 256 * 256;
-constexpr int PNG_META_WORDS = 4;                       // per block: compressed bytes, Adler s1, Adler s2, filtered bytes
+constexpr int PNG_META_WORDS = 8;                       // per block: compressed bytes, Adler s1, Adler s2, filtered bytes, CRC-32 of
+                                                        // the compressed bytes, 3 spare
 constexpr uint32_t PNG_ADLER_BASE = 65521;
 
 struct PngTables {
@@ -190,6 +191,34 @@ __device__ __forceinline__ void png_or_bits(uint32_t* stage, unsigned long long 
     if (sh + n > 32) atomicOr(p + 1, (uint32_t)(x >> 32));
 }
 
+// CRC-32 arithmetic in the reflected representation zlib uses (bit 31 = x^0): a * b mod P, and x^(8 * len) mod P.
+// crc(A || B) = png_multmodp(x^(8 len B), crc(A)) ^ crc(B) for standard CRCs (zlib's crc32_combine).
+__host__ __device__ inline uint32_t png_multmodp(uint32_t a, uint32_t b)
+{
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) {
+            p ^= b;
+            if ((a & (m - 1)) == 0) break;
+        }
+        m >>= 1;
+        b = (b & 1) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
+    }
+    return p;
+}
+__host__ __device__ inline uint32_t png_x8n(uint64_t len)
+{
+    uint32_t sq = 0x00800000u;               // x^8
+    uint32_t p = 1u << 31;                    // x^0
+    while (len) {
+        if (len & 1) p = png_multmodp(sq, p);
+        sq = png_multmodp(sq, sq);
+        len >>= 1;
+    }
+    return p;
+}
+__host__ __device__ inline uint32_t png_crc_combine(uint32_t crc1, uint32_t crc2, uint64_t len2) { return png_multmodp(png_x8n(len2), crc1) ^ crc2; }
+
 __global__ __launch_bounds__(PNG_THREADS) void png_deflate_kernel(PngArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char png_smem[];
@@ -287,12 +316,41 @@ __global__ __launch_bounds__(PNG_THREADS) void png_deflate_kernel(PngArgs a)
     uint32_t* const out = (uint32_t*)(a.slots + (size_t)b * PNG_SLOT_BYTES);
     const int nw = (int)((total_bytes + 3) / 4);
     for (int i = tid; i < nw; i += PNG_THREADS) out[i] = stage[i];
+
+    // ---- CRC-32 of the block's bytes, so that the host only combines (the chunk CRC is the framing's one pass over
+    // the data): 255 threads take L bytes each from the end, thread 0 the rest; partial CRCs are combined pairwise,
+    // the right operand of a combination always a whole number of L-byte pieces ----
+    uint32_t* const ctab = tbl;                                           // the code table is no longer needed
+    {
+        uint32_t c = (uint32_t)tid;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+        __syncthreads();                                                  // (everybody is done with tbl)
+        ctab[tid] = c;
+    }
+    __syncthreads();
+    const int nbytes = (int)total_bytes, L = nbytes / PNG_THREADS;
+    const int c0 = tid == 0 ? 0 : nbytes - (PNG_THREADS - tid) * L, c1 = tid == 0 ? nbytes - (PNG_THREADS - 1) * L : c0 + L;
+    const uint8_t* const sb8 = (const uint8_t*)stage;
+    uint32_t crc = 0xffffffffu;
+    for (int i = c0; i < c1; ++i) crc = ctab[(crc ^ sb8[i]) & 0xffu] ^ (crc >> 8);
+    crc = ~crc;                                                           // (an empty piece has CRC 0: the neutral element)
+    uint32_t* const cred = (uint32_t*)(red + 8);                          // the scan array is free again
+    cred[tid] = crc;
+    uint32_t op = png_x8n((uint64_t)L);                                   // x^(8 L): the right operand of level 0 is L bytes long
+    __syncthreads();
+    for (int d = 1; d < PNG_THREADS; d <<= 1) {
+        if ((tid & (2 * d - 1)) == 0) cred[tid] = L ? png_multmodp(op, cred[tid]) ^ cred[tid + d] : cred[tid];
+        op = png_multmodp(op, op);
+        __syncthreads();
+    }
     if (tid == 0) {
         uint32_t* const m = a.meta + (size_t)b * PNG_META_WORDS;
         m[0] = (uint32_t)total_bytes;
         m[1] = (uint32_t)((1 + red[4]) % PNG_ADLER_BASE);                 // Adler-32 of the block on its own
         m[2] = (uint32_t)((red[5] + (unsigned long long)n) % PNG_ADLER_BASE);
         m[3] = (uint32_t)n;
+        m[4] = cred[0];
     }
 }
 
@@ -365,9 +423,10 @@ inline int png_assemble(const uint8_t* workspace, int h, int w, uint8_t* out, si
     size_t total = 0;
     uint64_t filtered = 0;
     for (int b = 0; b < nb; ++b) {
-        if (meta[4 * b] == 0 || meta[4 * b] > (uint32_t)PNG_SLOT_BYTES) { err = "PNG workspace: block size out of range (kernel not run?)"; return 1; }
-        total += meta[4 * b];
-        filtered += meta[4 * b + 3];
+        const uint32_t* m = meta + (size_t)PNG_META_WORDS * b;
+        if (m[0] == 0 || m[0] > (uint32_t)PNG_SLOT_BYTES) { err = "PNG workspace: block size out of range (kernel not run?)"; return 1; }
+        total += m[0];
+        filtered += m[3];
     }
     if (filtered != (uint64_t)h * (3 * (uint64_t)w + 1)) { err = "PNG workspace: block lengths do not add up to the frame"; return 1; }
     const size_t idat = 2 + total + 4, need = 8 + 25 + 12 + idat + 12;
@@ -385,13 +444,18 @@ inline int png_assemble(const uint8_t* workspace, int h, int w, uint8_t* out, si
     data[0] = 0x78; data[1] = 0x01;                                       // zlib: deflate, 32 KiB window, fastest
     uint8_t* q = data + 2;
     uint32_t adler = 1;
+    uint32_t crc = crc32(0, p + 4, 4 + 2);                                // "IDAT" + the zlib header; the blocks' CRCs come from the GPU
     for (int b = 0; b < nb; ++b) {
-        std::memcpy(q, slots + (size_t)b * PNG_SLOT_BYTES, meta[4 * b]);
-        q += meta[4 * b];
-        adler = adler_combine(adler, meta[4 * b + 1] | (meta[4 * b + 2] << 16), meta[4 * b + 3]);
+        const uint32_t* m = meta + (size_t)PNG_META_WORDS * b;
+        std::memcpy(q, slots + (size_t)b * PNG_SLOT_BYTES, m[0]);
+        q += m[0];
+        adler = adler_combine(adler, m[1] | (m[2] << 16), m[3]);
+        crc = png_crc_combine(crc, m[4], m[0]);
     }
-    be32(q, adler); q += 4;
-    be32(q, crc32(0, p + 4, 4 + idat)); q += 4;
+    be32(q, adler);
+    crc = png_crc_combine(crc, crc32(0, q, 4), 4);
+    q += 4;
+    be32(q, crc); q += 4;
     be32(q, 0); std::memcpy(q + 4, "IEND", 4); be32(q + 8, crc32(0, q + 4, 4));
     return 0;
 }
@@ -435,10 +499,13 @@ inline void png_deflate_host(const uint8_t* src, size_t stride, int h, int w, ui
         uint8_t* slot = slots + (size_t)b * PNG_SLOT_BYTES;
         std::memset(slot, 0, (bw.bytes.size() + 3) / 4 * 4);
         std::memcpy(slot, bw.bytes.data(), bw.bytes.size());
-        meta[4 * b] = (uint32_t)bw.bytes.size();
-        meta[4 * b + 1] = (uint32_t)((1 + s1) % PNG_ADLER_BASE);
-        meta[4 * b + 2] = (uint32_t)((s2 + (uint64_t)n) % PNG_ADLER_BASE);
-        meta[4 * b + 3] = (uint32_t)n;
+        uint32_t* m = meta + (size_t)PNG_META_WORDS * b;
+        m[0] = (uint32_t)bw.bytes.size();
+        m[1] = (uint32_t)((1 + s1) % PNG_ADLER_BASE);
+        m[2] = (uint32_t)((s2 + (uint64_t)n) % PNG_ADLER_BASE);
+        m[3] = (uint32_t)n;
+        m[4] = png_detail::crc32(0, bw.bytes.data(), bw.bytes.size());
+        m[5] = m[6] = m[7] = 0;
     }
 }
 
