@@ -150,7 +150,8 @@ struct uva_net {
         bool busy = false;
         long long ticket = -1;
         uint8_t *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;   // h_*: pinned staging
-        size_t d_in_cap = 0, d_out_cap = 0, h_in_cap = 0, h_out_cap = 0;
+        uint8_t* d_png = nullptr;        // the PNG encoder's blocks before they are packed into the caller's workspace
+        size_t d_in_cap = 0, d_out_cap = 0, h_in_cap = 0, h_out_cap = 0, d_png_cap = 0;
         hipEvent_t ev_h2d = nullptr, ev_done = nullptr, ev_d2h = nullptr;
         uint8_t* user_out = nullptr;     // where collect copies the staged result (null: D2H went there directly)
         size_t user_out_stride = 0, out_row = 0;
@@ -195,6 +196,7 @@ struct uva_net {
         for (auto& ps : pipe) {
             if (ps.d_in) (void)hipFree(ps.d_in);
             if (ps.d_out) (void)hipFree(ps.d_out);
+            if (ps.d_png) (void)hipFree(ps.d_png);
             if (ps.h_in) (void)hipHostFree(ps.h_in);
             if (ps.h_out) (void)hipHostFree(ps.h_out);
             if (ps.ev_h2d) (void)hipEventDestroy(ps.ev_h2d);
@@ -1231,11 +1233,12 @@ namespace {
 struct PngDev {
     uint32_t* d_code = nullptr;
     uint8_t* d_hdr = nullptr;
+    uint32_t* d_crcmul = nullptr;
     bool attr_set = false;
     // the synchronous utility's own buffers
     hipStream_t stream = nullptr;
-    uint8_t* d_frame = nullptr;
-    size_t d_frame_cap = 0;
+    uint8_t *d_frame = nullptr, *d_blocks = nullptr;
+    size_t d_frame_cap = 0, d_blocks_cap = 0;
 };
 std::mutex g_png_mu;          // the table uploads
 std::mutex g_png_util_mu;     // uva_png_deflate_u8's stream and frame buffer (never taken inside g_png_mu, or the reverse)
@@ -1252,7 +1255,9 @@ void png_release_all()
         if (c.stream) { (void)hipStreamSynchronize(c.stream); (void)hipStreamDestroy(c.stream); }
         if (c.d_code) (void)hipFree(c.d_code);
         if (c.d_hdr) (void)hipFree(c.d_hdr);
+        if (c.d_crcmul) (void)hipFree(c.d_crcmul);
         if (c.d_frame) (void)hipFree(c.d_frame);
+        if (c.d_blocks) (void)hipFree(c.d_blocks);
         c = PngDev();
     }
 }
@@ -1270,6 +1275,8 @@ int png_dev(int device, PngDev** out)
         HIP_TRY(hipMalloc((void**)&c.d_hdr, sizeof T.hdr));
         HIP_TRY(hipMemcpy(c.d_code, T.code, sizeof T.code, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c.d_hdr, T.hdr, sizeof T.hdr, hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&c.d_crcmul, sizeof T.crcmul));
+        HIP_TRY(hipMemcpy(c.d_crcmul, T.crcmul, sizeof T.crcmul, hipMemcpyHostToDevice));
         HIP_TRY(hipFuncSetAttribute((const void*)png_deflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, png_lds_bytes()));
         c.attr_set = true;
     }
@@ -1277,11 +1284,10 @@ int png_dev(int device, PngDev** out)
     return 0;
 }
 
-// deflate the h x w u8 BGR frame at d_frame (HBM) into the page-locked workspace `ws`, on `stream`
-int png_launch(int device, hipStream_t stream, const uint8_t* d_frame, size_t stride, int h, int w, void* ws, size_t ws_bytes)
+// deflate the h x w u8 BGR frame at d_frame (HBM) into blocks at d_blocks (HBM, png_workspace_bytes(h, w)), on `stream`
+int png_launch(int device, hipStream_t stream, const uint8_t* d_frame, size_t stride, int h, int w, uint8_t* d_blocks)
 {
     if (h <= 0 || w <= 0 || 3 * (long long)w + 1 > PNG_FILT_CAP) return fail("PNG encoder: frame width out of range");
-    if (!ws || ws_bytes < png_workspace_bytes(h, w)) return fail("PNG workspace too small");
     PngDev* c = nullptr;
     if (png_dev(device, &c)) return 1;
     PngArgs a;
@@ -1289,11 +1295,26 @@ int png_launch(int device, hipStream_t stream, const uint8_t* d_frame, size_t st
     a.src = d_frame; a.stride = stride; a.h = h; a.w = w;
     a.rows_per_block = png_rows_per_block(w);
     a.nblocks = png_num_blocks(h, w);
-    a.code = c->d_code; a.hdr = c->d_hdr;
+    a.code = c->d_code; a.hdr = c->d_hdr; a.crcmul = c->d_crcmul;
     for (int t = 0; t < PNG_TABLES; ++t) a.hdr_bits[t] = png_tables().hdr_bits[t];
-    a.meta = (uint32_t*)ws;
-    a.slots = (uint8_t*)ws + png_meta_bytes(h, w);
+    a.meta = (uint32_t*)d_blocks;
+    a.slots = d_blocks + png_meta_bytes(h, w);
     hipLaunchKernelGGL(png_deflate_kernel, dim3(a.nblocks), dim3(PNG_THREADS), png_lds_bytes(), stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// the blocks at d_blocks, concatenated, into the page-locked workspace `ws`, on `stream`
+int png_pack_launch(hipStream_t stream, const uint8_t* d_blocks, int h, int w, void* ws, size_t ws_bytes)
+{
+    if (!ws || ws_bytes < png_workspace_bytes(h, w)) return fail("PNG workspace too small");
+    PngPackArgs a;
+    a.meta = (const uint32_t*)d_blocks;
+    a.slots = d_blocks + png_meta_bytes(h, w);
+    a.nblocks = png_num_blocks(h, w);
+    a.out_meta = (uint32_t*)ws;
+    a.out_data = (uint8_t*)ws + png_meta_bytes(h, w);
+    hipLaunchKernelGGL(png_pack_kernel, dim3(a.nblocks), dim3(PNG_PACK_THREADS), 0, stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1697,6 +1718,11 @@ long long submit_u8(uva_net* n, const uint8_t* in, int h, int w, size_t in_strid
             tryhip(hipEventCreateWithFlags(&ps.ev_d2h, hipEventDisableTiming), "hipEventCreate")) return -1;
     }
     if (grow_dev(&ps.d_in, &ps.d_in_cap, in_bytes) || grow_dev(&ps.d_out, &ps.d_out_cap, out_bytes)) return -1;
+    if (png_ws) {
+        if (uva_png_workspace_bytes(h * s, w * s) == 0) { fail("PNG encoder: frame width out of range"); return -1; }
+        if (png_ws_bytes < png_workspace_bytes(h * s, w * s)) { fail("PNG workspace too small"); return -1; }
+        if (grow_dev(&ps.d_png, &ps.d_png_cap, png_workspace_bytes(h * s, w * s))) return -1;
+    }
     // H2D: straight from the caller's buffer when it is pinned (uva_host_alloc / hipHostMalloc /
     // hipHostRegister), through this slot's pinned staging buffer otherwise
     const uint8_t* src = in;
@@ -1710,12 +1736,14 @@ long long submit_u8(uva_net* n, const uint8_t* in, int h, int w, size_t in_strid
         tryhip(hipEventRecord(ps.ev_h2d, n->s_h2d), "hipEventRecord") ||
         tryhip(hipStreamWaitEvent(n->stream, ps.ev_h2d, 0), "hipStreamWaitEvent")) return -1;
     if (uva_net_process_u8_device(n, ps.d_in, h, w, in_row, ps.d_out, out_row, tile_size, border)) return -1;
+    // png: the deflate kernel follows the net on its stream and leaves the blocks in HBM
+    if (png_ws && png_launch(n->device, n->stream, ps.d_out, out_row, h * s, w * s, ps.d_png)) return -1;
     if (tryhip(hipEventRecord(ps.ev_done, n->stream), "hipEventRecord") ||
         tryhip(hipStreamWaitEvent(n->s_d2h, ps.ev_done, 0), "hipStreamWaitEvent")) return -1;
     if (png_ws) {
-        // the deflate kernel follows the net on its stream and writes straight into the caller's page-locked workspace
-        if (png_launch(n->device, n->stream, ps.d_out, out_row, h * s, w * s, png_ws, png_ws_bytes)) return -1;
-        if (tryhip(hipEventRecord(ps.ev_d2h, n->stream), "hipEventRecord")) return -1;
+        // ... and the download stream packs them into the caller's page-locked workspace while the next frame computes
+        if (png_pack_launch(n->s_d2h, ps.d_png, h * s, w * s, png_ws, png_ws_bytes)) return -1;
+        if (tryhip(hipEventRecord(ps.ev_d2h, n->s_d2h), "hipEventRecord")) return -1;
         ps.user_out = nullptr;
         ps.busy = true;
         ps.ticket = n->next_ticket;
@@ -1776,9 +1804,10 @@ int uva_png_deflate_u8(int device, const uint8_t* bgr, int h, int w, size_t stri
     HIP_TRY(hipSetDevice(device));
     if (!c->stream) HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     const size_t row = (size_t)w * 3;
-    if (grow_dev(&c->d_frame, &c->d_frame_cap, row * h)) return 1;
+    if (grow_dev(&c->d_frame, &c->d_frame_cap, row * h) || grow_dev(&c->d_blocks, &c->d_blocks_cap, png_workspace_bytes(h, w))) return 1;
     HIP_TRY(hipMemcpy2DAsync(c->d_frame, row, bgr, stride, row, h, hipMemcpyHostToDevice, c->stream));
-    if (png_launch(device, c->stream, c->d_frame, row, h, w, png_ws, png_ws_bytes)) return 1;
+    if (png_launch(device, c->stream, c->d_frame, row, h, w, c->d_blocks)) return 1;
+    if (png_pack_launch(c->stream, c->d_blocks, h, w, png_ws, png_ws_bytes)) return 1;
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }

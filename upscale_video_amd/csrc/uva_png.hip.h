@@ -15,10 +15,14 @@
 //     by plain byte copies, the last one carries BFINAL;
 //   * the workgroup also returns the Adler-32 of its stretch of filtered bytes; the host combines them.
 //
-// The kernel writes each block's bytes straight into page-locked host memory (only the bytes it produced cross PCIe,
-// about half of the raw frame), the host concatenates, adds the zlib / PNG framing and the chunk CRC
-// (uva_png_assemble: any thread, no GPU call).  The stream is plain RFC 1950/1951: every PNG reader decodes it to the
-// same pixels cv2.imwrite's file gives.
+//   * and the CRC-32 of its compressed bytes (the PNG chunk CRC is the framing's one pass over the data otherwise).
+//
+// Two kernels: png_deflate_kernel leaves every block in a slot of its own in HBM (it runs on the net's stream, so it
+// must not wait for PCIe); png_pack_kernel, on the download stream, concatenates the blocks into the caller's
+// page-locked workspace -- only the bytes produced cross PCIe, about half of the raw frame, while the next frame's
+// net already runs.  The host adds the zlib / PNG framing and combines the checksums (uva_png_assemble: any thread,
+// no GPU call, no pass over the data besides the one copy).  The stream is plain RFC 1950/1951: every PNG reader
+// decodes it to the same pixels cv2.imwrite's file gives.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -41,10 +45,16 @@ constexpr int PNG_META_WORDS = 8;                       // per block: compressed
                                                         // the compressed bytes, 3 spare
 constexpr uint32_t PNG_ADLER_BASE = 65521;
 
+constexpr int PNG_CRC_PIECE = 64;                       // bytes of a block one thread of the CRC phase takes
+constexpr int PNG_CRC_LEVELS = 10;                      // 1024 pieces are combined pairwise in 10 levels
+
 struct PngTables {
     uint32_t code[PNG_TABLES][260];                     // [symbol 0..256]: (bit-reversed code << 5) | length
     uint8_t hdr[PNG_TABLES][PNG_HDR_CAP];               // block header bits (BFINAL = 0, BTYPE = 2, the code lengths), LSB first
     int hdr_bits[PNG_TABLES];
+    // CRC-32 combination: [level k][nibble j][value v] = (v << 4j) * x^(8 * PNG_CRC_PIECE * 2^k) mod P, so that appending
+    // 2^k pieces to a partial CRC costs 8 lookups instead of a 32-step shift-and-add
+    uint32_t crcmul[PNG_CRC_LEVELS][8][16];
 };
 
 // ---- host: code construction ------------------------------------------------------------------------------------
@@ -117,6 +127,34 @@ struct BitWriter {
 
 }  // namespace png_detail
 
+// CRC-32 arithmetic in the reflected representation zlib uses (bit 31 = x^0): a * b mod P, and x^(8 * len) mod P.
+// crc(A || B) = png_multmodp(x^(8 len B), crc(A)) ^ crc(B) for standard CRCs (zlib's crc32_combine).  a != 0.
+__host__ __device__ inline uint32_t png_multmodp(uint32_t a, uint32_t b)
+{
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) {
+            p ^= b;
+            if ((a & (m - 1)) == 0) break;
+        }
+        m >>= 1;
+        b = (b & 1) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
+    }
+    return p;
+}
+__host__ __device__ inline uint32_t png_x8n(uint64_t len)
+{
+    uint32_t sq = 0x00800000u;               // x^8
+    uint32_t p = 1u << 31;                    // x^0
+    while (len) {
+        if (len & 1) p = png_multmodp(sq, p);
+        sq = png_multmodp(sq, sq);
+        len >>= 1;
+    }
+    return p;
+}
+__host__ __device__ inline uint32_t png_crc_combine(uint32_t crc1, uint32_t crc2, uint64_t len2) { return png_multmodp(png_x8n(len2), crc1) ^ crc2; }
+
 // The four literal codes and their block headers.  Model: filtered byte v is the residual r = (int8)v with
 // P(r) ~ exp(-|r| / sigma) (+ a floor so that every byte value has a code); sigma = 1, 3, 8 and "flat".
 inline const PngTables& png_tables()
@@ -154,6 +192,11 @@ inline const PngTables& png_tables()
             std::memcpy(t.hdr[k], w.bytes.data(), w.bytes.size());
             t.hdr_bits[k] = w.nbits;
         }
+        for (int k = 0; k < PNG_CRC_LEVELS; ++k) {
+            const uint32_t op = png_x8n((uint64_t)PNG_CRC_PIECE << k);
+            for (int j = 0; j < 8; ++j)
+                for (uint32_t v = 0; v < 16; ++v) t.crcmul[k][j][v] = png_multmodp(op, v << (4 * j));
+        }
         return t;
     }();
     return T;
@@ -161,7 +204,8 @@ inline const PngTables& png_tables()
 
 inline int png_rows_per_block(int w) { return std::max(1, PNG_FILT_CAP / (3 * w + 1)); }
 inline int png_num_blocks(int h, int w) { const int r = png_rows_per_block(w); return (h + r - 1) / r; }
-// bytes of the page-locked workspace a frame needs: [meta: nblocks x 16 B, padded to 4 KiB][nblocks slots]
+// bytes of the workspace a frame needs, in HBM ([meta: nblocks x 32 B, padded to 4 KiB][nblocks slots]) and in page-locked
+// host memory ([the same meta][the blocks' bytes, concatenated]: the same bound)
 inline size_t png_meta_bytes(int h, int w) { return ((size_t)png_num_blocks(h, w) * PNG_META_WORDS * 4 + 4095) / 4096 * 4096; }
 inline size_t png_workspace_bytes(int h, int w) { return png_meta_bytes(h, w) + (size_t)png_num_blocks(h, w) * PNG_SLOT_BYTES; }
 
@@ -172,13 +216,15 @@ struct PngArgs {
     int h, w, rows_per_block, nblocks;
     const uint32_t* code;         // [PNG_TABLES][260]
     const uint8_t* hdr;           // [PNG_TABLES][PNG_HDR_CAP]
+    const uint32_t* crcmul;       // [PNG_CRC_LEVELS][8][16]
     int hdr_bits[PNG_TABLES];
-    uint32_t* meta;               // [nblocks][4]  (page-locked host memory)
-    uint8_t* slots;               // [nblocks][PNG_SLOT_BYTES]
+    uint32_t* meta;               // [nblocks][PNG_META_WORDS]   (HBM)
+    uint8_t* slots;               // [nblocks][PNG_SLOT_BYTES]   (HBM)
 };
 
-constexpr int PNG_THREADS = 256;
-constexpr int png_lds_bytes() { return PNG_FILT_CAP + PNG_STAGE_BYTES + 260 * 4 + PNG_TABLES * 260 + 1024 * 8; }
+constexpr int PNG_THREADS = 1024;     // 16 waves per CU: the per-thread byte loops are chains of dependent LDS reads, more waves hide them
+static_assert(PNG_THREADS * PNG_CRC_PIECE >= PNG_STAGE_BYTES && (1 << PNG_CRC_LEVELS) == PNG_THREADS, "CRC phase: one piece per thread");
+constexpr int png_lds_bytes() { return PNG_FILT_CAP + PNG_STAGE_BYTES + 260 * 4 + 260 * 8 + (PNG_THREADS + 8) * 8; }
 static_assert(png_lds_bytes() <= 160 * 1024, "PNG kernel LDS budget");
 
 __device__ __forceinline__ void png_or_bits(uint32_t* stage, unsigned long long pos, unsigned long long v, int n)
@@ -191,33 +237,12 @@ __device__ __forceinline__ void png_or_bits(uint32_t* stage, unsigned long long 
     if (sh + n > 32) atomicOr(p + 1, (uint32_t)(x >> 32));
 }
 
-// CRC-32 arithmetic in the reflected representation zlib uses (bit 31 = x^0): a * b mod P, and x^(8 * len) mod P.
-// crc(A || B) = png_multmodp(x^(8 len B), crc(A)) ^ crc(B) for standard CRCs (zlib's crc32_combine).
-__host__ __device__ inline uint32_t png_multmodp(uint32_t a, uint32_t b)
+__device__ __forceinline__ unsigned long long png_wave_sum(unsigned long long v)
 {
-    uint32_t m = 1u << 31, p = 0;
-    for (;;) {
-        if (a & m) {
-            p ^= b;
-            if ((a & (m - 1)) == 0) break;
-        }
-        m >>= 1;
-        b = (b & 1) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
-    }
-    return p;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
 }
-__host__ __device__ inline uint32_t png_x8n(uint64_t len)
-{
-    uint32_t sq = 0x00800000u;               // x^8
-    uint32_t p = 1u << 31;                    // x^0
-    while (len) {
-        if (len & 1) p = png_multmodp(sq, p);
-        sq = png_multmodp(sq, sq);
-        len >>= 1;
-    }
-    return p;
-}
-__host__ __device__ inline uint32_t png_crc_combine(uint32_t crc1, uint32_t crc2, uint64_t len2) { return png_multmodp(png_x8n(len2), crc1) ^ crc2; }
 
 __global__ __launch_bounds__(PNG_THREADS) void png_deflate_kernel(PngArgs a)
 {
@@ -225,21 +250,60 @@ __global__ __launch_bounds__(PNG_THREADS) void png_deflate_kernel(PngArgs a)
     uint8_t* const filt = (uint8_t*)png_smem;
     uint32_t* const stage = (uint32_t*)(png_smem + PNG_FILT_CAP);
     uint32_t* const tbl = (uint32_t*)(png_smem + PNG_FILT_CAP + PNG_STAGE_BYTES);
-    uint8_t* const lens = (uint8_t*)(tbl + 260);                                   // [PNG_TABLES][260]
-    unsigned long long* const red = (unsigned long long*)(lens + PNG_TABLES * 260);  // reductions and the scan
+    unsigned long long* const lens = (unsigned long long*)(tbl + 260);             // [symbol]: the four tables' lengths, 16 bits each
+    unsigned long long* const red = lens + 260;                                    // reductions and the scan
     const int tid = threadIdx.x, b = blockIdx.x;
     const int r0 = b * a.rows_per_block, nr = min(a.rows_per_block, a.h - r0);
     const int rowb = 3 * a.w + 1, n = nr * rowb;
 
-    for (int i = tid; i < PNG_TABLES * 260; i += PNG_THREADS) lens[i] = (uint8_t)(a.code[i] & 31u);
-    for (int i = tid; i < PNG_STAGE_BYTES / 4; i += PNG_THREADS) stage[i] = 0;
+    for (int i = tid; i < 257; i += PNG_THREADS) {
+        unsigned long long l = 0;
+#pragma unroll
+        for (int t = 0; t < PNG_TABLES; ++t) l |= (unsigned long long)(a.code[t * 260 + i] & 31u) << (16 * t);
+        lens[i] = l;
+    }
     if (tid < 8) red[tid] = 0;
+    // ---- the block's rows -> LDS (the staging area, not needed yet), with as many loads in flight as registers allow:
+    // a pixel-by-pixel walk over HBM is one ~1 us round trip per byte and thread ----
+    uint8_t* const raw = (uint8_t*)stage;
+    const int rawb = 3 * a.w, rawp = (rawb + 3) & ~3;
+    if ((((uintptr_t)a.src | a.stride) & 3) == 0) {
+        const int row_dw = (rawb + 3) / 4;                                // (the tail dword of a row reads into the next row: inside the frame
+        constexpr int NB = 3;                                             //  except behind the last row, where it is read byte by byte)
+        for (int row = 0; row < nr; ++row) {
+            const uint32_t* const sp = (const uint32_t*)(a.src + (size_t)(r0 + row) * a.stride);
+            uint32_t* const dp = (uint32_t*)(raw + (size_t)row * rawp);
+            for (int base = 0; base < row_dw; base += NB * PNG_THREADS) {
+                uint32_t v[NB];
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    const int j = base + k * PNG_THREADS + tid;
+                    const bool last_partial = (r0 + row == a.h - 1) && 4 * j + 4 > rawb;
+                    v[k] = 0;
+                    if (j < row_dw) {
+                        if (!last_partial) v[k] = sp[j];
+                        else for (int e = 0; 4 * j + e < rawb; ++e) v[k] |= (uint32_t)((const uint8_t*)sp)[4 * j + e] << (8 * e);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    const int j = base + k * PNG_THREADS + tid;
+                    if (j < row_dw) dp[j] = v[k];
+                }
+            }
+        }
+    } else {
+        for (int row = 0; row < nr; ++row)
+            for (int k = tid; k < rawb; k += PNG_THREADS) raw[(size_t)row * rawp + k] = a.src[(size_t)(r0 + row) * a.stride + k];
+    }
     __syncthreads();
 
     // ---- filter (Sub, BGR -> RGB), cost under each table, Adler-32 sums ----
-    unsigned long long cost[PNG_TABLES] = {0, 0, 0, 0}, s1 = 0, s2 = 0;
+    unsigned long long c01 = 0, c23 = 0, s2 = 0;                          // costs of tables 0 | 1 << 32 and 2 | 3 << 32
+    uint32_t s1 = 0;
     for (int row = 0; row < nr; ++row) {
-        const uint8_t* const sp = a.src + (size_t)(r0 + row) * a.stride;
+        unsigned long long cost4 = 0;                                     // (a thread's <= 48 bytes of a row, <= 15 bits each: 16-bit fields hold)
+        const uint8_t* const sp = raw + (size_t)row * rawp;
         uint8_t* const fp = filt + row * rowb;
         for (int k = tid; k < rowb; k += PNG_THREADS) {
             unsigned v = 1;                                               // filter type 1
@@ -249,16 +313,26 @@ __global__ __launch_bounds__(PNG_THREADS) void png_deflate_kernel(PngArgs a)
                 v = (cur - left) & 0xffu;
             }
             fp[k] = (uint8_t)v;
-#pragma unroll
-            for (int t = 0; t < PNG_TABLES; ++t) cost[t] += lens[t * 260 + v];
+            cost4 += lens[v];
             s1 += v;
-            s2 += (unsigned long long)(n - (row * rowb + k)) * v;
+            s2 += (unsigned long long)((uint32_t)(n - (row * rowb + k)) * v);
+        }
+        c01 += (cost4 & 0xffffull) | ((cost4 & 0xffff0000ull) << 16);
+        c23 += ((cost4 >> 32) & 0xffffull) | ((cost4 >> 16) & 0xffff00000000ull);
+    }
+    {
+        c01 = png_wave_sum(c01);
+        c23 = png_wave_sum(c23);
+        const unsigned long long w1 = png_wave_sum((unsigned long long)s1), w2 = png_wave_sum(s2);
+        if ((tid & 63) == 0) {
+            atomicAdd(&red[0], c01 & 0xffffffffull); atomicAdd(&red[1], c01 >> 32);
+            atomicAdd(&red[2], c23 & 0xffffffffull); atomicAdd(&red[3], c23 >> 32);
+            atomicAdd(&red[4], w1);
+            atomicAdd(&red[5], w2);
         }
     }
-#pragma unroll
-    for (int t = 0; t < PNG_TABLES; ++t) atomicAdd(&red[t], cost[t]);
-    atomicAdd(&red[4], s1);
-    atomicAdd(&red[5], s2);
+    __syncthreads();
+    for (int i = tid; i < PNG_STAGE_BYTES / 4; i += PNG_THREADS) stage[i] = 0;    // the raw rows have been used up
     __syncthreads();
     int best = 0;
 #pragma unroll
@@ -312,36 +386,45 @@ __global__ __launch_bounds__(PNG_THREADS) void png_deflate_kernel(PngArgs a)
     }
     __syncthreads();
 
-    // ---- out: this block's bytes to its slot in page-locked host memory ----
+    // ---- out: this block's bytes to its slot ----
     uint32_t* const out = (uint32_t*)(a.slots + (size_t)b * PNG_SLOT_BYTES);
     const int nw = (int)((total_bytes + 3) / 4);
     for (int i = tid; i < nw; i += PNG_THREADS) out[i] = stage[i];
 
-    // ---- CRC-32 of the block's bytes, so that the host only combines (the chunk CRC is the framing's one pass over
-    // the data): 255 threads take L bytes each from the end, thread 0 the rest; partial CRCs are combined pairwise,
-    // the right operand of a combination always a whole number of L-byte pieces ----
-    uint32_t* const ctab = tbl;                                           // the code table is no longer needed
+    // ---- CRC-32 of the block's bytes, so that the host only combines: every thread takes one piece of PNG_CRC_PIECE
+    // bytes, counted from the END of the block (the first pieces are empty: CRC 0, the neutral element); partial CRCs
+    // are then combined pairwise, the right operand of a level-k combination always exactly 2^k pieces long, so the
+    // multipliers are constants and come as nibble tables ----
+    uint32_t* const ctab = tbl;                                           // (everybody is done with tbl and filt: the barrier above)
+    uint32_t* const cmul = (uint32_t*)filt;
     {
         uint32_t c = (uint32_t)tid;
 #pragma unroll
         for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-        __syncthreads();                                                  // (everybody is done with tbl)
-        ctab[tid] = c;
+        if (tid < 256) ctab[tid] = c;
+        for (int i = tid; i < PNG_CRC_LEVELS * 128; i += PNG_THREADS) cmul[i] = a.crcmul[i];
     }
     __syncthreads();
-    const int nbytes = (int)total_bytes, L = nbytes / PNG_THREADS;
-    const int c0 = tid == 0 ? 0 : nbytes - (PNG_THREADS - tid) * L, c1 = tid == 0 ? nbytes - (PNG_THREADS - 1) * L : c0 + L;
+    const int nbytes = (int)total_bytes;
+    const int c0 = max(0, nbytes - (PNG_THREADS - tid) * PNG_CRC_PIECE), c1 = max(0, nbytes - (PNG_THREADS - 1 - tid) * PNG_CRC_PIECE);
     const uint8_t* const sb8 = (const uint8_t*)stage;
     uint32_t crc = 0xffffffffu;
     for (int i = c0; i < c1; ++i) crc = ctab[(crc ^ sb8[i]) & 0xffu] ^ (crc >> 8);
-    crc = ~crc;                                                           // (an empty piece has CRC 0: the neutral element)
+    crc = ~crc;
     uint32_t* const cred = (uint32_t*)(red + 8);                          // the scan array is free again
     cred[tid] = crc;
-    uint32_t op = png_x8n((uint64_t)L);                                   // x^(8 L): the right operand of level 0 is L bytes long
     __syncthreads();
-    for (int d = 1; d < PNG_THREADS; d <<= 1) {
-        if ((tid & (2 * d - 1)) == 0) cred[tid] = L ? png_multmodp(op, cred[tid]) ^ cred[tid + d] : cred[tid];
-        op = png_multmodp(op, op);
+#pragma unroll 1
+    for (int k = 0; k < PNG_CRC_LEVELS; ++k) {
+        const int d = 1 << k;
+        if ((tid & (2 * d - 1)) == 0) {
+            const uint32_t c = cred[tid];
+            const uint32_t* const T = cmul + k * 128;
+            uint32_t m = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m ^= T[j * 16 + ((c >> (4 * j)) & 15u)];
+            cred[tid] = m ^ cred[tid + d];
+        }
         __syncthreads();
     }
     if (tid == 0) {
@@ -351,6 +434,48 @@ __global__ __launch_bounds__(PNG_THREADS) void png_deflate_kernel(PngArgs a)
         m[2] = (uint32_t)((red[5] + (unsigned long long)n) % PNG_ADLER_BASE);
         m[3] = (uint32_t)n;
         m[4] = cred[0];
+        m[5] = m[6] = m[7] = 0;
+    }
+}
+
+// The blocks, concatenated, into the caller's page-locked workspace: [meta, as png_deflate_kernel left it][the bytes].
+// One workgroup per block; destination offsets are unaligned, the middle of every block goes out as aligned dwords.
+struct PngPackArgs {
+    const uint32_t* meta;         // HBM
+    const uint8_t* slots;         // HBM
+    int nblocks;
+    uint32_t* out_meta;           // page-locked host memory
+    uint8_t* out_data;
+};
+constexpr int PNG_PACK_THREADS = 256;
+
+__global__ __launch_bounds__(PNG_PACK_THREADS) void png_pack_kernel(PngPackArgs a)
+{
+    __shared__ unsigned long long off_s;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    if (tid == 0) off_s = 0;
+    __syncthreads();
+    unsigned long long part = 0;
+    for (int j = tid; j < b; j += PNG_PACK_THREADS) part += a.meta[(size_t)j * PNG_META_WORDS];
+    part = png_wave_sum(part);
+    if ((tid & 63) == 0 && part) atomicAdd(&off_s, part);
+    __syncthreads();
+    const size_t off = (size_t)off_s;
+    const uint32_t* const m = a.meta + (size_t)b * PNG_META_WORDS;
+    const int nbytes = (int)m[0];
+    if (tid < PNG_META_WORDS) a.out_meta[(size_t)b * PNG_META_WORDS + tid] = m[tid];
+    const uint8_t* const src = a.slots + (size_t)b * PNG_SLOT_BYTES;      // 256-byte aligned
+    uint8_t* const dst = a.out_data + off;
+    const int head = min(nbytes, (int)((4 - ((uintptr_t)dst & 3)) & 3));  // bytes until dst is dword aligned
+    const int ndw = (nbytes - head) / 4, tail = nbytes - head - 4 * ndw;
+    if (tid < head) dst[tid] = src[tid];
+    if (tid < tail) dst[head + 4 * ndw + tid] = src[head + 4 * ndw + tid];
+    const uint32_t* const s32 = (const uint32_t*)src;
+    uint32_t* const d32 = (uint32_t*)(dst + head);
+    for (int i = tid; i < ndw; i += PNG_PACK_THREADS) {
+        // destination dword i = source bytes [head + 4i, head + 4i + 4)
+        const uint32_t lo = s32[i], hi = head ? s32[i + 1] : 0u;          // (i + 1 stays inside the slot: PNG_SLOT_BYTES > PNG_STAGE_BYTES)
+        d32[i] = head ? __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)head) : lo;
     }
 }
 
@@ -419,7 +544,7 @@ inline int png_assemble(const uint8_t* workspace, int h, int w, uint8_t* out, si
     using namespace png_detail;
     const int nb = png_num_blocks(h, w);
     const uint32_t* meta = (const uint32_t*)workspace;
-    const uint8_t* slots = workspace + png_meta_bytes(h, w);
+    const uint8_t* bytes = workspace + png_meta_bytes(h, w);
     size_t total = 0;
     uint64_t filtered = 0;
     for (int b = 0; b < nb; ++b) {
@@ -442,13 +567,12 @@ inline int png_assemble(const uint8_t* workspace, int h, int w, uint8_t* out, si
     be32(p, (uint32_t)idat); std::memcpy(p + 4, "IDAT", 4);
     uint8_t* const data = p + 8;
     data[0] = 0x78; data[1] = 0x01;                                       // zlib: deflate, 32 KiB window, fastest
-    uint8_t* q = data + 2;
+    std::memcpy(data + 2, bytes, total);
+    uint8_t* q = data + 2 + total;
     uint32_t adler = 1;
     uint32_t crc = crc32(0, p + 4, 4 + 2);                                // "IDAT" + the zlib header; the blocks' CRCs come from the GPU
     for (int b = 0; b < nb; ++b) {
         const uint32_t* m = meta + (size_t)PNG_META_WORDS * b;
-        std::memcpy(q, slots + (size_t)b * PNG_SLOT_BYTES, m[0]);
-        q += m[0];
         adler = adler_combine(adler, m[1] | (m[2] << 16), m[3]);
         crc = png_crc_combine(crc, m[4], m[0]);
     }
@@ -460,14 +584,14 @@ inline int png_assemble(const uint8_t* workspace, int h, int w, uint8_t* out, si
     return 0;
 }
 
-// Host restatement of png_deflate_kernel, block for block and bit for bit (test hook: the CPU suite checks tables, headers
+// Host restatement of png_deflate_kernel + png_pack_kernel, block for block and bit for bit (test hook: the CPU suite checks tables, headers
 // and framing with it against a PNG reader, the GPU suite checks the kernel against it).  Not a product path.
 inline void png_deflate_host(const uint8_t* src, size_t stride, int h, int w, uint8_t* workspace)
 {
     const PngTables& T = png_tables();
     const int R = png_rows_per_block(w), nb = png_num_blocks(h, w), rowb = 3 * w + 1;
     uint32_t* meta = (uint32_t*)workspace;
-    uint8_t* slots = workspace + png_meta_bytes(h, w);
+    uint8_t* bytes = workspace + png_meta_bytes(h, w);
     std::vector<uint8_t> filt;
     for (int b = 0; b < nb; ++b) {
         const int r0 = b * R, nr = std::min(R, h - r0), n = nr * rowb;
@@ -496,9 +620,8 @@ inline void png_deflate_host(const uint8_t* src, size_t stride, int h, int w, ui
         bw.put(b == nb - 1 ? 1u : 0u, 3);
         while (bw.nbits & 7) bw.put(0, 1);
         bw.put(0xffff0000u, 32);
-        uint8_t* slot = slots + (size_t)b * PNG_SLOT_BYTES;
-        std::memset(slot, 0, (bw.bytes.size() + 3) / 4 * 4);
-        std::memcpy(slot, bw.bytes.data(), bw.bytes.size());
+        std::memcpy(bytes, bw.bytes.data(), bw.bytes.size());
+        bytes += bw.bytes.size();
         uint32_t* m = meta + (size_t)PNG_META_WORDS * b;
         m[0] = (uint32_t)bw.bytes.size();
         m[1] = (uint32_t)((1 + s1) % PNG_ADLER_BASE);
