@@ -191,6 +191,25 @@ __global__ __launch_bounds__(256) void g_conv3_lds(GConvArgs a)
         for (int m = 0; m < MBN; ++m) acc[f][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int unit_of_o = o == 0 ? 0 : o == 1 ? 2 : o == 2 ? 1 : 3;
 
+    uint4 tv[RB][2];                                             // half a tile chunk in registers: 34 pixels x 8 units = 272 per row, two per thread
+    auto tfetch = [&](int c0, int cn, int half) {
+        const int units = cn * 4;
+        const unsigned inv = (65536u + units - 1) / units;
+        const int row_units = GC_PW * units;
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {
+            const int r = RB * half + rr, ay = y0 + ORG + r;
+            const _Float16* const grow = a.in + ((size_t)ay * (a.w + 2) + x0 + ORG) * a.in_stride + 32 * c0;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int j = tid + 256 * k;
+                const int c = (int)(((unsigned)j * inv) >> 16), u = j - c * units;
+                tv[rr][k] = make_uint4(0, 0, 0, 0);
+                if (j < row_units && ay <= a.h + 1 && x0 + ORG + c <= a.w + 1) tv[rr][k] = *(const uint4*)(grow + (size_t)c * a.in_stride + 8 * u);
+            }
+        }
+    };
+
     wfetch(0);
     for (int s = 0; s < nstage; ++s) {
         const int c0 = (s / KSZ) * GC_CH, cn = min(GC_CH, c32n - c0), tr = s % KSZ;
@@ -199,26 +218,16 @@ __global__ __launch_bounds__(256) void g_conv3_lds(GConvArgs a)
             // halo tile of this chunk: array rows y0 .. y0+9, columns x0 .. x0+33 (the array carries a one-pixel zero
             // border: pixel (y, x) sits at row y+1, column x+1), channels 32*c0 .. +32*cn; outside the array: zeros.  A
             // tile row is GC_PW consecutive pixels of the array; the pixel of unit j is j / units by a multiplication
-            // (exact for j < 34 * 8); half the rows' loads are in flight before the first is stored.
+            // (exact for j < 34 * 8).  The first chunk's rows are fetched here, half of them in flight at a time; the
+            // first half of every later chunk's rows has been on its way since the previous chunk's tile was stored
+            // (tfetch below), so that only the second half's latency is left in the open.
             if (s > 0) __syncthreads();                          // the previous chunk's tile has been used up
             const int units = cn * 4;                            // 16-byte units per pixel of this chunk (32 channels = 4)
             const unsigned inv = (65536u + units - 1) / units;
             const int row_units = GC_PW * units;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                uint4 v[RB][2];                                  // 34 pixels x 8 units = 272 per row: two per thread
-#pragma unroll
-                for (int rr = 0; rr < RB; ++rr) {
-                    const int r = RB * half + rr, ay = y0 + ORG + r;
-                    const _Float16* const grow = a.in + ((size_t)ay * (a.w + 2) + x0 + ORG) * a.in_stride + 32 * c0;
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const int j = tid + 256 * k;
-                        const int c = (int)(((unsigned)j * inv) >> 16), u = j - c * units;
-                        v[rr][k] = make_uint4(0, 0, 0, 0);
-                        if (j < row_units && ay <= a.h + 1 && x0 + ORG + c <= a.w + 1) v[rr][k] = *(const uint4*)(grow + (size_t)c * a.in_stride + 8 * u);
-                    }
-                }
+                if (half == 1 || s == 0) tfetch(c0, cn, half);
 #pragma unroll
                 for (int rr = 0; rr < RB; ++rr) {
                     char* const lrow = tile + (size_t)(RB * half + rr) * GC_PW * pstride;
@@ -226,10 +235,11 @@ __global__ __launch_bounds__(256) void g_conv3_lds(GConvArgs a)
                     for (int k = 0; k < 2; ++k) {
                         const int j = tid + 256 * k;
                         const int c = (int)(((unsigned)j * inv) >> 16), u = j - c * units;
-                        if (j < row_units) *(uint4*)(lrow + (size_t)c * pstride + 16 * u) = v[rr][k];
+                        if (j < row_units) *(uint4*)(lrow + (size_t)c * pstride + 16 * u) = tv[rr][k];
                     }
                 }
             }
+            if (s + KSZ < nstage) tfetch(c0 + GC_CH, min(GC_CH, c32n - c0 - GC_CH), 0);
         } else {
             __syncthreads();                                     // everybody is done with the previous row of taps
         }
