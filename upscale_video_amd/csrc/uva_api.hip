@@ -359,46 +359,57 @@ int launch_trunk(uva_net* n, const Workspace* ws, ConvArgs ca, int ablate = 0)
 // its last output row), the next segment starts on the following row and recomputes two intermediate rows.
 // Consecutive ranges go to the workgroups of one XCD (block b runs on XCD b % 8).
 int build_trunk2_schedule(const std::vector<PlaneDesc>& planes, int grid, size_t guard_bytes, std::vector<Trunk2Step>& steps,
-                          std::vector<int>& nsteps, int* max_steps)
+                          std::vector<int>& nsteps, int* max_steps, bool narrow_ok = true)
 {
     constexpr int PIXB = 128;
     struct Seg { int plane, x0, ya, rows, k; };
+    // ranges of equal COST: a step of a narrow strip (<= 14 columns: one fragment column instead of two) runs its k-loops
+    // with half the MFMAs and is counted as 8 tenths of a step (measured: its phases are then bounded by the other group's epilogue)
+    constexpr int COST = 10, COST_NARROW = 8;
+    auto step_cost = [&](const PlaneDesc& p, int x0) { return (narrow_ok && p.w - x0 <= 14) ? COST_NARROW : COST; };
     long long total = 0;
-    for (const auto& p : planes) total += (long long)((p.w + T2_SW - 1) / T2_SW) * ((p.h + 2 + 3) / 4);
+    for (const auto& p : planes)
+        for (int x0 = 0; x0 < p.w; x0 += T2_SW) total += (long long)((p.h + 2 + 3) / 4) * step_cost(p, x0);
     std::vector<std::vector<Seg>> per_wg;
-    int L = (int)std::max<long long>(4, (total + grid - 1) / grid);
+    int L = (int)std::max<long long>(4 * COST, (total + grid - 1) / grid);
     for (;; ++L) {
         per_wg.assign(1, {});
         int cap = L;
-        bool ok = true;
         auto next_wg = [&]() { per_wg.emplace_back(); cap = L; };
-        for (size_t pi = 0; pi < planes.size() && ok; ++pi) {
+        for (size_t pi = 0; pi < planes.size(); ++pi) {
             const PlaneDesc& p = planes[pi];
             for (int x0 = 0; x0 < p.w; x0 += T2_SW) {
+                const int c = step_cost(p, x0);
                 int y = 0;
                 while (y < p.h) {
-                    const int need = (p.h - y + 2 + 3) / 4;
-                    if (need <= cap) {
+                    const int need = (p.h - y + 2 + 3) / 4, fit = cap / c;
+                    if (need <= fit) {
                         per_wg.back().push_back({(int)pi, x0, y, p.h - y, need});
-                        cap -= need;
+                        cap -= need * c;
                         y = p.h;
-                    } else if (cap < 2) {
+                    } else if (fit < 2) {
                         next_wg();
                         continue;
                     } else {
-                        per_wg.back().push_back({(int)pi, x0, y, 4 * cap - 2, cap});
-                        y += 4 * cap - 2;
+                        per_wg.back().push_back({(int)pi, x0, y, 4 * fit - 2, fit});
+                        y += 4 * fit - 2;
                         cap = 0;
                     }
-                    if (cap == 0) next_wg();
+                    if (cap < COST_NARROW) next_wg();
                 }
             }
         }
         while (!per_wg.empty() && per_wg.back().empty()) per_wg.pop_back();
         if ((int)per_wg.size() <= grid) break;
     }
-    *max_steps = L;
-    const int stride = L + T2_PAD_STEPS;
+    int most = 0;
+    for (const auto& v : per_wg) {
+        int k = 0;
+        for (const Seg& sg : v) k += sg.k;
+        most = std::max(most, k);
+    }
+    *max_steps = most;
+    const int stride = most + T2_PAD_STEPS;
     steps.assign((size_t)grid * stride, Trunk2Step{make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)});
     nsteps.assign(grid, 0);
     const int per_xcd = grid / 8;
@@ -419,14 +430,16 @@ int build_trunk2_schedule(const std::vector<PlaneDesc>& planes, int grid, size_t
                 for (int r = 0; r < 4; ++r)
                     if (yA + r >= 0 && yA + r < p.h) rmask |= 1u << r;
                 const unsigned c_lo = sg.x0 == 0 ? 1 : 0, c_hi = (unsigned)std::min(32, p.w - sg.x0 + 1);
-                out[g].a = make_uint4((unsigned)ao, (unsigned)(ao >> 32) | (rmask << 8) | (c_lo << 12) | (c_hi << 18) | (1u << 24),
+                // strips of at most 14 columns need only the first of the two 16-column fragment columns (bit 25, both halves)
+                const unsigned narrow = (p.w - sg.x0 <= 14 && narrow_ok) ? 1u << 25 : 0u;
+                out[g].a = make_uint4((unsigned)ao, (unsigned)(ao >> 32) | (rmask << 8) | (c_lo << 12) | (c_hi << 18) | (1u << 24) | narrow,
                                       (unsigned)(p.pitch * PIXB), (unsigned)sg.plane);
                 if (j < nb) {
                     const int yo = sg.ya + 4 * j;
                     const long long bo = (long long)guard_bytes +
                                          ((long long)p.act_off + (long long)(yo + 1) * p.pitch + (sg.x0 + 1)) * PIXB;
                     const unsigned vy = (unsigned)std::min(4, sg.ya + sg.rows - yo), vx = (unsigned)std::min(T2_SW, p.w - sg.x0);
-                    out[g].b = make_uint4((unsigned)bo, (unsigned)(bo >> 32) | (vy << 8) | (vx << 11) | (1u << 24),
+                    out[g].b = make_uint4((unsigned)bo, (unsigned)(bo >> 32) | (vy << 8) | (vx << 11) | (1u << 24) | narrow,
                                           (unsigned)(p.pitch * PIXB), (unsigned)sg.plane);
                 }
             }
@@ -765,7 +778,8 @@ int get_workspace(uva_net* n, int h, int w, int tile_size, int border, Workspace
                 }
         }
         ws.grid2 = std::max(8, (n->ncu / 8) * 8);
-        if (build_trunk2_schedule(ws.planes, ws.grid2, ws.guard_bytes, steps2, nsteps2, &ws.max_steps2)) return 1;
+        const char* const nv = std::getenv("UVA_T2_NARROW");      // (A/B switch: 0 = every strip computes both fragment columns)
+        if (build_trunk2_schedule(ws.planes, ws.grid2, ws.guard_bytes, steps2, nsteps2, &ws.max_steps2, !(nv && std::atoi(nv) == 0))) return 1;
     }
     const size_t bytes = pix * (size_t)n->g.nf * 2 + 2 * ws.guard_bytes;
     // LRU over the cached geometries, by bytes (the fused route keeps one workspace per frame size, the

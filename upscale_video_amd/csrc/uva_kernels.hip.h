@@ -2053,41 +2053,52 @@ __global__ __launch_bounds__(512, 2) void trunk2_kernel(Trunk2Args a)
             const int bblk = blk + 1 >= 3 ? blk - 2 : blk + 1;        // B: block (it - 2) % 3
             const Win wn = window(sl, bblk);
             auto read_b = [&](int f) __attribute__((always_inline)) -> half8 { return read_frag(wn, f); };
-            constexpr int NSTEP = 24, NFRAG = 48;
-            constexpr int RQ = PFF + 2;
-            half8 bq[RQ];
-            __builtin_amdgcn_sched_barrier(0);
+            // NARROW: the step's strip is at most 14 columns wide (the 10-column strip that ends a 970-wide plane of the
+            // reference's tiling): the second fragment column (intermediate / output columns 16..31) is neither read nor
+            // computed -- half of the step's MFMAs, 1.5 % of a 1080p frame's
+            auto kloop = [&](auto narrow_tag) __attribute__((always_inline)) {
+                constexpr bool NARROW = decltype(narrow_tag)::value;
+                constexpr int NSTEP = 24, NFRAG = 48;
+                constexpr int RQ = PFF + 2;
+                half8 bq[RQ];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int f = 0; f < PFF; ++f) bq[f] = pre[f];
+                for (int f = 0; f < PFF; ++f) bq[f] = pre[f];
 #pragma unroll
-            for (int st = 0; st < NSTEP; ++st) {
+                for (int st = 0; st < NSTEP; ++st) {
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
-                    if (2 * st + c + PFF < NFRAG) bq[(2 * st + c + PFF) % RQ] = read_b(2 * st + c + PFF);
-                const int R = st & 3, ch = (st >> 2) & 1, dx = st >> 3;
-                const half8 b0 = bq[(2 * st) % RQ], b1 = bq[(2 * st + 1) % RQ];
+                    for (int c = 0; c < (NARROW ? 1 : 2); ++c)
+                        if (2 * st + c + PFF < NFRAG) bq[(2 * st + c + PFF) % RQ] = read_b(2 * st + c + PFF);
+                    const int R = st & 3, ch = (st >> 2) & 1, dx = st >> 3;
+                    const half8 b0 = bq[(2 * st) % RQ], b1 = bq[(2 * st + 1) % RQ];
 #pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    if (n == 0 ? R > 2 : R < 1) continue;       // output row n, tap (dy = R - n, dx)
-                    const bool first = st == n;
+                    for (int n = 0; n < 2; ++n) {
+                        if (n == 0 ? R > 2 : R < 1) continue;       // output row n, tap (dy = R - n, dx)
+                        const bool first = st == n;
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) {
-                        const half8 wv = w[(((R - n) * 3 + dx) * 2 + ch) * 2 + m];
-                        acc[n][0][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, b0, first ? zero4 : acc[n][0][m], 0, 0, 0);
-                        acc[n][1][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, b1, first ? zero4 : acc[n][1][m], 0, 0, 0);
+                        for (int m = 0; m < 2; ++m) {
+                            const half8 wv = w[(((R - n) * 3 + dx) * 2 + ch) * 2 + m];
+                            acc[n][0][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, b0, first ? zero4 : acc[n][0][m], 0, 0, 0);
+                            if constexpr (!NARROW)
+                                acc[n][1][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, b1, first ? zero4 : acc[n][1][m], 0, 0, 0);
+                            else if (first) acc[n][1][m] = zero4;
+                        }
                     }
                 }
-            }
 #pragma unroll
-            for (int st = 0; st < NSTEP; ++st) {
-                const int R = st & 3;
-                const bool light = R == 0 || R == 3;
-                const bool rd = 2 * st + PFF < NFRAG;
-                if (light) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); else __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                if (rd) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                if (light) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); else __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                if (rd) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
+                for (int st = 0; st < NSTEP; ++st) {
+                    const int R = st & 3;
+                    const bool light = R == 0 || R == 3;
+                    const bool rd = 2 * st + PFF < NFRAG;
+                    constexpr int D = NARROW ? 2 : 1;
+                    if (light) __builtin_amdgcn_sched_group_barrier(0x008, 2 / D, 0); else __builtin_amdgcn_sched_group_barrier(0x008, 4 / D, 0);
+                    if (rd) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (light) __builtin_amdgcn_sched_group_barrier(0x008, 2 / D, 0); else __builtin_amdgcn_sched_group_barrier(0x008, 4 / D, 0);
+                    if (rd && !NARROW) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            };
+            if ((__builtin_amdgcn_readfirstlane(e_own.y) >> 25) & 1u) kloop(std::true_type{});
+            else kloop(std::false_type{});
             __builtin_amdgcn_s_setprio(0);
         }
         if (stamp) sdbg[16 * it + 1] = __builtin_amdgcn_s_memtime();
