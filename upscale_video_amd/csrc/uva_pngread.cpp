@@ -54,14 +54,18 @@ uint32_t crc32(uint32_t crc, const uint8_t* p, size_t n)
 
 uint32_t adler32(const uint8_t* p, size_t n)
 {
+    // 32-byte blocks: a' = a + sum p[i], b' = b + 32 a + sum (32 - i) p[i]; the two sums have no carried dependency and
+    // vectorise, the byte-by-byte form is a chain of two dependent additions per byte
     uint32_t a = 1, b = 0;
     while (n) {
-        size_t k = n < 5552 ? n : 5552;     // largest run that cannot overflow 32 bits
+        size_t k = n < 5536 ? n : 5536;     // a multiple of 32 below the largest run that cannot overflow 32 bits (5552)
         n -= k;
-        while (k >= 8) {
-            a += p[0]; b += a; a += p[1]; b += a; a += p[2]; b += a; a += p[3]; b += a;
-            a += p[4]; b += a; a += p[5]; b += a; a += p[6]; b += a; a += p[7]; b += a;
-            p += 8; k -= 8;
+        while (k >= 32) {
+            uint32_t s1 = 0, s2 = 0;
+            for (int i = 0; i < 32; ++i) { s1 += p[i]; s2 += (uint32_t)(32 - i) * p[i]; }
+            b += 32 * a + s2;
+            a += s1;
+            p += 32; k -= 32;
         }
         while (k--) { a += *p++; b += a; }
         a %= 65521; b %= 65521;
@@ -72,7 +76,8 @@ uint32_t adler32(const uint8_t* p, size_t n)
 // ---- inflate ------------------------------------------------------------------------------------------------------
 // Table entry: bits 0..3 code length consumed at this level (or, for a link, the sub-table's index width),
 // bits 4..7 kind, bits 8..12 extra-bit count, bits 16..31 base value / sub-table offset.
-enum { K_LITERAL = 1, K_LENGTH = 2, K_EOB = 3, K_LINK = 4, K_DIST = 5, K_INVALID = 0 };
+enum { K_LITERAL = 1, K_LENGTH = 2, K_EOB = 3, K_LINK = 4, K_DIST = 5, K_INVALID = 0,
+       K_LITERAL2 = 9 };     // two literals in one entry (value = first | second << 8): kind & 7 == K_LITERAL for both
 constexpr int LIT_BITS = 11, DIST_BITS = 8;
 inline uint32_t mk(int len, int kind, int extra, int value) { return (uint32_t)len | ((uint32_t)kind << 4) | ((uint32_t)extra << 8) | ((uint32_t)value << 16); }
 
@@ -95,7 +100,7 @@ inline uint32_t rev(uint32_t v, int n)
 
 // canonical Huffman decode table from code lengths; is_dist selects the payload encoding.  Returns false for an
 // over-subscribed code, or an incomplete one other than the single-code cases deflate allows.
-bool build_table(const uint8_t* lens, int n, int root, bool is_dist, Table& t)
+bool build_table(const uint8_t* lens, int n, int root, bool is_dist, Table& t, bool pair_literals = false)
 {
     int count[16] = {0};
     for (int i = 0; i < n; ++i) count[lens[i]]++;
@@ -160,6 +165,19 @@ bool build_table(const uint8_t* lens, int n, int root, bool is_dist, Table& t)
             const uint32_t r = rev(c & (((uint32_t)1 << sl) - 1), sl);
             const uint32_t ent = payload(i, sl);
             for (uint32_t k = r; k < ((uint32_t)1 << sb); k += (uint32_t)1 << sl) t.e[sub_off[prefix] + k] = ent;
+        }
+    }
+    if (pair_literals) {
+        // Filtered image data is mostly literals with short codes, and a literal costs one dependent table look-up: where
+        // the root index holds a literal AND the whole code of a second one, the entry delivers both.  From the top down:
+        // the entry looked up for the second symbol (index i >> len < i) is then still the single one.
+        for (uint32_t i = (uint32_t)1 << root; i-- > 0;) {
+            const uint32_t e = t.e[i];
+            if (((e >> 4) & 15) != K_LITERAL) continue;
+            const int l1 = (int)(e & 15);
+            const uint32_t e2 = t.e[i >> l1];
+            if (((e2 >> 4) & 15) == K_LITERAL && l1 + (int)(e2 & 15) <= root)
+                t.e[i] = mk(l1 + (int)(e2 & 15), K_LITERAL2, 0, (int)((e >> 16) | ((e2 >> 16) << 8)));
         }
     }
     return true;
@@ -239,7 +257,7 @@ bool inflate_raw(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_len,
                 nlit = 288; ndist = 30;
                 for (int i = 0; i < 30; ++i) lens[288 + i] = 5;
                 lens[288 + 30] = lens[288 + 31] = 5;
-                if (!build_table(lens, 288, LIT_BITS, false, lit)) { err = "inflate: internal table error"; return false; }
+                if (!build_table(lens, 288, LIT_BITS, false, lit, true)) { err = "inflate: internal table error"; return false; }
                 uint8_t dl[32];
                 for (int i = 0; i < 32; ++i) dl[i] = 5;
                 if (!build_table(dl, 32, DIST_BITS, true, dist)) { err = "inflate: internal table error"; return false; }
@@ -270,7 +288,7 @@ bool inflate_raw(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_len,
                     }
                 }
                 if (lens[256] == 0) { err = "inflate: no end-of-block code"; return false; }
-                if (!build_table(lens, nlit, LIT_BITS, false, lit)) { err = "inflate: bad literal/length code"; return false; }
+                if (!build_table(lens, nlit, LIT_BITS, false, lit, true)) { err = "inflate: bad literal/length code"; return false; }
                 if (!build_table(lens + nlit, ndist, DIST_BITS, true, dist)) { err = "inflate: bad distance code"; return false; }
             }
             if (b.ran_dry()) { err = "inflate: truncated stream"; return false; }
@@ -287,7 +305,7 @@ bool inflate_raw(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_len,
                 const uint8_t* p = b.p;
                 const uint8_t* const in_safe = b.end - 8;
                 uint8_t* const out_safe = oend - FAST_OUT;
-                const uint32_t LIT = (uint32_t)K_LITERAL << 4;
+                const uint32_t LIT = (uint32_t)K_LITERAL << 4, LITMASK = 0x70u;       // one literal or two
                 while (p <= in_safe && o <= out_safe) {
                     uint64_t v;
                     std::memcpy(&v, p, 8);
@@ -296,9 +314,11 @@ bool inflate_raw(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_len,
                     nb |= 56;
                     uint32_t e = LT[buf & ((1u << LIT_BITS) - 1)];
                     bool refill_first = false;
-                    while ((e & 0xf0u) == LIT) {
+                    while ((e & LITMASK) == LIT) {
                         buf >>= (e & 15); nb -= (int)(e & 15);
-                        *o++ = (uint8_t)(e >> 16);
+                        o[0] = (uint8_t)(e >> 16);
+                        o[1] = (uint8_t)(e >> 24);              // (a single literal's entry has a zero here: overwritten next)
+                        o += 1 + ((e >> 7) & 1);
                         if (nb < 32) { refill_first = true; break; }
                         e = LT[buf & ((1u << LIT_BITS) - 1)];
                     }
@@ -310,7 +330,7 @@ bool inflate_raw(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_len,
                     }
                     const uint32_t kind = (e >> 4) & 15;
                     buf >>= (e & 15); nb -= (int)(e & 15);
-                    if (kind == K_LITERAL) { *o++ = (uint8_t)(e >> 16); continue; }
+                    if (kind == K_LITERAL) { *o++ = (uint8_t)(e >> 16); continue; }     // (from a sub-table: always single)
                     if (kind == K_EOB) { block_done = true; break; }
                     if (kind != K_LENGTH) { err = "inflate: invalid literal/length code"; return false; }
                     const uint32_t xl = (e >> 8) & 31;
@@ -354,6 +374,12 @@ bool inflate_raw(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_len,
                 }
                 const int kind = (int)((e >> 4) & 15);
                 b.drop((int)(e & 15));
+                if (kind == K_LITERAL2) {
+                    if (oend - o < 2) { err = "inflate: more data than the image holds"; return false; }
+                    *o++ = (uint8_t)(e >> 16);
+                    *o++ = (uint8_t)(e >> 24);
+                    continue;
+                }
                 if (kind == K_LITERAL) {
                     if (o == oend) { err = "inflate: more data than the image holds"; return false; }
                     *o++ = (uint8_t)(e >> 16);
@@ -428,13 +454,27 @@ inline int paeth(int a, int b, int c)
 }
 
 // PNG filters undone in place (raw: h rows of 1 + w*bpp bytes), bpp = bytes per pixel
-bool unfilter(uint8_t* raw, int h, int w, int bpp, std::string& err)
+// bgr (bpp 3 only): the unfiltered row also goes out as B G R pixels, h rows of 3 w bytes -- in the same pass for Sub rows
+// (what cv2.imwrite and this library's own encoder write), whose running pixel then lives in registers instead of being
+// stored and reloaded three bytes later
+bool unfilter(uint8_t* raw, int h, int w, int bpp, uint8_t* bgr, std::string& err)
 {
     const size_t rowb = (size_t)w * bpp;
     std::vector<uint8_t> zero(rowb, 0);
     const uint8_t* prev = zero.data();
     for (int y = 0; y < h; ++y) {
         uint8_t* const row = raw + (size_t)y * (rowb + 1) + 1;
+        uint8_t* const drow = bpp == 3 && bgr ? bgr + (size_t)y * rowb : nullptr;
+        if (drow && row[-1] == 1) {
+            unsigned r = 0, g = 0, b = 0;
+            for (size_t i = 0; i < rowb; i += 3) {
+                r = (r + row[i]) & 0xffu; g = (g + row[i + 1]) & 0xffu; b = (b + row[i + 2]) & 0xffu;
+                row[i] = (uint8_t)r; row[i + 1] = (uint8_t)g; row[i + 2] = (uint8_t)b;       // (the next row may be Up / Paeth)
+                drow[i] = (uint8_t)b; drow[i + 1] = (uint8_t)g; drow[i + 2] = (uint8_t)r;
+            }
+            prev = row;
+            continue;
+        }
         switch (row[-1]) {
         case 0: break;
         case 1:
@@ -455,6 +495,8 @@ bool unfilter(uint8_t* raw, int h, int w, int bpp, std::string& err)
             err = "PNG: unknown filter type";
             return false;
         }
+        if (drow)
+            for (size_t i = 0; i < rowb; i += 3) { drow[i] = row[i + 2]; drow[i + 1] = row[i + 1]; drow[i + 2] = row[i]; }
         prev = row;
     }
     return true;
@@ -474,6 +516,9 @@ int png_read_bgr(const uint8_t* file, size_t len, uint8_t* out, size_t cap, int*
     bool seen_ihdr = false, seen_iend = false;
     static thread_local std::vector<uint8_t> idat, raw;      // reused: a fresh 6 MB vector per frame is 1-2 ms of page faults
     idat.clear();
+    const uint8_t* one_idat = nullptr;                       // a file with a single IDAT chunk is inflated in place
+    size_t one_len = 0;
+    int nidat = 0;
     while (pos + 12 <= len && !seen_iend) {
         const uint32_t n = rd_be32(file + pos);
         if (n > len - pos - 12) { err = "PNG: chunk runs past the end of the file"; return 1; }
@@ -490,7 +535,11 @@ int png_read_bgr(const uint8_t* file, size_t len, uint8_t* out, size_t cap, int*
             if (body[8] != 8 || body[12] != 0 || !(ctype == 0 || ctype == 2 || ctype == 4 || ctype == 6)) return 2;
         } else if (!std::memcmp(type, "IDAT", 4)) {
             if (!seen_ihdr) { err = "PNG: IDAT before IHDR"; return 1; }
-            idat.insert(idat.end(), body, body + n);
+            if (++nidat == 1) { one_idat = body; one_len = n; }                       // the only chunk so far: no copy yet
+            else {
+                if (nidat == 2) idat.assign(one_idat, one_idat + one_len);
+                idat.insert(idat.end(), body, body + n);
+            }
         } else if (!std::memcmp(type, "IEND", 4)) {
             seen_iend = true;
         } else if (!(type[0] & 0x20)) {
@@ -499,7 +548,9 @@ int png_read_bgr(const uint8_t* file, size_t len, uint8_t* out, size_t cap, int*
         }
         pos += 12 + (size_t)n;
     }
-    if (!seen_ihdr || !seen_iend || idat.empty()) { err = "PNG: missing IHDR, IDAT or IEND"; return 1; }
+    const uint8_t* const zdata = nidat >= 2 ? idat.data() : one_idat;
+    const size_t zlen = nidat >= 2 ? idat.size() : one_len;
+    if (!seen_ihdr || !seen_iend || zlen == 0) { err = "PNG: missing IHDR, IDAT or IEND"; return 1; }
     if (h_out) *h_out = h;
     if (w_out) *w_out = w;
     const size_t need = (size_t)h * w * 3;
@@ -508,10 +559,11 @@ int png_read_bgr(const uint8_t* file, size_t len, uint8_t* out, size_t cap, int*
     const int bpp = ctype == 0 ? 1 : ctype == 4 ? 2 : ctype == 2 ? 3 : 4;
     // deflate cannot expand by more than 1032:1: a header that promises more than the IDAT data could hold is damage (or
     // an attempt to make the reader allocate terabytes)
-    if ((size_t)h * ((size_t)w * bpp + 1) > idat.size() * 1032 + 1024) { err = "PNG: image larger than its data can be"; return 1; }
+    if ((size_t)h * ((size_t)w * bpp + 1) > zlen * 1032 + 1024) { err = "PNG: image larger than its data can be"; return 1; }
     raw.resize((size_t)h * ((size_t)w * bpp + 1) + 8);                    // + slack for the word-wise match copy
-    if (!zlib_decompress(idat.data(), idat.size(), raw.data(), raw.size() - 8, err)) return 1;
-    if (!unfilter(raw.data(), h, w, bpp, err)) return 1;
+    if (!zlib_decompress(zdata, zlen, raw.data(), raw.size() - 8, err)) return 1;
+    if (!unfilter(raw.data(), h, w, bpp, out, err)) return 1;
+    if (bpp != 3)
     for (int y = 0; y < h; ++y) {
         const uint8_t* s = raw.data() + (size_t)y * ((size_t)w * bpp + 1) + 1;
         uint8_t* d = out + (size_t)y * w * 3;
