@@ -17,10 +17,10 @@
 //
 //   * and the CRC-32 of its compressed bytes (the PNG chunk CRC is the framing's one pass over the data otherwise).
 //
-// Two kernels: png_deflate_kernel leaves every block in a slot of its own in HBM (it runs on the net's stream, so it
-// must not wait for PCIe); png_pack_kernel, on the download stream, concatenates the blocks into the caller's
-// page-locked workspace -- only the bytes produced cross PCIe, about half of the raw frame, while the next frame's
-// net already runs.  The host adds the zlib / PNG framing and combines the checksums (uva_png_assemble: any thread,
+// Two kernels on the net's stream: png_deflate_kernel leaves every block in a slot of its own in HBM, png_pack_kernel
+// concatenates them (HBM to HBM); the copy engine then takes the packed bytes to the caller's page-locked workspace on
+// the download stream -- only the bytes produced cross PCIe, about half of the raw frame, while the next frame's net
+// already runs and without a kernel waiting for PCIe.  The host adds the zlib / PNG framing and combines the checksums (uva_png_assemble: any thread,
 // no GPU call, no pass over the data besides the one copy).  The stream is plain RFC 1950/1951: every PNG reader
 // decodes it to the same pixels cv2.imwrite's file gives.
 #pragma once
@@ -438,13 +438,14 @@ __global__ __launch_bounds__(PNG_THREADS) void png_deflate_kernel(PngArgs a)
     }
 }
 
-// The blocks, concatenated, into the caller's page-locked workspace: [meta, as png_deflate_kernel left it][the bytes].
-// One workgroup per block; destination offsets are unaligned, the middle of every block goes out as aligned dwords.
+// The blocks, concatenated (device to device; the copy engine takes the result to the caller's page-locked workspace:
+// [meta, as png_deflate_kernel left it][the bytes]).  One workgroup per block; destination offsets are unaligned, the
+// middle of every block goes out as aligned dwords.
 struct PngPackArgs {
     const uint32_t* meta;         // HBM
     const uint8_t* slots;         // HBM
     int nblocks;
-    uint32_t* out_meta;           // page-locked host memory
+    uint32_t* out_meta;           // nullptr, or where the meta rows are to be copied as well
     uint8_t* out_data;
 };
 constexpr int PNG_PACK_THREADS = 256;
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(PNG_PACK_THREADS) void png_pack_kernel(PngPackArgs 
     const size_t off = (size_t)off_s;
     const uint32_t* const m = a.meta + (size_t)b * PNG_META_WORDS;
     const int nbytes = (int)m[0];
-    if (tid < PNG_META_WORDS) a.out_meta[(size_t)b * PNG_META_WORDS + tid] = m[tid];
+    if (a.out_meta && tid < PNG_META_WORDS) a.out_meta[(size_t)b * PNG_META_WORDS + tid] = m[tid];
     const uint8_t* const src = a.slots + (size_t)b * PNG_SLOT_BYTES;      // 256-byte aligned
     uint8_t* const dst = a.out_data + off;
     const int head = min(nbytes, (int)((4 - ((uintptr_t)dst & 3)) & 3));  // bytes until dst is dword aligned
