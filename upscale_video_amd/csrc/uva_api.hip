@@ -156,6 +156,8 @@ struct uva_net {
         size_t png_sent = 0;             // frame's download, and the frame size (collect fetches the rest, if any)
         int png_h = 0, png_w = 0;
         hipEvent_t ev_h2d = nullptr, ev_done = nullptr, ev_d2h = nullptr;
+        static constexpr int BANDS = 4;  // a staged (pageable) result comes down in row bands: collect copies band k to the
+        hipEvent_t ev_band[BANDS] = {nullptr, nullptr, nullptr, nullptr};   // caller while band k + 1 is still on PCIe
         uint8_t* user_out = nullptr;     // where collect copies the staged result (null: D2H went there directly)
         size_t user_out_stride = 0, out_row = 0;
         int out_rows = 0;
@@ -206,6 +208,8 @@ struct uva_net {
             if (ps.ev_h2d) (void)hipEventDestroy(ps.ev_h2d);
             if (ps.ev_done) (void)hipEventDestroy(ps.ev_done);
             if (ps.ev_d2h) (void)hipEventDestroy(ps.ev_d2h);
+            for (auto& e : ps.ev_band)
+                if (e) (void)hipEventDestroy(e);
             ps = PipeSlot();
         }
         if (s_h2d) (void)hipStreamDestroy(s_h2d);
@@ -1805,8 +1809,19 @@ long long submit_u8(uva_net* n, const uint8_t* in, int h, int w, size_t in_strid
         dst = ps.h_out; dst_stride = out_row;
         ps.user_out = out; ps.user_out_stride = out_stride; ps.out_row = out_row; ps.out_rows = h * s;
     }
-    if (tryhip(hipMemcpy2DAsync(dst, dst_stride, ps.d_out, out_row, out_row, (size_t)h * s, hipMemcpyDeviceToHost, n->s_d2h), "D2H") ||
-        tryhip(hipEventRecord(ps.ev_d2h, n->s_d2h), "hipEventRecord")) return -1;
+    if (ps.user_out) {
+        const int rows = h * s, per = (rows + uva_net::PipeSlot::BANDS - 1) / uva_net::PipeSlot::BANDS;
+        for (int k = 0; k < uva_net::PipeSlot::BANDS; ++k) {
+            if (!ps.ev_band[k] && tryhip(hipEventCreateWithFlags(&ps.ev_band[k], hipEventDisableTiming), "hipEventCreate")) return -1;
+            const int r0 = std::min(rows, k * per), nr = std::min(rows, r0 + per) - r0;
+            if (nr > 0 && tryhip(hipMemcpyAsync(dst + (size_t)r0 * out_row, ps.d_out + (size_t)r0 * out_row, (size_t)nr * out_row,
+                                                hipMemcpyDeviceToHost, n->s_d2h), "D2H")) return -1;
+            if (tryhip(hipEventRecord(ps.ev_band[k], n->s_d2h), "hipEventRecord")) return -1;
+        }
+    } else if (tryhip(hipMemcpy2DAsync(dst, dst_stride, ps.d_out, out_row, out_row, (size_t)h * s, hipMemcpyDeviceToHost, n->s_d2h), "D2H")) {
+        return -1;
+    }
+    if (tryhip(hipEventRecord(ps.ev_d2h, n->s_d2h), "hipEventRecord")) return -1;
     ps.busy = true;
     ps.ticket = n->next_ticket;
     return n->next_ticket++;
@@ -1904,6 +1919,21 @@ int uva_net_collect_u8(uva_net* n, long long ticket)
     if (!slot) return fail("uva_net_collect_u8: ticket " + std::to_string(ticket) + " is not in flight");
     uva_net::PipeSlot& ps = *slot;
     HIP_TRY(hipSetDevice(n->device));
+    if (ps.user_out) {
+        const int per = (ps.out_rows + uva_net::PipeSlot::BANDS - 1) / uva_net::PipeSlot::BANDS;
+        for (int k = 0; k < uva_net::PipeSlot::BANDS; ++k) {
+            HIP_TRY(hipEventSynchronize(ps.ev_band[k]));
+            const int r0 = std::min(ps.out_rows, k * per), r1 = std::min(ps.out_rows, r0 + per);
+            if (ps.user_out_stride == ps.out_row) {
+                if (r1 > r0) std::memcpy(ps.user_out + (size_t)r0 * ps.out_row, ps.h_out + (size_t)r0 * ps.out_row, (size_t)(r1 - r0) * ps.out_row);
+            } else {
+                for (int y = r0; y < r1; ++y)
+                    std::memcpy(ps.user_out + (size_t)y * ps.user_out_stride, ps.h_out + (size_t)y * ps.out_row, ps.out_row);
+            }
+        }
+        ps.busy = false;
+        return 0;
+    }
     HIP_TRY(hipEventSynchronize(ps.ev_d2h));
     if (ps.png_ws) {
         // the meta is here: fetch what the download did not cover (a frame that compressed worse than the one before)
@@ -1916,9 +1946,6 @@ int uva_net_collect_u8(uva_net* n, long long ticket)
         n->png_guess = total;
         ps.png_ws = nullptr;
     }
-    if (ps.user_out)
-        for (int y = 0; y < ps.out_rows; ++y)
-            std::memcpy(ps.user_out + (size_t)y * ps.user_out_stride, ps.h_out + (size_t)y * ps.out_row, ps.out_row);
     ps.busy = false;
     return 0;
 }
