@@ -111,9 +111,10 @@ void uva_host_free(void* p);
 
 /* cv2.imwrite(frame.png) of the result frame (upscale_processing.py:288, :519), with the deflate work done on the GPU:
  * like uva_net_submit_u8, but the result frame stays in HBM, a kernel behind the net compresses it (Sub filter, fixed
- * Huffman tables, one deflate block per group of rows) and writes the compressed blocks straight into `png_ws`:
+ * Huffman tables, one deflate block per group of rows) and the copy engine brings the compressed blocks into `png_ws`:
  * page-locked memory (uva_host_alloc) of uva_png_workspace_bytes(h*scale, w*scale) bytes that must stay untouched until
- * uva_net_collect_u8(ticket) has returned.  uva_png_assemble() -- host only, any thread -- then turns the workspace into
+ * uva_net_collect_u8(ticket) has returned (collect completes the workspace: a frame that compressed worse than the
+ * one before it has its last bytes fetched there).  uva_png_assemble() -- host only, any thread -- then turns the workspace into
  * the bytes of the PNG file: *len receives the size; out may be NULL to ask for it (the call then fails after setting
  * *len).  h, w there are the RESULT frame's.  Any PNG reader decodes the file to exactly the frame
  * uva_net_submit_u8 would have returned.  uva_png_workspace_bytes() returns 0 for frames the encoder does not take
