@@ -141,6 +141,38 @@ def test_net_result_through_the_png_route_equals_the_frame_route():
 
 
 @pytest.mark.gpu
+def test_a_frame_that_compresses_worse_than_the_one_before_it():
+    """The download that travels with a frame carries as many packed bytes as the previous frame had (+ 6 %); what a
+    larger frame has beyond that is fetched by collect_u8.  Flat frames (tiny files) alternate with noise (the largest)."""
+    import os
+    from upscale_video_amd import ncnn
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    net = ncnn.Net()
+    net.set_vulkan_device(0)
+    base = os.path.join(root, "models", "2x_Compact_Pretrain")
+    assert net.load_param(base + ".param") == 0 and net.load_model(base + ".bin") == 0
+    rng = np.random.default_rng(12)
+    imgs = []
+    for i in range(6):
+        imgs.append(np.full((270, 480, 3), 40 * i, np.uint8) if i % 2 == 0 else rng.integers(0, 256, (270, 480, 3), dtype=np.uint8))
+    want = [net.process_u8(im, tile_size=0).copy() for im in imgs]
+    spaces = [ncnn.PngWorkspace(540, 960) for _ in range(3)]
+    sizes = []
+    for depth in (1, 3):                                 # one at a time (the guess is always the previous frame), and pipelined
+        tickets, got = [], []
+        for i, im in enumerate(imgs):
+            if len(tickets) == depth:
+                got.append(bytes(net.collect_u8(tickets.pop(0)).file_bytes()))
+            tickets.append(net.submit_u8_png(im, workspace=spaces[i % 3], tile_size=0))
+        while tickets:
+            got.append(bytes(net.collect_u8(tickets.pop(0)).file_bytes()))
+        for png, ref in zip(got, want):
+            np.testing.assert_array_equal(decode(png), ref)
+        sizes = [len(g) for g in got]
+    assert min(sizes[1::2]) > 4 * max(sizes[0::2])        # the test does alternate small and large
+
+
+@pytest.mark.gpu
 def test_full_size_frame_round_trip():
     from upscale_video_amd import ncnn
     from upscale_video_amd.synth import synthetic_frame
