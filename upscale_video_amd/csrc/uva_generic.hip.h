@@ -129,7 +129,8 @@ struct GConvArgs {
     float slope;
 };
 constexpr int GC_TH = 8, GC_TW = 32;
-constexpr int GC_CH = 2;          // input channels go through LDS 64 at a time (two k-steps of 32)
+constexpr int GC_CH = 1;          // input channels go through LDS 32 at a time (one k-step): 33 KB and 80-100 registers per
+                                  // workgroup, four of them share a CU (64 at a time: two or three, -14 % on Valar)
 // (ksize 1: the same kernel without the halo and with a single tap -- the RRDBs' 1x1 residual convolutions)
 inline size_t g_conv3_lds_bytes(int cin_pad, int mbn, int ksize = 3)
 {
@@ -155,8 +156,8 @@ __global__ __launch_bounds__(256) void g_conv3_lds(GConvArgs a)
     char* const tile = gsm;
     char* const wbuf = gsm + (size_t)GC_NPIX * (cn_max * 64 + 16);   // one ROW of taps of the current channel chunk
 
-    // The input channels go through LDS in chunks of 64 (the tile of a 192-channel convolution would fill the LDS: one
-    // workgroup per CU, its load, compute and store phases in series -- with 57 KiB per workgroup two or three share a
+    // The input channels go through LDS in chunks of 32 * GC_CH (the tile of a 192-channel convolution would fill the LDS:
+    // one workgroup per CU, its load, compute and store phases in series -- with 33 KiB per workgroup four share a
     // CU and overlap them), the weights one row of taps (KSZ taps x chunk) at a time, the next row's on their way in
     // registers while this one is used.  Stage s = (chunk, tap row).
     constexpr int WMAX = (KSZ * GC_CH * MBN * 64 + 255) / 256;   // 16-byte units per thread and weight stage
