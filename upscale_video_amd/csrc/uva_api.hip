@@ -1135,7 +1135,10 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
                 ga.h = a.h; ga.w = a.w;
                 ga.has_act = gl.has_act ? 1 : 0; ga.slope = gl.act_slope;
                 const int mbn = cd.cout_pad / 16;
-                const size_t lds = g_conv3_lds_bytes(cd.cin_pad, mbn, gl.ksize);
+                // (UVA_GENERIC_WG=0: the 3x3 convolutions stage their weights through LDS again -- the A/B switch)
+                static const int wg_max = [] { const char* e = std::getenv("UVA_GENERIC_WG"); return e ? std::atoi(e) : 4; }();
+                const bool wg = gl.ksize == 3 && mbn <= wg_max && (mbn == 2 || mbn == 4);
+                const size_t lds = g_conv3_lds_bytes(cd.cin_pad, mbn, gl.ksize, wg);
                 const dim3 g3((a.w + GC_TW - 1) / GC_TW, (a.h + GC_TH - 1) / GC_TH);
                 auto launch = [&](auto kern, int slot) -> int {
                     if (!n->attr_set[slot]) {
@@ -1151,6 +1154,8 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
                     else if (mbn == 3) { if (launch(g_conv3_lds<3, 1>, 18)) return 1; }
                     else { if (launch(g_conv3_lds<4, 1>, 19)) return 1; }
                 }
+                else if (wg && mbn == 2) { if (launch(g_conv3_lds<2, 3, true>, 21)) return 1; }
+                else if (wg && mbn == 4) { if (launch(g_conv3_lds<4, 3, true>, 22)) return 1; }
                 else if (mbn == 1) { if (launch(g_conv3_lds<1>, 11)) return 1; }
                 else if (mbn == 2) { if (launch(g_conv3_lds<2>, 12)) return 1; }
                 else if (mbn == 3) { if (launch(g_conv3_lds<3>, 13)) return 1; }

@@ -132,19 +132,23 @@ constexpr int GC_TH = 8, GC_TW = 32;
 constexpr int GC_CH = 1;          // input channels go through LDS 32 at a time (one k-step): 33 KB and 80-100 registers per
                                   // workgroup, four of them share a CU (64 at a time: two or three, -14 % on Valar)
 // (ksize 1: the same kernel without the halo and with a single tap -- the RRDBs' 1x1 residual convolutions)
-inline size_t g_conv3_lds_bytes(int cin_pad, int mbn, int ksize = 3)
+inline size_t g_conv3_lds_bytes(int cin_pad, int mbn, int ksize = 3, bool wg = false)
 {
     const size_t npix = (size_t)(GC_TH + ksize - 1) * (GC_TW + ksize - 1);
     const int cn = std::min(GC_CH, cin_pad / 32);
-    const size_t work = npix * (cn * 64 + 16) + (size_t)ksize * cn * mbn * 1024;                       // halo tile chunk + one row of taps
+    const size_t work = npix * (cn * 64 + 16) + (wg ? 0 : (size_t)ksize * cn * mbn * 1024);            // halo tile chunk + one row of taps
     const size_t stage = (size_t)GC_TH * GC_TW * (mbn * 32 + 16);                                      // the epilogue's output staging tile
     return work > stage ? work : stage;
 }
 __device__ __forceinline__ int gpix(int p) { return p < 4 ? 2 * p : p >= 12 ? 2 * (p - 8) : 2 * (p - 4) + 1; }
 
-template <int MBN, int KSZ = 3>
+// WG: the weights do not go through LDS: every wave fetches its fragments of the next row of taps from L2 / L1 into
+// registers while the current row's MFMAs run.  No weight staging, no barrier per row of taps (two per channel chunk
+// remain, around the tile), 6 KB less LDS.
+template <int MBN, int KSZ = 3, bool WG = false>
 __global__ __launch_bounds__(256) void g_conv3_lds(GConvArgs a)
 {
+    static_assert(!WG || (KSZ == 3 && GC_CH == 1), "weights from global memory: 3x3, 32-channel chunks");
     constexpr int GC_PH = GC_TH + KSZ - 1, GC_PW = GC_TW + KSZ - 1, GC_NPIX = GC_PH * GC_PW, ORG = KSZ == 3 ? 0 : 1;
     constexpr int RB = GC_PH / 2;                                // tile rows per load batch
     extern __shared__ __attribute__((aligned(16))) char gsm[];
@@ -211,7 +215,18 @@ __global__ __launch_bounds__(256) void g_conv3_lds(GConvArgs a)
         }
     };
 
-    wfetch(0);
+    half8 wq[KSZ][MBN];                                          // WG: this row of taps' weight fragments
+    auto wload = [&](int st, int t, half8 (&wv)[MBN]) {
+        const int c0 = st / KSZ, tr = st % KSZ;
+#pragma unroll
+        for (int m = 0; m < MBN; ++m) wv[m] = a.wpk[((size_t)(tr * KSZ + t) * c32n + c0) * MBN * 64 + m * 64 + lane];
+    };
+    if constexpr (WG) {
+#pragma unroll
+        for (int t = 0; t < KSZ; ++t) wload(0, t, wq[t]);
+    } else {
+        wfetch(0);
+    }
     for (int s = 0; s < nstage; ++s) {
         const int c0 = (s / KSZ) * GC_CH, cn = min(GC_CH, c32n - c0), tr = s % KSZ;
         const int pstride = cn * 64 + 16;                        // bytes per pixel of this chunk's tile: an odd number of units
@@ -241,18 +256,36 @@ __global__ __launch_bounds__(256) void g_conv3_lds(GConvArgs a)
                 }
             }
             if (s + KSZ < nstage) tfetch(c0 + GC_CH, min(GC_CH, c32n - c0 - GC_CH), 0);
-        } else {
+            if constexpr (WG) __syncthreads();                   // the tile is in place
+        } else if constexpr (!WG) {
             __syncthreads();                                     // everybody is done with the previous row of taps
         }
-        wstore(s);
-        __syncthreads();
-        if (s + 1 < nstage) wfetch(s + 1);
+        if constexpr (!WG) {
+            wstore(s);
+            __syncthreads();
+            if (s + 1 < nstage) wfetch(s + 1);
+        }
 
         // fragment f = 2*n + c: row 2*wave + n, columns 16*c .. 16*c + 15 of the tile's interior
         unsigned fbase[4];
 #pragma unroll
         for (int f = 0; f < 4; ++f)
             fbase[f] = (unsigned)(((2 * wave + (f >> 1) + tr) * GC_PW + 16 * (f & 1) + pix) * pstride + unit_of_o * 16);
+        if constexpr (WG) {
+            // one k-step per tap column; a slot is refilled with the same column of the NEXT row of taps right after use
+#pragma unroll
+            for (int t = 0; t < KSZ; ++t) {
+                half8 bv[4];
+#pragma unroll
+                for (int f = 0; f < 4; ++f) bv[f] = *(const half8*)(tile + fbase[f] + t * pstride);
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+#pragma unroll
+                    for (int m = 0; m < MBN; ++m) acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[t][m], bv[f], acc[f][m], 0, 0, 0);
+                if (s + 1 < nstage) wload(s + 1, t, wq[t]);
+            }
+            continue;
+        }
         // k-steps of this stage: (tap column t, 32-channel group c); operands of the next one are read while this one's
         // MFMAs run
         const int nk = KSZ * cn;
