@@ -158,3 +158,15 @@ def test_opportunistic_pin_against_real_ncnn_and_cv2(uva, oracle, oracle_models)
             got = np.array(out)
             want = oracle_models[key].forward(oracle.from_pixels_normalize(img))
             assert np.abs(got - want).max() <= 2e-3, (key, float(np.abs(got - want).max()))
+
+
+@pytest.mark.gpu
+def test_narrow_strip_kloop_equals_the_full_one():
+    """Strips of <= 14 columns run trunk2_kernel's k-loop without the second fragment column (UVA_T2_NARROW=0 turns that
+    off): every width 1..47, the 970-wide planes of the reference's tiling and a tiled frame give identical bytes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "narrow_check.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "differing: none" in r.stdout
