@@ -1138,14 +1138,17 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
                 // (UVA_GENERIC_WG=0: the 3x3 convolutions stage their weights through LDS again -- the A/B switch)
                 static const int wg_max = [] { const char* e = std::getenv("UVA_GENERIC_WG"); return e ? std::atoi(e) : 4; }();
                 const bool wg = gl.ksize == 3 && mbn <= wg_max && (mbn == 2 || mbn == 4);
-                const size_t lds = g_conv3_lds_bytes(cd.cin_pad, mbn, gl.ksize, wg);
-                const dim3 g3((a.w + GC_TW - 1) / GC_TW, (a.h + GC_TH - 1) / GC_TH);
+                // 16-row tiles (8 waves) where the plane is tall enough to keep every CU busy with them
+                static const int nw_max = [] { const char* e = std::getenv("UVA_GENERIC_NW"); return e ? std::atoi(e) : 4; }();
+                const int nw = (wg && nw_max >= 8 && (long long)((a.w + GC_TW - 1) / GC_TW) * ((a.h + 15) / 16) >= 4LL * n->ncu) ? 8 : 4;
+                const size_t lds = g_conv3_lds_bytes(cd.cin_pad, mbn, gl.ksize, wg, nw);
+                const dim3 g3((a.w + GC_TW - 1) / GC_TW, (a.h + 2 * nw - 1) / (2 * nw));
                 auto launch = [&](auto kern, int slot) -> int {
                     if (!n->attr_set[slot]) {
                         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                         n->attr_set[slot] = true;
                     }
-                    hipLaunchKernelGGL(kern, g3, dim3(256), lds, n->stream, ga);
+                    hipLaunchKernelGGL(kern, g3, dim3(64 * nw), lds, n->stream, ga);
                     return 0;
                 };
                 if (gl.ksize == 1) {
@@ -1154,6 +1157,8 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
                     else if (mbn == 3) { if (launch(g_conv3_lds<3, 1>, 18)) return 1; }
                     else { if (launch(g_conv3_lds<4, 1>, 19)) return 1; }
                 }
+                else if (wg && mbn == 2 && nw == 8) { if (launch(g_conv3_lds<2, 3, true, 8>, 23)) return 1; }
+                else if (wg && mbn == 4 && nw == 8) { if (launch(g_conv3_lds<4, 3, true, 8>, 15)) return 1; }
                 else if (wg && mbn == 2) { if (launch(g_conv3_lds<2, 3, true>, 21)) return 1; }
                 else if (wg && mbn == 4) { if (launch(g_conv3_lds<4, 3, true>, 22)) return 1; }
                 else if (mbn == 1) { if (launch(g_conv3_lds<1>, 11)) return 1; }

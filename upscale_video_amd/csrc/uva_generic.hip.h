@@ -132,12 +132,13 @@ constexpr int GC_TH = 8, GC_TW = 32;
 constexpr int GC_CH = 1;          // input channels go through LDS 32 at a time (one k-step): 33 KB and 80-100 registers per
                                   // workgroup, four of them share a CU (64 at a time: two or three, -14 % on Valar)
 // (ksize 1: the same kernel without the halo and with a single tap -- the RRDBs' 1x1 residual convolutions)
-inline size_t g_conv3_lds_bytes(int cin_pad, int mbn, int ksize = 3, bool wg = false)
+inline size_t g_conv3_lds_bytes(int cin_pad, int mbn, int ksize = 3, bool wg = false, int nw = 4)
 {
-    const size_t npix = (size_t)(GC_TH + ksize - 1) * (GC_TW + ksize - 1);
+    const int th = 2 * nw;                                                                             // tile rows: two per wave
+    const size_t npix = (size_t)(th + ksize - 1) * (GC_TW + ksize - 1);
     const int cn = std::min(GC_CH, cin_pad / 32);
     const size_t work = npix * (cn * 64 + 16) + (wg ? 0 : (size_t)ksize * cn * mbn * 1024);            // halo tile chunk + one row of taps
-    const size_t stage = (size_t)GC_TH * GC_TW * (mbn * 32 + 16);                                      // the epilogue's output staging tile
+    const size_t stage = (size_t)th * GC_TW * (mbn * 32 + 16);                                         // the epilogue's output staging tile
     return work > stage ? work : stage;
 }
 __device__ __forceinline__ int gpix(int p) { return p < 4 ? 2 * p : p >= 12 ? 2 * (p - 8) : 2 * (p - 4) + 1; }
@@ -145,16 +146,22 @@ __device__ __forceinline__ int gpix(int p) { return p < 4 ? 2 * p : p >= 12 ? 2 
 // WG: the weights do not go through LDS: every wave fetches its fragments of the next row of taps from L2 / L1 into
 // registers while the current row's MFMAs run.  No weight staging, no barrier per row of taps (two per channel chunk
 // remain, around the tile), 6 KB less LDS.
-template <int MBN, int KSZ = 3, bool WG = false>
-__global__ __launch_bounds__(256) void g_conv3_lds(GConvArgs a)
+// NW waves own a 2 NW x 32 output tile (8 x 32, or 16 x 32: its halo is 1.20 instead of 1.33 times the tile -- the
+// convolutions of a dense block are bound by re-reading their inputs).
+template <int MBN, int KSZ = 3, bool WG = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void g_conv3_lds(GConvArgs a)
 {
-    static_assert(!WG || (KSZ == 3 && GC_CH == 1), "weights from global memory: 3x3, 32-channel chunks");
-    constexpr int GC_PH = GC_TH + KSZ - 1, GC_PW = GC_TW + KSZ - 1, GC_NPIX = GC_PH * GC_PW, ORG = KSZ == 3 ? 0 : 1;
+    static_assert(GC_CH == 1, "32-channel chunks: four 16-byte units per pixel");
+    static_assert(!WG || KSZ == 3, "weights from global memory: 3x3");
+    constexpr int NT = 64 * NW, TH = 2 * NW;
+    constexpr int GC_PH = TH + KSZ - 1, GC_PW = GC_TW + KSZ - 1, GC_NPIX = GC_PH * GC_PW, ORG = KSZ == 3 ? 0 : 1;
     constexpr int RB = GC_PH / 2;                                // tile rows per load batch
+    static_assert(GC_PH % 2 == 0, "two load batches");
+    constexpr int ROWU = GC_PW * 4, HU = RB * ROWU, KT = (HU + NT - 1) / NT;   // 16-byte units per tile row, per batch, per thread
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int p = lane & 15, o = lane >> 4, pix = gpix(p);
-    const int x0 = blockIdx.x * GC_TW, y0 = blockIdx.y * GC_TH;
+    const int x0 = blockIdx.x * GC_TW, y0 = blockIdx.y * TH;
     const int c32n = a.cin_pad / 32;
     const int cn_max = min(GC_CH, c32n);
     char* const tile = gsm;
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(256) void g_conv3_lds(GConvArgs a)
     // one workgroup per CU, its load, compute and store phases in series -- with 33 KiB per workgroup four share a
     // CU and overlap them), the weights one row of taps (KSZ taps x chunk) at a time, the next row's on their way in
     // registers while this one is used.  Stage s = (chunk, tap row).
-    constexpr int WMAX = (KSZ * GC_CH * MBN * 64 + 255) / 256;   // 16-byte units per thread and weight stage
+    constexpr int WMAX = (KSZ * GC_CH * MBN * 64 + NT - 1) / NT;   // 16-byte units per thread and weight stage
     const int nstage = ((c32n + GC_CH - 1) / GC_CH) * KSZ;
     half8 wreg[WMAX];
     auto wfetch = [&](int s) {
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(256) void g_conv3_lds(GConvArgs a)
         const int per_tap = cn * MBN * 64;                       // units per tap of this chunk
 #pragma unroll
         for (int k = 0; k < WMAX; ++k) {
-            const int j = tid + 256 * k;
+            const int j = tid + NT * k;
             if (j < KSZ * per_tap) {
                 const int t = j / per_tap, r = j - t * per_tap;
                 wreg[k] = a.wpk[((size_t)(tr * KSZ + t) * c32n + c0) * MBN * 64 + r];
@@ -184,7 +191,7 @@ __global__ __launch_bounds__(256) void g_conv3_lds(GConvArgs a)
         const int per_tap = cn * MBN * 64;
 #pragma unroll
         for (int k = 0; k < WMAX; ++k) {
-            const int j = tid + 256 * k;
+            const int j = tid + NT * k;
             if (j < KSZ * per_tap) *(half8*)(wbuf + (size_t)j * 16) = wreg[k];
         }
     };
@@ -196,22 +203,25 @@ __global__ __launch_bounds__(256) void g_conv3_lds(GConvArgs a)
         for (int m = 0; m < MBN; ++m) acc[f][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int unit_of_o = o == 0 ? 0 : o == 1 ? 2 : o == 2 ? 1 : 3;
 
-    uint4 tv[RB][2];                                             // half a tile chunk in registers: 34 pixels x 8 units = 272 per row, two per thread
-    auto tfetch = [&](int c0, int cn, int half) {
-        const int units = cn * 4;
-        const unsigned inv = (65536u + units - 1) / units;
-        const int row_units = GC_PW * units;
+    // half a tile chunk in registers: unit j of the batch is row j / ROWU, pixel (j % ROWU) / 4, 16-byte unit j % 4
+    uint4 tv2[2][KT];
+    auto tfetch = [&](int c0, int half) {
+        uint4 (&tv)[KT] = tv2[half];
 #pragma unroll
-        for (int rr = 0; rr < RB; ++rr) {
-            const int r = RB * half + rr, ay = y0 + ORG + r;
-            const _Float16* const grow = a.in + ((size_t)ay * (a.w + 2) + x0 + ORG) * a.in_stride + 32 * c0;
+        for (int k = 0; k < KT; ++k) {
+            const int j = tid + NT * k, rr = j / ROWU, q = j - rr * ROWU, c = q >> 2, u = q & 3;
+            const int ay = y0 + ORG + RB * half + rr;
+            tv[k] = make_uint4(0, 0, 0, 0);
+            if (j < HU && ay <= a.h + 1 && x0 + ORG + c <= a.w + 1)
+                tv[k] = *(const uint4*)(a.in + ((size_t)ay * (a.w + 2) + x0 + ORG + c) * a.in_stride + 32 * c0 + 8 * u);
+        }
+    };
+    auto tstore = [&](int half, int pstride) {
+        uint4 (&tv)[KT] = tv2[half];
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int j = tid + 256 * k;
-                const int c = (int)(((unsigned)j * inv) >> 16), u = j - c * units;
-                tv[rr][k] = make_uint4(0, 0, 0, 0);
-                if (j < row_units && ay <= a.h + 1 && x0 + ORG + c <= a.w + 1) tv[rr][k] = *(const uint4*)(grow + (size_t)c * a.in_stride + 8 * u);
-            }
+        for (int k = 0; k < KT; ++k) {
+            const int j = tid + NT * k, rr = j / ROWU, q = j - rr * ROWU, c = q >> 2, u = q & 3;
+            if (j < HU) *(uint4*)(tile + (size_t)((RB * half + rr) * GC_PW + c) * pstride + 16 * u) = tv[k];
         }
     };
 
@@ -233,29 +243,14 @@ __global__ __launch_bounds__(256) void g_conv3_lds(GConvArgs a)
         if (tr == 0) {
             // halo tile of this chunk: array rows y0 .. y0+9, columns x0 .. x0+33 (the array carries a one-pixel zero
             // border: pixel (y, x) sits at row y+1, column x+1), channels 32*c0 .. +32*cn; outside the array: zeros.  A
-            // tile row is GC_PW consecutive pixels of the array; the pixel of unit j is j / units by a multiplication
-            // (exact for j < 34 * 8).  The first chunk's rows are fetched here, half of them in flight at a time; the
+            // tile row is GC_PW consecutive pixels of the array.  The first chunk's rows are fetched here, half of them in flight at a time; the
             // first half of every later chunk's rows has been on its way since the previous chunk's tile was stored
             // (tfetch below), so that only the second half's latency is left in the open.
             if (s > 0) __syncthreads();                          // the previous chunk's tile has been used up
-            const int units = cn * 4;                            // 16-byte units per pixel of this chunk (32 channels = 4)
-            const unsigned inv = (65536u + units - 1) / units;
-            const int row_units = GC_PW * units;
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                if (half == 1 || s == 0) tfetch(c0, cn, half);
-#pragma unroll
-                for (int rr = 0; rr < RB; ++rr) {
-                    char* const lrow = tile + (size_t)(RB * half + rr) * GC_PW * pstride;
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const int j = tid + 256 * k;
-                        const int c = (int)(((unsigned)j * inv) >> 16), u = j - c * units;
-                        if (j < row_units) *(uint4*)(lrow + (size_t)c * pstride + 16 * u) = tv[rr][k];
-                    }
-                }
-            }
-            if (s + KSZ < nstage) tfetch(c0 + GC_CH, min(GC_CH, c32n - c0 - GC_CH), 0);
+            if (s == 0) { tfetch(c0, 0); tfetch(c0, 1); }
+            tstore(0, pstride);
+            tstore(1, pstride);
+            if (s + KSZ < nstage) { tfetch(c0 + GC_CH, 0); tfetch(c0 + GC_CH, 1); }
             if constexpr (WG) __syncthreads();                   // the tile is in place
         } else if constexpr (!WG) {
             __syncthreads();                                     // everybody is done with the previous row of taps
@@ -338,14 +333,14 @@ __global__ __launch_bounds__(256) void g_conv3_lds(GConvArgs a)
     __syncthreads();
     if (a.cout % 8 == 0) {
         const int upp = a.cout / 8;                               // 16-byte units per pixel
-        for (int i = tid; i < GC_TH * GC_TW * upp; i += 256) {
+        for (int i = tid; i < TH * GC_TW * upp; i += NT) {
             const int px = i / upp, u = i - px * upp;
             const int y = y0 + px / GC_TW, x = x0 + px % GC_TW;
             if (y < a.h && x < a.w)
                 *(uint4*)(a.out + ((size_t)(y + 1) * (a.w + 2) + (x + 1)) * a.out_stride + a.out_coff + 8 * u) = *(const uint4*)(stage + px * OUTB + 16 * u);
         }
     } else {
-        for (int i = tid; i < GC_TH * GC_TW * a.cout; i += 256) {
+        for (int i = tid; i < TH * GC_TW * a.cout; i += NT) {
             const int px = i / a.cout, c = i - px * a.cout;
             const int y = y0 + px / GC_TW, x = x0 + px % GC_TW;
             if (y < a.h && x < a.w)
