@@ -183,6 +183,39 @@ def test_valar_graph_with_synthetic_weights(uva, oracle, tmp_path):
     assert np.array_equal(up.net.process_u8(img, tile_size=960, border=10), u8)
 
 
+_FUSE_CHILD = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from upscale_video_amd import ncnn
+from upscale_video_amd.synth import synthetic_frame
+net = ncnn.Net(); net.set_vulkan_device(0)
+assert net.load_param(sys.argv[2]) == 0 and net.load_model(sys.argv[3]) == 0
+outs = [net.process_u8(synthetic_frame(h, w, seed=h + w), tile_size=t, border=10) for h, w, t in ((12, 20, 0), (37, 45, 0), (50, 70, 32))]
+np.savez(sys.argv[4], *outs)
+"""
+
+
+@pytest.mark.gpu
+def test_sums_done_in_the_convolution_epilogue_change_nothing(tmp_path):
+    """Valar's Eltwise / BinaryOp sums that follow a convolution are done while its result leaves the kernel
+    (GConvArgs::res); with UVA_GENERIC_FUSE_ADD=0 every sum is a launch of its own.  Same bytes, also with the reference
+    tiling and ragged tiles."""
+    import subprocess
+    import sys
+    from oracle import generic_oracle as go
+    b = str(tmp_path / "4x_Valar_v1.bin")
+    go.write_synthetic_bin(VALAR, b, seed=7, gain=0.5)
+    res = []
+    for v in ("1", "0"):
+        f = str(tmp_path / ("o%s.npz" % v))
+        subprocess.check_call([sys.executable, "-c", _FUSE_CHILD, ROOT, VALAR, b, f], env=dict(os.environ, UVA_GENERIC_FUSE_ADD=v))
+        res.append(np.load(f))
+    for k in res[0].files:
+        assert np.array_equal(res[0][k], res[1][k]), k
+        assert res[0][k].std() > 0
+
+
 @pytest.mark.gpu
 def test_compact_graphs_through_the_generic_executor(uva, oracle, oracle_models, monkeypatch):
     """Cross-check with REAL weights: the generic executor (UVA_GENERIC=1) on the 2x / 1x Compact graphs against

@@ -139,6 +139,7 @@ struct uva_net {
     _Float16* d_sink = nullptr;   // where out-of-image lanes of the trunk kernel store to
     bool attr_set[24] = {false};  // hipFuncAttributeMaxDynamicSharedMemorySize done for kernel slot k on this net's device
     int last_act_buf = 0;         // which ping-pong buffer the last run_graph() left its last trunk activation in
+    bool generic_fuse_add = true; // generic graphs: sums that follow a convolution are done in its epilogue (UVA_GENERIC_FUSE_ADD=0: own launch)
     bool generic_lds_conv = true; // generic graphs: 3x3 convolutions through g_conv3_lds (UVA_GENERIC_LDS=0: the plain g_conv<3>)
     bool fuse_all = true;         // 24-feature 1x net: all ten convolutions in one launch (sub10_kernel); UVA_SUB10=0 turns it off
     bool fuse_pairs = true;       // 64-feature nets: trunk layers run two per launch (trunk2_kernel); UVA_TRUNK_FUSION=0 turns it off
@@ -615,6 +616,7 @@ int ensure_device(uva_net* n)
     if (const char* e = std::getenv("UVA_TRUNK_FUSION")) n->fuse_pairs = std::atoi(e) != 0;
     if (const char* e = std::getenv("UVA_SUB10")) n->fuse_all = std::atoi(e) != 0;
     if (const char* e = std::getenv("UVA_GENERIC_LDS")) n->generic_lds_conv = std::atoi(e) != 0;
+    if (const char* e = std::getenv("UVA_GENERIC_FUSE_ADD")) n->generic_fuse_add = std::atoi(e) != 0;
     HIP_TRY(hipMalloc((void**)&n->d_sink, 64 * 128 + 256));
     if (n->generic) {
         // generic graph: every convolution's MFMA image ([tap][cin/32][cout/16][lane][8]) and padded bias
@@ -1103,18 +1105,50 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
         }
     } cleanup{n, &buf, &garr, &g, use_groups};
     const int T = 256;
-    for (const GLayer& gl : g.layers) {
-        if (gl.kind == GLayer::SPLIT) continue;
-        const GBlob& ob = g.blobs[gl.out[0]];
+    // Element-wise sums that directly follow a convolution of g_conv3_lds are done in its epilogue (GConvArgs::res): the
+    // convolution's own result never goes to memory, the sum layer is skipped.  Conditions: the convolution's result has
+    // no other reader, the other operand exists when the convolution runs, whole 16-byte channel units.
+    std::vector<int> fuse_add(g.layers.size(), -1), fuse_pos(g.layers.size(), 0);
+    std::vector<char> skip(g.layers.size(), 0);
+    if (n->generic_lds_conv && n->generic_fuse_add) {
+        std::vector<int> producer(g.blobs.size(), -1);
+        for (size_t li = 0; li < g.layers.size(); ++li)
+            if (g.layers[li].kind != GLayer::SPLIT && !g.layers[li].out.empty()) producer[g.layers[li].out[0]] = (int)li;
+        for (size_t ri = 0; ri < g.layers.size(); ++ri) {
+            const GLayer& r = g.layers[ri];
+            if ((r.kind != GLayer::ADD && r.kind != GLayer::ELTWISE_SUM) || r.in.size() != 2 || r.coeffs.size() != 2) continue;
+            for (int k = 0; k < 2 && !skip[ri]; ++k) {
+                const int cb = root(r.in[k]), ob2 = root(r.in[1 - k]);
+                const int li = producer[cb];
+                if (li < 0 || cb == ob2 || g.layers[li].kind != GLayer::CONV || fuse_add[li] >= 0) continue;
+                if (g.blobs[cb].consumers != 1 || g.blobs[cb].channels % 8 || group_of(cb) >= 0) continue;
+                if (!n->gd.convs[g.layers[li].conv].wpk_lds || producer[ob2] < 0 || producer[ob2] >= li) continue;
+                fuse_add[li] = (int)ri;
+                fuse_pos[li] = k;
+                skip[ri] = 1;
+            }
+        }
+    }
+    auto acquire_out = [&](const GLayer& ly, GBuf* out) -> int {
+        const GBlob& ob = g.blobs[ly.out[0]];
         GBuf o;
-        if (group_of(gl.out[0]) >= 0) {
+        if (group_of(ly.out[0]) >= 0) {
             GBuf& ga = garr[ob.group];
             if (!ga.p && generic_acquire(n, h * ob.scale, w * ob.scale, g.group_channels[ob.group], &ga)) return 1;
             o = ga;                                   // same geometry and pixel stride (cpad) ...
             o.p = ga.p + ob.group_off;                // ... starting at the blob's first channel
             o.c = ob.channels;
         } else if (generic_acquire(n, h * ob.scale, w * ob.scale, ob.channels, &o)) return 1;
-        buf[gl.out[0]] = o;
+        buf[ly.out[0]] = o;
+        *out = o;
+        return 0;
+    };
+    for (size_t layer_i = 0; layer_i < g.layers.size(); ++layer_i) {
+        const GLayer& gl = g.layers[layer_i];
+        if (gl.kind == GLayer::SPLIT || skip[layer_i]) continue;
+        const GLayer* const sum = fuse_add[layer_i] >= 0 ? &g.layers[fuse_add[layer_i]] : nullptr;
+        GBuf o;
+        if (acquire_out(sum ? *sum : gl, &o)) return 1;       // (a fused convolution writes the sum's array, it has none of its own)
         auto in = [&](int k) -> const GBuf& { return buf[root(gl.in[k])]; };
         switch (gl.kind) {
         case GLayer::INPUT:
@@ -1134,6 +1168,11 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
                 ga.out = o.p; ga.out_stride = o.cpad; ga.out_coff = 0; ga.cout = o.c;
                 ga.h = a.h; ga.w = a.w;
                 ga.has_act = gl.has_act ? 1 : 0; ga.slope = gl.act_slope;
+                if (sum) {
+                    const GBuf& other = buf[root(sum->in[1 - fuse_pos[layer_i]])];
+                    ga.res = other.p; ga.res_stride = other.cpad; ga.res_first = fuse_pos[layer_i] == 1;
+                    ga.ca = sum->coeffs[0]; ga.cb = sum->coeffs[1];
+                }
                 const int mbn = cd.cout_pad / 16;
                 // (UVA_GENERIC_WG=0: the 3x3 convolutions stage their weights through LDS again -- the A/B switch)
                 static const int wg_max = [] { const char* e = std::getenv("UVA_GENERIC_WG"); return e ? std::atoi(e) : 4; }();
@@ -1223,6 +1262,7 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
         }
         HIP_TRY(hipGetLastError());
         for (int b : gl.in) done_with(b);
+        if (sum) done_with(sum->in[1 - fuse_pos[layer_i]]);
     }
     const GBuf& res = buf[root(g.out_blob)];
     const int s = g.scale;

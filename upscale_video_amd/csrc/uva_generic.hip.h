@@ -127,6 +127,12 @@ struct GConvArgs {
     int h, w;
     int has_act;
     float slope;
+    // the element-wise sum that follows the convolution, done while its result leaves (the sum layer is then skipped):
+    // out = x * ca + y * cb with (x, y) = (result, res) or, res_first, (res, result) -- g_axpby's expression, its operand
+    // order and its rounding of the convolution's result to fp16 first: bit for bit what the two launches give
+    const _Float16* res;          // nullptr: no sum
+    int res_stride, res_first;
+    float ca, cb;
 };
 constexpr int GC_TH = 8, GC_TW = 32;
 constexpr int GC_CH = 1;          // input channels go through LDS 32 at a time (one k-step): 33 KB and 80-100 registers per
@@ -336,8 +342,19 @@ __global__ __launch_bounds__(64 * NW) void g_conv3_lds(GConvArgs a)
         for (int i = tid; i < TH * GC_TW * upp; i += NT) {
             const int px = i / upp, u = i - px * upp;
             const int y = y0 + px / GC_TW, x = x0 + px % GC_TW;
-            if (y < a.h && x < a.w)
-                *(uint4*)(a.out + ((size_t)(y + 1) * (a.w + 2) + (x + 1)) * a.out_stride + a.out_coff + 8 * u) = *(const uint4*)(stage + px * OUTB + 16 * u);
+            if (y < a.h && x < a.w) {
+                const size_t pos = (size_t)(y + 1) * (a.w + 2) + (x + 1);
+                uint4 v = *(const uint4*)(stage + px * OUTB + 16 * u);
+                if (a.res) {
+                    const half8 c = __builtin_bit_cast(half8, v), r = *(const half8*)(a.res + pos * a.res_stride + 8 * u);
+                    const half8 xx = a.res_first ? r : c, yy = a.res_first ? c : r;
+                    half8 o8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o8[e] = (_Float16)((float)xx[e] * a.ca + (float)yy[e] * a.cb);
+                    v = __builtin_bit_cast(uint4, o8);
+                }
+                *(uint4*)(a.out + pos * a.out_stride + a.out_coff + 8 * u) = v;
+            }
         }
     } else {
         for (int i = tid; i < TH * GC_TW * a.cout; i += NT) {
