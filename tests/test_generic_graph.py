@@ -61,8 +61,10 @@ def test_numpy_restatement_agrees_with_the_c_oracle_on_the_real_compact_weights(
 
 def test_executor_plan_for_valar_and_the_mini_graph(uva, mini):
     """The plan the executor derives from the graph alone (csrc/uva_generic.h plan_concat_groups): Valar's 23 RRDBs x 3
-    dense blocks become 69 chains of four Concats each -- three of them free, the first copying x only -- in arrays of
-    64 + 4 x 32 channels, and all but the 1x1 convolutions take the LDS-tiled kernel."""
+    dense blocks become 69 chains of four Concats each in arrays of 64 + 4 x 32 channels -- all free, the block's input x
+    being written into the array by the sum (or the convolution with the sum in its epilogue) that produces it; only the
+    very first block's x, which comes from the 3-channel head convolution, is copied -- and all but the 1x1 convolutions
+    take the LDS-tiled kernel."""
     import ctypes
     from upscale_video_amd import _lib
     L = _lib.load()
@@ -71,7 +73,7 @@ def test_executor_plan_for_valar_and_the_mini_graph(uva, mini):
     info = (ctypes.c_int * 8)()
     assert L.uva_net_debug_generic_plan(net._h, info) == 0, L.uva_last_error()
     groups, concats, free, first, lds_convs, widest = list(info)[:6]
-    assert (groups, concats, free, first, widest) == (69, 276, 207, 69, 192)
+    assert (groups, concats, free, first, widest) == (69, 276, 275, 1, 192)
     assert lds_convs == 420 - 69                         # the one 1x1 convolution of every dense block stays on the plain kernel
     p, b, _ = mini
     net2 = uva.Net()

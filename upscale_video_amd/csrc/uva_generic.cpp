@@ -259,6 +259,29 @@ void plan_concat_groups(GenericGraph& g)
             // a member feeds every Concat of the chain from its own on, once each
             ok = ok && in_chain == (int)chain.size() - (int)(k - 1);
         }
+        // The chain's first blob x (a dense block's input) joins too -- the first Concat then copies nothing -- if it is
+        // written by a sum or a convolution of g_conv3_lds and all its other readers take a channel range of a wider
+        // array: sums, and 3x3 / 1x1 convolutions of that kernel.
+        bool x_joins = ok;
+        if (x_joins) {
+            const int x = cur[0], pl = producer[x];
+            auto conv_any = [&](int li, int cin) {
+                const GLayer& gl = g.layers[li];
+                return gl.kind == GLayer::CONV && g.blobs[gl.out[0]].channels <= 64 && cin <= 192 && cin % 32 == 0;
+            };
+            x_joins = pl >= 0 && g.blobs[x].alias_of < 0 && g.blobs[x].group < 0 && x != g.out_blob;
+            if (x_joins) {
+                const GLayer& pr = g.layers[pl];
+                x_joins = pr.kind == GLayer::ADD || pr.kind == GLayer::ELTWISE_SUM || conv_any(pl, g.blobs[root(pr.in[0])].channels);
+            }
+            int in_chain = 0;
+            for (int r : readers[x]) {
+                const GLayer& rd = g.layers[r];
+                if (std::find(chain.begin(), chain.end(), r) != chain.end()) ++in_chain;
+                else x_joins = x_joins && (rd.kind == GLayer::ADD || rd.kind == GLayer::ELTWISE_SUM || conv_any(r, g.blobs[x].channels));
+            }
+            x_joins = x_joins && in_chain == (int)chain.size();
+        }
         for (size_t j = 0; j < chain.size() && ok; ++j) {
             const int o = g.layers[chain[j]].out[0];
             ok = g.blobs[o].alias_of < 0 && g.blobs[o].channels % 32 == 0 && g.blobs[o].channels <= 192 && o != g.out_blob;
@@ -268,6 +291,11 @@ void plan_concat_groups(GenericGraph& g)
         const int gid = (int)g.group_channels.size();
         g.group_channels.push_back(g.blobs[g.layers[chain.back()].out[0]].channels);
         int off = g.blobs[cur[0]].channels, count = 0;
+        if (x_joins) {
+            g.blobs[cur[0]].group = gid;
+            g.blobs[cur[0]].group_off = 0;
+            ++count;
+        }
         for (size_t k = 1; k < cur.size(); ++k) {
             g.blobs[cur[k]].group = gid;
             g.blobs[cur[k]].group_off = off;
@@ -276,7 +304,7 @@ void plan_concat_groups(GenericGraph& g)
         }
         for (size_t j = 0; j < chain.size(); ++j) {
             GLayer& c = g.layers[chain[j]];
-            c.concat_mode = j == 0 ? 1 : 2;
+            c.concat_mode = (j == 0 && !x_joins) ? 1 : 2;
             g.blobs[c.out[0]].group = gid;
             g.blobs[c.out[0]].group_off = 0;
             used[chain[j]] = 1;
