@@ -1,0 +1,43 @@
+import itertools
+# ds_read_b128 lane groups (16 lanes each)
+groups = [[0,1,2,3,12,13,14,15,20,21,22,23,24,25,26,27],
+          [4,5,6,7,8,9,10,11,16,17,18,19,28,29,30,31],
+          [32,33,34,35,44,45,46,47,52,53,54,55,56,57,58,59],
+          [36,37,38,39,40,41,42,43,48,49,50,51,60,61,62,63]]
+def ok(pixb_units, slot_fn, pixmap=lambda p: p, octmap=lambda o: o, nchunk_units=4):
+    # lane = (o<<4)|p reads pixel c0+pixmap(p), logical unit octmap(o); physical slot = slot_fn(col, unit)
+    for c0 in range(0, 64):
+        for g in groups:
+            banks = set()
+            for l in g:
+                o, p = l >> 4, l & 15
+                col = c0 + pixmap(p)
+                u = octmap(o)
+                a = col * pixb_units + slot_fn(col, u)
+                banks.add(a % 16)
+            if len(banks) != 16:
+                return False
+    return True
+# 64-byte pixels (4 units), XOR swizzle by table over (col>>2)&3, or col&3, etc.
+found = []
+for H in itertools.product(range(4), repeat=4):
+    for sh in (0, 1, 2):
+        f = lambda col, u, H=H, sh=sh: u ^ H[(col >> sh) & 3]
+        if ok(4, f): found.append(("xor", H, sh))
+print(found[:10], len(found))
+# general: slot = (u + H[...]) & 3
+found = []
+for H in itertools.product(range(4), repeat=4):
+    for sh in (0, 1, 2):
+        f = lambda col, u, H=H, sh=sh: (u + H[(col >> sh) & 3]) & 3
+        if ok(4, f): found.append(("add", H, sh))
+print(found[:10], len(found))
+# with the gpix permutation (even pixels in lanes {0-3,12-15}, odd in {4-11})
+gpix = lambda p: 2*p if p < 4 else (2*(p-8) if p >= 12 else 2*(p-4)+1)
+for name, om in (("id", lambda o:o), ("0213", lambda o:[0,2,1,3][o])):
+    found = []
+    for H in itertools.product(range(4), repeat=4):
+        for sh in (0, 1, 2, 3):
+            f = lambda col, u, H=H, sh=sh: u ^ H[(col >> sh) & 3]
+            if ok(4, f, gpix, om): found.append((H, sh))
+    print("gpix", name, found[:10], len(found))

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libuva.so")
 SOURCES = ["uva_api.hip", "uva_model.cpp", "uva_generic.cpp", "uva_pngread.cpp"]
-DEPS = SOURCES + ["uva_kernels.hip.h", "uva_generic.hip.h", "uva_generic.h", "uva_model.h", "uva_png.hip.h", "uva_denoise.hip.h", os.path.join("..", "..", "include", "uva.h")]
+DEPS = SOURCES + ["uva_kernels.hip.h", "uva_rdb.hip.h", "uva_generic.hip.h", "uva_generic.h", "uva_model.h", "uva_png.hip.h", "uva_denoise.hip.h", os.path.join("..", "..", "include", "uva.h")]
 
 
 def hipcc():

@@ -137,7 +137,7 @@ struct uva_net {
     float *d_fin = nullptr, *d_fout = nullptr;
     size_t d_fin_cap = 0, d_fout_cap = 0;
     _Float16* d_sink = nullptr;   // where out-of-image lanes of the trunk kernel store to
-    bool attr_set[24] = {false};  // hipFuncAttributeMaxDynamicSharedMemorySize done for kernel slot k on this net's device
+    bool attr_set[32] = {false};  // hipFuncAttributeMaxDynamicSharedMemorySize done for kernel slot k on this net's device
     int last_act_buf = 0;         // which ping-pong buffer the last run_graph() left its last trunk activation in
     bool generic_fuse_add = true; // generic graphs: sums that follow a convolution are done in its epilogue (UVA_GENERIC_FUSE_ADD=0: own launch)
     bool generic_lds_conv = true; // generic graphs: 3x3 convolutions through g_conv3_lds (UVA_GENERIC_LDS=0: the plain g_conv<3>)
@@ -1160,6 +1160,49 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
             const GBuf& a = in(0);
             if ((group_of(gl.out[0]) >= 0 || group_of(root(gl.in[0])) >= 0) && !cd.wpk_lds)
                 return fail("generic executor: a dense-chain convolution without the LDS kernel (plan_concat_groups and ensure_device disagree)");
+            // 3x3 convolutions with 64 output channels from 64 or 192 input channels: weights stationary in registers
+            // (g_conv3_sw, uva_rdb.hip.h).  UVA_GENERIC_SW=0: the layer-by-layer kernel below (the A/B switch).
+            static const bool sw_on = [] { const char* e = std::getenv("UVA_GENERIC_SW"); return !e || std::atoi(e) != 0; }();
+            if (sw_on && n->generic_lds_conv && gl.ksize == 3 && cd.cout_pad == 64 && o.c == 64 && (cd.cin_pad == 64 || cd.cin_pad == 192)) {
+                const int cols = cd.cin_pad == 192 ? sw_cols<1>() : sw_cols<2>();
+                if (a.w + 2 >= cols + 2) {
+                    GenericDevice::SwPlan& plan = n->gd.sw_plans[std::make_tuple(a.h, a.w, cols)];
+                    if (!plan.segs) {
+                        std::vector<GSwSeg> segs;
+                        std::vector<int> sbeg;
+                        plan.grid = std::max(8, (n->ncu / 8) * 8);
+                        sw_segments(a.h, a.w, cols, plan.grid, segs, sbeg);
+                        if (upload(&plan.segs, segs.data(), segs.size() * sizeof(GSwSeg), n->stream)) return 1;
+                        if (upload(&plan.seg_begin, sbeg.data(), sbeg.size() * sizeof(int), n->stream)) return 1;
+                        HIP_TRY(hipStreamSynchronize(n->stream));       // (the vectors go away)
+                    }
+                    GSwArgs sa;
+                    std::memset(&sa, 0, sizeof sa);
+                    sa.in = a.p; sa.in_stride = a.cpad; sa.wpk = cd.wpk; sa.bias = cd.bias;
+                    sa.out = o.p; sa.out_stride = o.cpad; sa.out_coff = 0;
+                    sa.h = a.h; sa.w = a.w;
+                    sa.slope = gl.act_slope;
+                    if (sum) {
+                        const GBuf& other = buf[root(sum->in[1 - fuse_pos[layer_i]])];
+                        sa.res = other.p; sa.res_stride = other.cpad; sa.res_first = fuse_pos[layer_i] == 1;
+                        sa.ca = sum->coeffs[0]; sa.cb = sum->coeffs[1];
+                    }
+                    sa.segs = plan.segs; sa.seg_begin = plan.seg_begin; sa.sink = n->d_sink;
+                    auto launch_sw = [&](auto kern, int slot, size_t lds) -> int {
+                        if (!n->attr_set[slot]) {
+                            HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                            n->attr_set[slot] = true;
+                        }
+                        hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(256), lds, n->stream, sa);
+                        return 0;
+                    };
+                    if (cd.cin_pad == 192 && gl.has_act) { if (launch_sw(g_conv3_sw<6, 1, true>, 24, sw_lds_bytes<6, 1>())) return 1; }
+                    else if (cd.cin_pad == 192) { if (launch_sw(g_conv3_sw<6, 1, false>, 25, sw_lds_bytes<6, 1>())) return 1; }
+                    else if (gl.has_act) { if (launch_sw(g_conv3_sw<2, 2, true>, 26, sw_lds_bytes<2, 2>())) return 1; }
+                    else { if (launch_sw(g_conv3_sw<2, 2, false>, 27, sw_lds_bytes<2, 2>())) return 1; }
+                    break;
+                }
+            }
             if (cd.wpk_lds && n->generic_lds_conv) {
                 GConvArgs ga;
                 std::memset(&ga, 0, sizeof ga);

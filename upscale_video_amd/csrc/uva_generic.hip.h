@@ -15,6 +15,7 @@
 
 #include "uva_generic.h"
 #include "uva_kernels.hip.h"
+#include "uva_rdb.hip.h"
 
 namespace uva {
 
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(64 * NW) void g_conv3_lds(GConvArgs a)
                     const half8 xx = a.res_first ? r : c, yy = a.res_first ? c : r;
                     half8 o8;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o8[e] = (_Float16)((float)xx[e] * a.ca + (float)yy[e] * a.cb);
+                    for (int e = 0; e < 8; ++e) o8[e] = g_axpby1((float)xx[e], a.ca, (float)yy[e], a.cb);
                     v = __builtin_bit_cast(uint4, o8);
                 }
                 *(uint4*)(a.out + pos * a.out_stride + a.out_coff + 8 * u) = v;
@@ -374,7 +375,7 @@ __global__ void g_axpby(const half8* a, float ca, const half8* b, float cb, half
     const half8 x = a[i], y = b[i];
     half8 r;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) r[e] = (_Float16)((float)x[e] * ca + (float)y[e] * cb);
+    for (int e = 0; e < 8; ++e) r[e] = g_axpby1((float)x[e], ca, (float)y[e], cb);
     out[i] = r;
 }
 
@@ -390,7 +391,7 @@ __global__ void g_axpby_strided(const _Float16* a, int sa, float ca, const _Floa
     const half8 x = *(const half8*)(a + pix * sa + 8 * k), y = *(const half8*)(b + pix * sb + 8 * k);
     half8 r;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) r[e] = (_Float16)((float)x[e] * ca + (float)y[e] * cb);
+    for (int e = 0; e < 8; ++e) r[e] = g_axpby1((float)x[e], ca, (float)y[e], cb);
     *(half8*)(out + pix * so + 8 * k) = r;
 }
 
@@ -465,6 +466,28 @@ __global__ void g_output_f32(const _Float16* in, int ho, int wo, int cpad, float
     for (int c = 0; c < 3; ++c) dst[((size_t)c * ho + Y) * wo + X] = (float)s[c];
 }
 
+// g_conv3_sw's work list: the plane is cut into strips of `cols` columns, a strip into blocks of SW_R rows; the blocks,
+// strip after strip and top to bottom, are dealt out to `grid` workgroups in contiguous runs of equal length (+-1); a
+// run that crosses a strip's end becomes two segments.  seg_begin has grid + 1 entries.
+inline void sw_segments(int h, int w, int cols, int grid, std::vector<GSwSeg>& segs, std::vector<int>& seg_begin)
+{
+    const int ns = (w + cols - 1) / cols, nb = (h + SW_R - 1) / SW_R;
+    const long long total = (long long)ns * nb;
+    segs.clear();
+    seg_begin.assign(1, 0);
+    for (int g = 0; g < grid; ++g) {
+        long long u = total * g / grid;
+        const long long u1 = total * (g + 1) / grid;
+        while (u < u1) {
+            const int s = (int)(u / nb), b0 = (int)(u - (long long)s * nb);
+            const int b1 = (int)std::min<long long>(nb, b0 + (u1 - u));
+            segs.push_back(GSwSeg{s * cols, b0 * SW_R, std::min(h, b1 * SW_R), 0});
+            u += b1 - b0;
+        }
+        seg_begin.push_back((int)segs.size());
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 struct GenericDevice {
     struct ConvDev {
@@ -477,6 +500,9 @@ struct GenericDevice {
     std::vector<float*> prelu;
     std::map<std::tuple<int, int, int>, std::vector<_Float16*>> pool;     // (h, w, channels) -> free zero-bordered arrays
     size_t pool_bytes = 0;
+    // g_conv3_sw: the strip segments of an h x w plane, dealt out to `grid` workgroups (sw_segments)
+    struct SwPlan { GSwSeg* segs = nullptr; int* seg_begin = nullptr; int grid = 0; };
+    std::map<std::tuple<int, int, int>, SwPlan> sw_plans;                 // (h, w, strip columns)
 
     static int pad32(int c) { return (c + 31) / 32 * 32; }
 
@@ -495,6 +521,11 @@ struct GenericDevice {
             for (auto p : kv.second) (void)hipFree(p);
         pool.clear();
         pool_bytes = 0;
+        for (auto& kv : sw_plans) {
+            if (kv.second.segs) (void)hipFree(kv.second.segs);
+            if (kv.second.seg_begin) (void)hipFree(kv.second.seg_begin);
+        }
+        sw_plans.clear();
     }
 };
 
