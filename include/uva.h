@@ -206,7 +206,8 @@ int uva_debug_trunk2_schedule(int h, int w, int tile_size, int border, int grid,
 
 /* Test hook (host only, after load_param of a generic graph such as 4x_Valar_v1): what the executor planned --
  * info[0] dense chains sharing one array, [1] Concat layers, [2] of them free (every input already in place), [3] copying
- * their first input only, [4] 3x3 convolutions that take the LDS-tiled kernel, [5] channels of the widest shared array. */
+ * their first input only, [4] 3x3 convolutions that take the LDS-tiled kernel, [5] channels of the widest shared array, [6] residual dense blocks
+ * whose first four convolutions run as one launch (rdb4_kernel).  info: at least 8 ints. */
 int uva_net_debug_generic_plan(const uva_net* net, int* info);
 
 /* Test hook (host only): the row lists sub10_kernel (the whole 24-feature 1x net, one launch) walks for an h x w

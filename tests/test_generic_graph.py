@@ -185,6 +185,38 @@ def test_valar_graph_with_synthetic_weights(uva, oracle, tmp_path):
     assert np.array_equal(up.net.process_u8(img, tile_size=960, border=10), u8)
 
 
+@pytest.mark.gpu
+def test_valar_graph_multi_tile_frame_against_the_restatement(uva, oracle, tmp_path):
+    """The as-named graph at the bar of the mini graph: all 1206 layers on a frame that takes the reference's tile loop
+    (32-pixel tiles, 10-pixel borders: nine planes, 42..52 pixels wide -- rdb4_kernel for the dense blocks' first four
+    convolutions, g_conv3_sw for the 192 -> 64 and 64 -> 64 ones) and on one 75-pixel-wide plane through the float route,
+    synthetic weights, against the numpy restatement in fp16-storage mode: f32 within 4e-3 of max|out|, u8 within 2 LSB."""
+    from oracle import generic_oracle as go
+    from upscale_video_amd import upscale_processing as up
+    b = str(tmp_path / "4x_Valar_v1.bin")
+    go.write_synthetic_bin(VALAR, b, seed=11, gain=0.5)
+    om = go.Model(VALAR, b)
+    net = uva.Net()
+    net.set_vulkan_device(0)
+    assert net.load_param(VALAR) == 0 and net.load_model(b) == 0, getattr(net, "last_error", "")
+    x = oracle.from_pixels_normalize(oracle.synthetic_frame(34, 75, seed=21))
+    got = net._extract(x)
+    want = om.forward(x, f16_storage=True)
+    ok, info = _close(got, want, 4e-3)
+    assert ok, info
+    h, w, ts = 70, 75, 32
+    img = oracle.synthetic_frame(h, w, seed=9)
+    u8 = net.process_u8(img, tile_size=ts, border=10)
+    ref = np.zeros((4 * h, 4 * w, 3), np.uint8)
+    for ty in range(-(-h // ts)):
+        for tx in range(-(-w // ts)):
+            (y0, y1, x0, x1), (top, bottom, left, right) = up.tile_window(ts, ty, tx, h, w)
+            tile = om.apply_u8(np.ascontiguousarray(img[y0 - top:y1 + bottom, x0 - left:x1 + right]), f16_storage=True)
+            ref[4 * y0:4 * y1, 4 * x0:4 * x1] = tile[4 * top:4 * (top + y1 - y0), 4 * left:4 * (left + x1 - x0)]
+    d = np.abs(u8.astype(int) - ref.astype(int))
+    assert d.max() <= 2 and (d > 0).mean() < 0.1, (int(d.max()), float((d > 0).mean()))
+
+
 _FUSE_CHILD = r"""
 import os, sys
 sys.path.insert(0, sys.argv[1])

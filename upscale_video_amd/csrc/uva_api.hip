@@ -642,6 +642,7 @@ int ensure_device(uva_net* n)
             if (upload(&cd.bias, b.data(), b.size() * 4, n->stream)) return 1;
             HIP_TRY(hipStreamSynchronize(n->stream));
         }
+        n->gd.rdbs = find_rdbs(gg);
         n->gd.prelu.assign(gg.prelu.size(), nullptr);
         for (size_t i = 0; i < gg.prelu.size(); ++i) {
             if (upload(&n->gd.prelu[i], gg.prelu[i].data(), gg.prelu[i].size() * 4, n->stream)) return 1;
@@ -1129,6 +1130,22 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
             }
         }
     }
+    // residual dense blocks whose first four convolutions run as one rdb4_kernel launch at the first one (UVA_GENERIC_RDB=0:
+    // layer by layer, the A/B switch): the other six layers are bookkeeping only, and none of their sums is fused elsewhere
+    static const bool rdb_on = [] { const char* e = std::getenv("UVA_GENERIC_RDB"); return !e || std::atoi(e) != 0; }();
+    std::vector<int> rdb_at(g.layers.size(), -1);
+    std::vector<char> rdb_skip(g.layers.size(), 0);
+    if (rdb_on && use_groups && w >= 16) {
+        for (size_t k = 0; k < n->gd.rdbs.size(); ++k) {
+            const RdbMatch& m = n->gd.rdbs[k];
+            rdb_at[m.c1] = (int)k;
+            for (int li : {m.c2, m.c2s, m.add2, m.c3, m.c4, m.add4}) {
+                rdb_skip[li] = 1;
+                skip[li] = 0;
+                fuse_add[li] = -1;
+            }
+        }
+    }
     auto acquire_out = [&](const GLayer& ly, GBuf* out) -> int {
         const GBlob& ob = g.blobs[ly.out[0]];
         GBuf o;
@@ -1146,6 +1163,12 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
     for (size_t layer_i = 0; layer_i < g.layers.size(); ++layer_i) {
         const GLayer& gl = g.layers[layer_i];
         if (gl.kind == GLayer::SPLIT || skip[layer_i]) continue;
+        if (rdb_skip[layer_i]) {          // done by the rdb4 launch at the block's first convolution: buffers and counts only
+            GBuf o;
+            if (group_of(gl.out[0]) >= 0 && acquire_out(gl, &o)) return 1;
+            for (int b : gl.in) done_with(b);
+            continue;
+        }
         const GLayer* const sum = fuse_add[layer_i] >= 0 ? &g.layers[fuse_add[layer_i]] : nullptr;
         GBuf o;
         if (acquire_out(sum ? *sum : gl, &o)) return 1;       // (a fused convolution writes the sum's array, it has none of its own)
@@ -1160,6 +1183,35 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
             const GBuf& a = in(0);
             if ((group_of(gl.out[0]) >= 0 || group_of(root(gl.in[0])) >= 0) && !cd.wpk_lds)
                 return fail("generic executor: a dense-chain convolution without the LDS kernel (plan_concat_groups and ensure_device disagree)");
+            if (rdb_at[layer_i] >= 0) {
+                const RdbMatch& m = n->gd.rdbs[rdb_at[layer_i]];
+                const GBuf& arr = garr[m.group];
+                GenericDevice::RdbPlan& plan = n->gd.rdb_plans[std::make_pair(a.h, a.w)];
+                if (!plan.segs) {
+                    std::vector<RdbSeg> segs;
+                    std::vector<int> sbeg;
+                    plan.grid = std::max(8, (n->ncu / 8) * 8);
+                    rdb_segments(a.h, a.w, plan.grid, segs, sbeg);
+                    if (upload(&plan.segs, segs.data(), segs.size() * sizeof(RdbSeg), n->stream)) return 1;
+                    if (upload(&plan.seg_begin, sbeg.data(), sbeg.size() * sizeof(int), n->stream)) return 1;
+                    HIP_TRY(hipStreamSynchronize(n->stream));
+                }
+                auto cdev = [&](int li) -> const GenericDevice::ConvDev& { return n->gd.convs[g.layers[li].conv]; };
+                RdbArgs ra;
+                std::memset(&ra, 0, sizeof ra);
+                ra.arr = arr.p; ra.stride = arr.cpad;
+                ra.w1 = cdev(m.c1).wpk; ra.w2 = cdev(m.c2).wpk; ra.w2s = cdev(m.c2s).wpk; ra.w3 = cdev(m.c3).wpk; ra.w4 = cdev(m.c4).wpk;
+                ra.b1 = cdev(m.c1).bias; ra.b2 = cdev(m.c2).bias; ra.b3 = cdev(m.c3).bias; ra.b4 = cdev(m.c4).bias;
+                ra.slope = m.slope;
+                ra.h = a.h; ra.w = a.w;
+                ra.segs = plan.segs; ra.seg_begin = plan.seg_begin; ra.sink = n->d_sink;
+                if (!n->attr_set[28]) {
+                    HIP_TRY(hipFuncSetAttribute((const void*)rdb4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    n->attr_set[28] = true;
+                }
+                hipLaunchKernelGGL(rdb4_kernel, dim3(plan.grid), dim3(256), rdb4_lds_bytes(), n->stream, ra);
+                break;
+            }
             // 3x3 convolutions with 64 output channels from 64 or 192 input channels: weights stationary in registers
             // (g_conv3_sw, uva_rdb.hip.h).  UVA_GENERIC_SW=0: the layer-by-layer kernel below (the A/B switch).
             static const bool sw_on = [] { const char* e = std::getenv("UVA_GENERIC_SW"); return !e || std::atoi(e) != 0; }();
@@ -1751,6 +1803,7 @@ int uva_net_debug_generic_plan(const uva_net* n, int* info)
     info[4] = lds;
     info[5] = 0;
     for (int c : g.group_channels) info[5] = std::max(info[5], c);
+    info[6] = (int)find_rdbs(g).size();
     return 0;
 }
 

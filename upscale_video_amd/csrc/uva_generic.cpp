@@ -314,6 +314,71 @@ void plan_concat_groups(GenericGraph& g)
     }
 }
 
+std::vector<RdbMatch> find_rdbs(const GenericGraph& g)
+{
+    std::vector<RdbMatch> out;
+    const int nb = (int)g.blobs.size(), nl = (int)g.layers.size();
+    auto root = [&](int b) { while (g.blobs[b].alias_of >= 0) b = g.blobs[b].alias_of; return b; };
+    std::vector<int> producer(nb, -1);
+    for (int li = 0; li < nl; ++li)
+        if (g.layers[li].kind != GLayer::SPLIT)
+            for (int b : g.layers[li].out) producer[b] = li;
+    for (int gi = 0; gi < (int)g.group_channels.size(); ++gi) {
+        if (g.group_channels[gi] != 192) continue;
+        // the chain's members by channel offset (Concat outputs sit at offset 0 with more than 64 channels)
+        int x = -1, xk[4] = {-1, -1, -1, -1}, cat[5] = {-1, -1, -1, -1, -1};      // cat[k]: the Concat blob with 64 + 32k channels
+        for (int b = 0; b < nb; ++b) {
+            const GBlob& bl = g.blobs[b];
+            if (bl.group != gi || bl.alias_of >= 0) continue;
+            if (bl.group_off == 0 && bl.channels == 64) x = b;
+            else if (bl.group_off == 0 && bl.channels > 64 && (bl.channels - 64) % 32 == 0 && bl.channels <= 192) cat[(bl.channels - 64) / 32] = b;
+            else if (bl.channels == 32 && bl.group_off >= 64 && (bl.group_off - 64) % 32 == 0) xk[(bl.group_off - 64) / 32] = b;
+        }
+        if (x < 0 || xk[0] < 0 || xk[1] < 0 || xk[2] < 0 || xk[3] < 0 || cat[1] < 0 || cat[2] < 0 || cat[3] < 0) continue;
+        RdbMatch m;
+        m.group = gi;
+        auto conv3_of = [&](int li, int in_blob, float* slope) {      // a 3x3 convolution with bias and LeakyReLU reading in_blob, 32 outputs
+            if (li < 0) return false;
+            const GLayer& l = g.layers[li];
+            if (l.kind != GLayer::CONV || l.ksize != 3 || !l.has_bias || !l.has_act || root(l.in[0]) != in_blob) return false;
+            if (g.convs[l.conv].cout != 32) return false;
+            *slope = l.act_slope;
+            return true;
+        };
+        float s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+        m.c1 = producer[xk[0]];
+        if (!conv3_of(m.c1, x, &s1)) continue;
+        m.add2 = producer[xk[1]];
+        m.c3 = producer[xk[2]];
+        m.add4 = producer[xk[3]];
+        if (m.add2 < 0 || m.add4 < 0 || !conv3_of(m.c3, cat[2], &s3)) continue;
+        const GLayer& a2 = g.layers[m.add2];
+        const GLayer& a4 = g.layers[m.add4];
+        auto plain_add = [](const GLayer& l) {
+            return (l.kind == GLayer::ADD || l.kind == GLayer::ELTWISE_SUM) && l.in.size() == 2 && l.coeffs.size() == 2 && l.coeffs[0] == 1.f && l.coeffs[1] == 1.f;
+        };
+        if (!plain_add(a2) || !plain_add(a4)) continue;
+        // x2 = conv3(cat(x, x1)) [first operand] + conv1(x) [second]; x4 = conv3(cat(x..x3)) + x2
+        const int pa = root(a2.in[0]), pb = root(a2.in[1]), pc = root(a4.in[0]);
+        if (g.blobs[pa].consumers != 1 || g.blobs[pb].consumers != 1 || g.blobs[pc].consumers != 1 || root(a4.in[1]) != xk[1]) continue;
+        if (g.blobs[pa].group >= 0 || g.blobs[pb].group >= 0 || g.blobs[pc].group >= 0) continue;
+        m.c2 = producer[pa];
+        m.c2s = producer[pb];
+        m.c4 = producer[pc];
+        if (!conv3_of(m.c2, cat[1], &s2) || !conv3_of(m.c4, cat[3], &s4)) continue;
+        if (m.c2s < 0) continue;
+        const GLayer& ls = g.layers[m.c2s];
+        if (ls.kind != GLayer::CONV || ls.ksize != 1 || ls.has_bias || ls.has_act || root(ls.in[0]) != x || g.convs[ls.conv].cout != 32) continue;
+        if (s1 != s2 || s1 != s3 || s1 != s4) continue;
+        // program order: everything the launch at c1 replaces comes after it, and x is written before it
+        if (!(m.c1 < m.c2 && m.c1 < m.c2s && m.c2 < m.add2 && m.c2s < m.add2 && m.add2 < m.c3 && m.c3 < m.c4 && m.c4 < m.add4)) continue;
+        if (producer[x] < 0 || producer[x] >= m.c1) continue;
+        m.slope = s1;
+        out.push_back(m);
+    }
+    return out;
+}
+
 bool load_bin_generic(const std::string& path, GenericGraph& g, std::string& err)
 {
     if (!g.param_loaded) return gfail(err, "load_model: load_param first");

@@ -71,6 +71,17 @@ struct GenericGraph {
 // GBlob::group / group_off, GenericGraph::group_*.  Pure analysis: the executor may ignore it.
 void plan_concat_groups(GenericGraph& g);
 
+// A residual dense block whose first four convolutions rdb4_kernel (csrc/uva_rdb.hip.h) runs in one launch:
+//   x1 = lrelu(conv3(x)), x2 = lrelu(conv3(x,x1)) + conv1(x), x3 = lrelu(conv3(x,x1,x2)), x4 = lrelu(conv3(x,x1,x2,x3)) + x2
+// (models/4x_Valar_v1.param:6-19), all five blobs members of one dense chain's 192-channel array (plan_concat_groups)
+// with x already in it.  Layer indices; `skip` = the layers the launch at c1 replaces.
+struct RdbMatch {
+    int group = -1;
+    int c1 = -1, c2 = -1, c2s = -1, add2 = -1, c3 = -1, c4 = -1, add4 = -1;
+    float slope = 0.f;
+};
+std::vector<RdbMatch> find_rdbs(const GenericGraph& g);
+
 bool parse_param_generic(const std::string& path, GenericGraph& g, std::string& err);
 bool load_bin_generic(const std::string& path, GenericGraph& g, std::string& err);
 

@@ -488,6 +488,39 @@ inline void sw_segments(int h, int w, int cols, int grid, std::vector<GSwSeg>& s
     }
 }
 
+// rdb4_kernel's work list: strips of 48 computed columns that own 42 of them (45 at the plane's left edge, everything up
+// to the right edge in the last one), cut into row segments; the rows, strip after strip, are dealt out to `grid`
+// workgroups in contiguous runs of equal length (every segment costs RA_LAG extra steps, so runs are not cut finer).
+inline void rdb_segments(int h, int w, int grid, std::vector<RdbSeg>& segs, std::vector<int>& seg_begin)
+{
+    std::vector<RdbSeg> strips;
+    for (int own0 = 0; own0 < w;) {
+        RdbSeg s{};
+        s.c0 = own0 == 0 ? 0 : own0 - 3;
+        s.own0 = own0;
+        s.own1 = s.c0 + RA_C >= w ? w : s.c0 + RA_C - 3;
+        strips.push_back(s);
+        own0 = s.own1;
+    }
+    const long long total = (long long)strips.size() * h;
+    segs.clear();
+    seg_begin.assign(1, 0);
+    for (int g = 0; g < grid; ++g) {
+        long long u = total * g / grid;
+        const long long u1 = total * (g + 1) / grid;
+        while (u < u1) {
+            const int s = (int)(u / h), y0 = (int)(u - (long long)s * h);
+            const int y1 = (int)std::min<long long>(h, y0 + (u1 - u));
+            RdbSeg sg = strips[s];
+            sg.yb = y0;
+            sg.ye = y1;
+            segs.push_back(sg);
+            u += y1 - y0;
+        }
+        seg_begin.push_back((int)segs.size());
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 struct GenericDevice {
     struct ConvDev {
@@ -503,6 +536,9 @@ struct GenericDevice {
     // g_conv3_sw: the strip segments of an h x w plane, dealt out to `grid` workgroups (sw_segments)
     struct SwPlan { GSwSeg* segs = nullptr; int* seg_begin = nullptr; int grid = 0; };
     std::map<std::tuple<int, int, int>, SwPlan> sw_plans;                 // (h, w, strip columns)
+    struct RdbPlan { RdbSeg* segs = nullptr; int* seg_begin = nullptr; int grid = 0; };
+    std::map<std::pair<int, int>, RdbPlan> rdb_plans;                     // (h, w)
+    std::vector<RdbMatch> rdbs;                                           // find_rdbs() of the loaded graph
 
     static int pad32(int c) { return (c + 31) / 32 * 32; }
 
@@ -526,6 +562,11 @@ struct GenericDevice {
             if (kv.second.seg_begin) (void)hipFree(kv.second.seg_begin);
         }
         sw_plans.clear();
+        for (auto& kv : rdb_plans) {
+            if (kv.second.segs) (void)hipFree(kv.second.segs);
+            if (kv.second.seg_begin) (void)hipFree(kv.second.seg_begin);
+        }
+        rdb_plans.clear();
     }
 };
 

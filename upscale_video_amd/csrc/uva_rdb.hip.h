@@ -32,6 +32,9 @@
 #ifndef UVA_SW_DBG
 #define UVA_SW_DBG 0
 #endif
+#ifndef UVA_RA_DBG
+#define UVA_RA_DBG 0       // timing experiments only (results are wrong): 1 no HBM stores, 2 no epilogue, 4 no x DMA, 8 no hand-over
+#endif
 
 namespace uva {
 
@@ -191,6 +194,7 @@ __global__ __launch_bounds__(256, 1) void g_conv3_sw(GSwArgs a)
                 for (int f = 0; f < NF; ++f) dst[f] = *(const half8*)(ring + rowb[ir] + offdx[dx] + c * (RC * 64) + f * 1024);
             };
             constexpr int NSTEP = KC * 3 * NIR;
+            __builtin_amdgcn_sched_barrier(0);                       // nothing else's LDS reads count as the pipeline's
 #pragma unroll
             for (int i = 0; i < D; ++i) rd(i, bq[i]);
             __builtin_amdgcn_sched_group_barrier(0x100, D * NF, 0);  // (the pipeline below counts its own reads only)
@@ -212,6 +216,7 @@ __global__ __launch_bounds__(256, 1) void g_conv3_sw(GSwArgs a)
                 if constexpr (idx + D < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, NF, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, ndy * NF * MBW, 0);
             });
+            __builtin_amdgcn_sched_barrier(0);
             // (4) LeakyReLU (ncnn activation_type 2), fp16, the fused sum, 8-byte stores: lane (o, p) holds channels
             // 16(mb0 + m) + 4o .. +3 of pixel (y0 + 4b + r, c0 + cw + 16f + p)
 #pragma unroll
@@ -243,6 +248,379 @@ __global__ __launch_bounds__(256, 1) void g_conv3_sw(GSwArgs a)
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(UVA_SW_DBG >= 1 ? 0 : NST) : "memory");
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// rdb4_kernel: the first FOUR convolutions of a residual dense block (models/4x_Valar_v1.param:6-19),
+//     x1 = lrelu(conv3(x))            x2 = lrelu(conv3(x,x1)) + conv1(x)
+//     x3 = lrelu(conv3(x,x1,x2))      x4 = lrelu(conv3(x,x1,x2,x3)) + x2
+// in ONE launch: x (64 channels) is read from the block's shared 192-channel array once, x1..x4 (32 channels each) are
+// written into their channel ranges of the same array once -- the growing prefix never goes back to HBM between the
+// convolutions (the layer-by-layer executor reads 64 + 96 + 128 + 160 channels plus halos for them).  The block's last
+// convolution (192 -> 64) follows as g_conv3_sw<6, 1>.
+//
+// One persistent 4-wave workgroup per CU walks down a strip of 48 computed columns, one row per step, one workgroup
+// barrier per step; x and the results live in row rings in LDS (64-byte chunk pixels, the XOR swizzle of g_conv3_sw).
+// The four convolutions are 18 + 29 + 36 + 45 = 128 k-steps (32 input channels x one tap x 32 output channels) per row:
+// 32 per wave, their weights (256 registers) stationary, every B fragment feeding two MFMAs.  A convolution that is
+// split between two waves hands its partial sums over through LDS (fp32, one step later); a wave's own parts run in
+// program order, so a stage may read the row its predecessor has just written:
+//
+//     wave 0   conv1 (18)         row s     -> x1 ring, HBM      | conv2 k-steps  0..13 (x only)     row s-1 -> P2
+//     wave 1   conv2 14..26 + 1x1 row s-2   -> x2 ring, HBM      | conv3 k-steps  0..16 (x only)     row s-3 -> P3
+//     wave 2   conv3 17..35       row s-4   -> x3 ring, HBM      | conv4 k-steps  0..12 (x only)     row s-5 -> P4
+//     wave 3   conv4 13..44 + x2  row s-6   -> HBM               | the LDS-DMA of x row s+2
+//
+// Ring depths follow: x 10 rows (s-7 .. s+2), x1 8, x2 6, x3 4; 121.6 KB + 36 KB of hand-over buffers.  What a strip
+// computes correctly shrinks by one column per side and convolution (x1 on 48 columns, x4 on 42); pixels outside the plane
+// are written as zero (the next convolution's padding), rows above a segment's first output row are recomputed (3 of x1, 2
+// of x2, 1 of x3).  Rounding points are the layer-by-layer executor's: every convolution result -> fp16, the two sums as
+// g_axpby1 of fp16 operands.
+struct RdbSeg { int c0, yb, ye, own0, own1, pad0, pad1, pad2; };   // computed columns [c0, c0+48); output rows [yb, ye), columns [own0, own1)
+
+struct RdbArgs {
+    _Float16* arr;                // the dense chain's array [(h+3)][(w+2)][stride]: channels 0..63 = x (read), 64..191 = x1..x4 (written)
+    int stride;
+    const half8* w1;              // pack_generic images (natural order), cout_pad 32: [tap][cin/32][2][64][8]
+    const half8* w2;
+    const half8* w2s;             // the 1x1 convolution 64 -> 32 behind x2 (no bias)
+    const half8* w3;
+    const half8* w4;
+    const float* b1;
+    const float* b2;
+    const float* b3;
+    const float* b4;
+    float slope;
+    int h, w;
+    const RdbSeg* segs;
+    const int* seg_begin;
+    _Float16* sink;
+};
+
+constexpr int RA_C = 48, RA_RC = 50, RA_NF = 3;
+constexpr int RA_CHB = RA_RC * 64;                                   // one chunk row: 3200 bytes
+constexpr int RA_XS = 10, RA_1S = 8, RA_2S = 6, RA_3S = 4;           // ring rows
+constexpr int RA_X_OFF = 0, RA_X1_OFF = RA_X_OFF + RA_XS * 2 * RA_CHB, RA_X2_OFF = RA_X1_OFF + RA_1S * RA_CHB,
+              RA_X3_OFF = RA_X2_OFF + RA_2S * RA_CHB, RA_P_OFF = RA_X3_OFF + RA_3S * RA_CHB;
+constexpr int RA_PB = RA_NF * 2 * 1024;                              // one hand-over buffer: 6 accumulator tiles
+constexpr int RA_PRM_OFF = RA_P_OFF + 3 * 2 * RA_PB;
+constexpr int rdb4_lds_bytes() { return RA_PRM_OFF + 4 * 32 * 4; }
+static_assert(rdb4_lds_bytes() <= 160 * 1024, "rdb4 kernel LDS budget");
+constexpr int RA_LAG = 9;                                            // steps of a segment beyond its output rows
+constexpr int RA_NDMA = (2 * RA_RC * 4 + 63) / 64;                   // LDS-DMA pieces of an x row (the last one 16 lanes)
+
+__global__ __launch_bounds__(256, 1) void rdb4_kernel(RdbArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int o = lane >> 4, p = lane & 15;
+    float* const prm = (float*)(smem + RA_PRM_OFF);
+    for (int i = threadIdx.x; i < RA_PRM_OFF / 16; i += 256) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x < 128) {
+        const int k = threadIdx.x >> 5, c = threadIdx.x & 31;
+        prm[threadIdx.x] = (k == 0 ? a.b1 : k == 1 ? a.b2 : k == 2 ? a.b3 : a.b4)[c];
+    }
+    // per-lane LDS offsets: B fragments (three tap columns) and this lane's 8 bytes of a result pixel (channel block m)
+    unsigned offdx[3], wroff[2];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        const int rc = p + dx;
+        offdx[dx] = (unsigned)(rc * 64 + ((o ^ (((rc >> 2) & 1) << 1)) * 16));
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int rc = p + 1, u = 2 * m + (o >> 1);
+        wroff[m] = (unsigned)(rc * 64 + ((u ^ (((rc >> 2) & 1) << 1)) * 16) + (o & 1) * 8);
+    }
+    const unsigned smem_lds = lds_offset(smem);
+    const size_t pitch = (size_t)(a.w + 2) * a.stride;               // elements per array row
+    _Float16* const sink = a.sink + lane * 4;
+
+    // ---- building blocks -----------------------------------------------------------------------------------------
+    // LDS address of ring row q (q = row - R0 + 8 >= 0) of ring g: 0 = x (two chunks), 1..3 = x1..x3
+    auto rowaddr = [&](int g, int q) -> unsigned {
+        return g == 0 ? RA_X_OFF + (unsigned)(q % RA_XS) * (2 * RA_CHB)
+             : g == 1 ? RA_X1_OFF + (unsigned)(q % RA_1S) * RA_CHB
+             : g == 2 ? RA_X2_OFF + (unsigned)(q % RA_2S) * RA_CHB
+                      : RA_X3_OFF + (unsigned)(q % RA_3S) * RA_CHB;
+    };
+    // k-steps [K0, K1) of a convolution whose k-step k = chunk * 9 + tap reads chunk 0, 1 = x, 2.. = x1.. ; row q
+    auto kpart = [&](auto K0c, auto K1c, const auto& wg, f32x4 (&acc)[RA_NF][2], const int q) {
+        constexpr int K0 = decltype(K0c)::value, K1 = decltype(K1c)::value, N = K1 - K0, D = 2;
+        constexpr int G0 = (K0 / 9 < 2) ? 0 : K0 / 9 - 1, G1 = ((K1 - 1) / 9 < 2) ? 0 : (K1 - 1) / 9 - 1;
+        unsigned ra[4][3];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) ra[g][dy] = (g >= G0 && g <= G1) ? rowaddr(g, q + dy - 1) : 0u;
+        half8 bq[D + 1][RA_NF];
+        auto rd = [&](auto KK, half8 (&dst)[RA_NF]) {
+            constexpr int k = K0 + decltype(KK)::value, chunk = k / 9, tap = k % 9, dy = tap / 3, dx = tap % 3;
+            constexpr int g = chunk < 2 ? 0 : chunk - 1, coff = chunk == 1 ? RA_CHB : 0;
+#pragma unroll
+            for (int f = 0; f < RA_NF; ++f) dst[f] = *(const half8*)(smem + ra[g][dy] + coff + offdx[dx] + f * 1024);
+        };
+        __builtin_amdgcn_sched_barrier(0);                           // nothing else's LDS reads count as the pipeline's
+        static_for<(D < N ? D : N)>([&](auto I) { rd(I, bq[decltype(I)::value]); });
+        __builtin_amdgcn_sched_group_barrier(0x100, (D < N ? D : N) * RA_NF, 0);
+        static_for<N>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if constexpr (i + D < N) rd(std::integral_constant<int, i + D>{}, bq[(i + D) % (D + 1)]);
+#pragma unroll
+            for (int f = 0; f < RA_NF; ++f)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wg[i][m], bq[i % (D + 1)][f], acc[f][m], 0, 0, 0);
+            if constexpr (i + D < N) __builtin_amdgcn_sched_group_barrier(0x100, RA_NF, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, RA_NF * 2, 0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto acc_bias = [&](f32x4 (&acc)[RA_NF][2], int conv) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const f32x4 bs = *(const f32x4*)(prm + conv * 32 + 16 * m + 4 * o);
+#pragma unroll
+            for (int f = 0; f < RA_NF; ++f) acc[f][m] = bs;
+        }
+    };
+    auto acc_load = [&](f32x4 (&acc)[RA_NF][2], int j, int buf) {
+        if (UVA_RA_DBG & 8) { acc_bias(acc, j); return; }
+        const char* const pb = smem + RA_P_OFF + (j * 2 + buf) * RA_PB + lane * 16;
+#pragma unroll
+        for (int f = 0; f < RA_NF; ++f)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc[f][m] = *(const f32x4*)(pb + (f * 2 + m) * 1024);
+    };
+    auto acc_store = [&](const f32x4 (&acc)[RA_NF][2], int j, int buf) {
+        if (UVA_RA_DBG & 8) {
+#pragma unroll
+            for (int f = 0; f < RA_NF; ++f)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) asm volatile("" ::"v"(acc[f][m]));
+            return;
+        }
+        char* const pb = smem + RA_P_OFF + (j * 2 + buf) * RA_PB + lane * 16;
+#pragma unroll
+        for (int f = 0; f < RA_NF; ++f)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) *(f32x4*)(pb + (f * 2 + m) * 1024) = acc[f][m];
+    };
+    auto lrelu16 = [&](const f32x4 v) -> half4 {
+        half4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = (_Float16)(v[j] > 0.f ? v[j] : v[j] * a.slope);
+        return r;
+    };
+    auto weights = [&](auto K0c, auto K1c, auto NCHc, const half8* wpk, auto& wg) {
+        constexpr int K0 = decltype(K0c)::value, K1 = decltype(K1c)::value, NCH = decltype(NCHc)::value;
+        static_for<K1 - K0>([&](auto I) {
+            constexpr int k = K0 + decltype(I)::value, chunk = k / 9, tap = k % 9;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) wg[decltype(I)::value][m] = wpk[((size_t)(tap * NCH + chunk) * 2 + m) * 64 + lane];
+        });
+    };
+    using std::integral_constant;
+#define IC(n) integral_constant<int, (n)>{}
+
+    const int sb = a.seg_begin[blockIdx.x], se = a.seg_begin[blockIdx.x + 1];
+    __syncthreads();
+
+    // result row `row` of convolution `conv` (1..4): value v16 (4 channels of this lane's pixel per tile) -> zero outside
+    // the plane -> the ring (conv < 4) and, for the segment's own rows and columns, the array
+    auto emit = [&](const half4 (&v16)[RA_NF][2], const int conv, const int row, const int q, const RdbSeg& sg) {
+        if (UVA_RA_DBG & 2) {
+#pragma unroll
+            for (int f = 0; f < RA_NF; ++f)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) asm volatile("" ::"v"(v16[f][m]));
+            return;
+        }
+        const bool row_in = row >= 0 && row < a.h, row_own = row >= sg.yb && row < sg.ye;
+        char* const rbase = smem + (conv == 1 ? rowaddr(1, q) : conv == 2 ? rowaddr(2, q) : rowaddr(3, q));
+        _Float16* const grow = a.arr + (size_t)(row + 1) * pitch + 64 + 32 * (conv - 1) + 4 * o;
+#pragma unroll
+        for (int f = 0; f < RA_NF; ++f) {
+            const int x = sg.c0 + 16 * f + p;
+            const bool in = row_in && x < a.w;
+            const bool own = row_own && in && x >= sg.own0 && x < sg.own1;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                half4 v = v16[f][m];
+                if (!in) v = half4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+                if (conv < 4) *(half4*)(rbase + wroff[m] + f * 1024) = v;
+                _Float16* const dst = own ? grow + (size_t)(x + 1) * a.stride + 16 * m : sink;
+                if (!(UVA_RA_DBG & 1)) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
+            }
+        }
+    };
+
+    // x row `row` -> ring row q, by LDS-DMA (wave 3 only): rows outside [-1, h] come from the array's zero border row
+    unsigned voff[RA_NDMA];
+    auto dma_setup = [&](const RdbSeg& sg) {
+#pragma unroll
+        for (int k = 0; k < RA_NDMA; ++k) {
+            const int idx = min(k * 64 + lane, 2 * RA_RC * 4 - 1);
+            const int ch = idx / (RA_RC * 4), rem = idx - ch * (RA_RC * 4), rc = rem >> 2, sl = rem & 3;
+            const int u = sl ^ (((rc >> 2) & 1) << 1);
+            voff[k] = (unsigned)(min(sg.c0 + rc, a.w + 1) * a.stride * 2 + ch * 64 + u * 16);
+        }
+    };
+    auto dma_x = [&](int row, int R0) {
+        const int ay = (row < -1 || row > a.h) ? 0 : row + 1;
+        const char* const src = (const char*)(a.arr + (size_t)ay * pitch);
+        const unsigned dst = smem_lds + rowaddr(0, row - R0 + 8);
+#pragma unroll
+        for (int k = 0; k < RA_NDMA; ++k) {
+            if (k + 1 < RA_NDMA) glds16_s(src, voff[k], dst + k * 1024);
+            else if (lane < 2 * RA_RC * 4 - (RA_NDMA - 1) * 64) glds16_s(src, voff[k], dst + k * 1024);
+        }
+    };
+    // Every wave runs the same sequence of barriers: two per segment, then one per step.  The segment loop sits INSIDE a
+    // wave's role so that its weights are fetched once per launch and stay where they are.
+#define RA_STEP_BARRIER() asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((UVA_RA_DBG & 3) ? 0 : 2 * RA_NF) : "memory")
+    if (wave == 0) {
+        half8 wa[18][2], wb[14][2];
+        weights(IC(0), IC(18), IC(2), a.w1, wa);
+        weights(IC(0), IC(14), IC(3), a.w2, wb);
+        for (int si = sb; si < se; ++si) {
+            const RdbSeg sg = a.segs[si];
+            const int R0 = sg.yb - 3, nsteps = sg.ye - sg.yb + RA_LAG;      // conv1's row at step 0; ring row index q = row - R0 + 8
+            sw_barrier();
+            sw_barrier();
+#pragma clang loop unroll(disable)
+            for (int s = 0; s < nsteps; ++s) {
+                f32x4 acc[RA_NF][2];
+                acc_bias(acc, 0);
+                kpart(IC(0), IC(18), wa, acc, s + 8);
+                half4 v16[RA_NF][2];
+#pragma unroll
+                for (int f = 0; f < RA_NF; ++f)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) v16[f][m] = lrelu16(acc[f][m]);
+                emit(v16, 1, R0 + s, s + 8, sg);
+                acc_bias(acc, 1);
+                kpart(IC(0), IC(14), wb, acc, s + 7);
+                acc_store(acc, 0, s & 1);
+                RA_STEP_BARRIER();
+            }
+        }
+    } else if (wave == 1) {
+        half8 wa[13][2], ws[2][2], wb[17][2];
+        weights(IC(14), IC(27), IC(3), a.w2, wa);
+        weights(IC(0), IC(17), IC(4), a.w3, wb);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) ws[c][m] = a.w2s[((size_t)c * 2 + m) * 64 + lane];
+        for (int si = sb; si < se; ++si) {
+            const RdbSeg sg = a.segs[si];
+            const int R0 = sg.yb - 3, nsteps = sg.ye - sg.yb + RA_LAG;
+            sw_barrier();
+            sw_barrier();
+#pragma clang loop unroll(disable)
+            for (int s = 0; s < nsteps; ++s) {
+                f32x4 acc[RA_NF][2];
+                acc_load(acc, 0, (s + 1) & 1);
+                kpart(IC(14), IC(27), wa, acc, s + 6);
+                half4 c3[RA_NF][2];
+#pragma unroll
+                for (int f = 0; f < RA_NF; ++f)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) c3[f][m] = lrelu16(acc[f][m]);
+                // the 1x1 convolution of x, same row: centre tap of both chunks (the accumulators are free again)
+                {
+                    const unsigned rx = rowaddr(0, s + 6);
+#pragma unroll
+                    for (int f = 0; f < RA_NF; ++f)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) acc[f][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int f = 0; f < RA_NF; ++f) {
+                            const half8 b = *(const half8*)(smem + rx + c * RA_CHB + offdx[1] + f * 1024);
+#pragma unroll
+                            for (int m = 0; m < 2; ++m) acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ws[c][m], b, acc[f][m], 0, 0, 0);
+                        }
+                }
+                half4 v16[RA_NF][2];
+#pragma unroll
+                for (int f = 0; f < RA_NF; ++f)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v16[f][m][j] = g_axpby1((float)c3[f][m][j], 1.f, (float)(_Float16)acc[f][m][j], 1.f);
+                emit(v16, 2, R0 + s - 2, s + 6, sg);
+                acc_bias(acc, 2);
+                kpart(IC(0), IC(17), wb, acc, s + 5);
+                acc_store(acc, 1, s & 1);
+                RA_STEP_BARRIER();
+            }
+        }
+    } else if (wave == 2) {
+        half8 wa[19][2], wb[13][2];
+        weights(IC(17), IC(36), IC(4), a.w3, wa);
+        weights(IC(0), IC(13), IC(5), a.w4, wb);
+        for (int si = sb; si < se; ++si) {
+            const RdbSeg sg = a.segs[si];
+            const int R0 = sg.yb - 3, nsteps = sg.ye - sg.yb + RA_LAG;
+            sw_barrier();
+            sw_barrier();
+#pragma clang loop unroll(disable)
+            for (int s = 0; s < nsteps; ++s) {
+                f32x4 acc[RA_NF][2];
+                acc_load(acc, 1, (s + 1) & 1);
+                kpart(IC(17), IC(36), wa, acc, s + 4);
+                half4 v16[RA_NF][2];
+#pragma unroll
+                for (int f = 0; f < RA_NF; ++f)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) v16[f][m] = lrelu16(acc[f][m]);
+                emit(v16, 3, R0 + s - 4, s + 4, sg);
+                acc_bias(acc, 3);
+                kpart(IC(0), IC(13), wb, acc, s + 3);
+                acc_store(acc, 2, s & 1);
+                RA_STEP_BARRIER();
+            }
+        }
+    } else {
+        half8 wa[32][2];
+        weights(IC(13), IC(45), IC(5), a.w4, wa);
+        for (int si = sb; si < se; ++si) {
+            const RdbSeg sg = a.segs[si];
+            const int R0 = sg.yb - 3, nsteps = sg.ye - sg.yb + RA_LAG;
+            dma_setup(sg);
+            sw_barrier();                                           // the previous segment is done with the rings
+            dma_x(R0 - 1, R0);
+            dma_x(R0, R0);
+            dma_x(R0 + 1, R0);
+            sw_barrier();
+#pragma clang loop unroll(disable)
+            for (int s = 0; s < nsteps; ++s) {
+                if (!(UVA_RA_DBG & 4)) dma_x(R0 + s + 2, R0);
+                f32x4 acc[RA_NF][2];
+                acc_load(acc, 2, (s + 1) & 1);
+                kpart(IC(13), IC(45), wa, acc, s + 2);
+                // + x2 of the same pixels (BinaryOp Add_14), from its ring
+                const char* const r2 = smem + rowaddr(2, s + 2);
+                half4 v16[RA_NF][2];
+#pragma unroll
+                for (int f = 0; f < RA_NF; ++f)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const half4 c4 = lrelu16(acc[f][m]);
+                        const half4 x2 = *(const half4*)(r2 + wroff[m] + f * 1024);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v16[f][m][j] = g_axpby1((float)c4[j], 1.f, (float)x2[j], 1.f);
+                    }
+                emit(v16, 4, R0 + s - 6, s + 2, sg);
+                RA_STEP_BARRIER();
+            }
+        }
+    }
+#undef RA_STEP_BARRIER
+#undef IC
 }
 
 }  // namespace uva
