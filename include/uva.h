@@ -25,14 +25,15 @@
 extern "C" {
 #endif
 
-#define UVA_ABI_VERSION 8   /* 2: + uva_net_submit_u8 / uva_net_collect_u8 / uva_host_alloc / uva_host_free;
+#define UVA_ABI_VERSION 9   /* 2: + uva_net_submit_u8 / uva_net_collect_u8 / uva_host_alloc / uva_host_free;
                                3: + uva_get_gpu_pci_bus_id, uva_debug_trunk2_schedule;
                                4: + uva_denoise_u8, uva_debug_denoise_stage; generic graphs (4x_Valar_v1) load;
                                5: + uva_debug_sub10_rows;
                                6: + uva_net_submit_u8_png, uva_png_workspace_bytes, uva_png_assemble, uva_png_deflate_u8,
                                   uva_debug_png_deflate_host;
                                7: + uva_png_decode_bgr, uva_debug_zlib_decompress;
-                               8: + uva_net_debug_generic_plan */
+                               8: + uva_net_debug_generic_plan;
+                               9: + uva_debug_generic_segments (generic graphs: the fused residual-dense-block kernels) */
 
 typedef struct uva_net uva_net;
 
@@ -60,9 +61,12 @@ uva_net* uva_net_create(void);
 /* net.opt.use_vulkan_compute = True; net.set_vulkan_device(gpus[gpu])   :67-68
  * device = HIP ordinal.  A negative index is rejected (no CPU path). */
 int uva_net_set_device(uva_net* net, int device);
-/* net.load_param(path)            :70   parses the ncnn text graph; only the
- * SRVGGNetCompact pattern (conv3x3+PReLU stack, conv3x3, PixelShuffle r, Interp nearest r,
- * BinaryOp add) is accepted, anything else (e.g. 4x_Valar_v1) returns an error. */
+/* net.load_param(path)            :70   parses the ncnn text graph.  The SRVGGNetCompact
+ * pattern (conv3x3+PReLU stack, conv3x3, PixelShuffle r, Interp nearest r, BinaryOp add) takes
+ * the fused kernels; any other graph made of Input / Split / Convolution 3x3 or 1x1 (+ fused
+ * LeakyReLU) / Concat / BinaryOp add / Eltwise sum / Interp nearest / PReLU / PixelShuffle --
+ * 4x_Valar_v1, `-m r`, :913-916 -- takes the generic executor (ABI 4); a layer type outside that
+ * list is an error naming it. */
 int uva_net_load_param(uva_net* net, const char* param_path);
 /* net.load_model(path)            :71   reads the .bin stream; every byte must be
  * consumed.  Weights are repacked for the MFMA kernels and uploaded on first use. */
@@ -209,6 +213,14 @@ int uva_debug_trunk2_schedule(int h, int w, int tile_size, int border, int grid,
  * their first input only, [4] 3x3 convolutions that take the LDS-tiled kernel, [5] channels of the widest shared array, [6] residual dense blocks
  * whose first four convolutions run as one launch (rdb4_kernel).  info: at least 8 ints. */
 int uva_net_debug_generic_plan(const uva_net* net, int* info);
+
+/* Test hook (host only): the work lists of the generic executor's persistent kernels for an h x w plane on `grid`
+ * workgroups -- kind 0: rdb4_kernel (a residual dense block's first four convolutions, models/4x_Valar_v1.param:6-19),
+ * kind 1 / 2: g_conv3_sw with 32 / 64-column strips (the 192 -> 64 and 64 -> 64 convolutions).  Every segment is 8 words
+ * {c0, y_begin, y_end, own0, own1, 0, 0, 0}: the kernel computes columns c0.. of rows [y_begin, y_end) and writes
+ * columns [own0, own1) of them; seg_begin (grid + 1 ints): workgroup g owns segments seg_begin[g] .. seg_begin[g+1]. */
+int uva_debug_generic_segments(int kind, int h, int w, int grid, int32_t* segs_words, size_t capacity_words, size_t* needed_words,
+                               int* seg_begin);
 
 /* Test hook (host only): the row lists sub10_kernel (the whole 24-feature 1x net, one launch) walks for an h x w
  * frame on `grid` workgroups.  Every workgroup has `*stride` 16-byte entries of 4 words {y, x0, emit, 0}

@@ -58,6 +58,28 @@ def test_two_batches_one_set_of_workers(fake):
     assert {int(g) for _, _, _, g in loads} <= {0, 1}
 
 
+def test_two_batches_from_two_directories_on_one_pool(fake, tmp_path, monkeypatch):
+    """the reference's orchestrator changes into every file's temp dir (upscale/upscale_processing.py:842, :971)
+    and hands the workers names relative to it; persistent workers keep the directory they were spawned in.  The second
+    file's frames -- same names -- must be read, written and deleted in ITS directory, with a relative model path too."""
+    gpus = [0, 1]
+    dirs = [tmp_path / "file_a", tmp_path / "file_b"]
+    for k, d in enumerate(dirs):
+        d.mkdir()
+        monkeypatch.chdir(d)
+        for n in (1, 2, 3):
+            _imageio.imwrite("%d.extract.png" % n, _frame(10 * k + n))
+        up.upscale_frames(1, 1, 4, "extract", 2, gpus, 0, os.path.relpath(fake), "x_fake", "input", "output")
+    pids = {p.pid for p in up.get_frame_pool(gpus).procs}
+    assert len(pids) == 2
+    for k, d in enumerate(dirs):
+        for n in (1, 2, 3):
+            assert not (d / ("%d.extract.png" % n)).exists()
+            want = np.repeat(np.repeat(_frame(10 * k + n), 2, 0), 2, 1) + 1
+            assert np.array_equal(_imageio.imread(str(d / ("%d.png" % n))), want), (k, n)
+    assert not [f for f in os.listdir(fake) if f.endswith(".png")]
+
+
 def test_process_model_then_upscale_chain(fake):
     for n in (1, 2, 3):
         _imageio.imwrite("%d.extract.png" % n, _frame(n))

@@ -1,12 +1,14 @@
 """Generic ncnn graphs (`-m r`, models/4x_Valar_v1.param): host loader on CPU, the HIP
 executor against the numpy restatement (oracle/generic_oracle.py) under -m gpu.  The Valar weights are a
 missing blob upstream, so every comparison here uses synthetic weights: functional coverage, no parity claim."""
+import ctypes
 import os
 
 import numpy as np
 import pytest
 
 from conftest import ROOT, load_net, model_paths, psnr_u8
+from upscale_video_amd import _lib
 
 VALAR = os.path.join(ROOT, "models", "4x_Valar_v1.param")
 
@@ -265,3 +267,62 @@ def test_compact_graphs_through_the_generic_executor(uva, oracle, oracle_models,
         assert d.max() <= 2 and psnr_u8(got, want) >= 50, (key, int(d.max()), psnr_u8(got, want))
         d2 = np.abs(got.astype(int) - fused[key].process_u8(img, tile_size=0).astype(int))
         assert d2.max() <= 1
+
+
+def _segments(kind, h, w, grid=256):
+    L = _lib.load()
+    need = ctypes.c_size_t(0)
+    L.uva_debug_generic_segments(kind, h, w, grid, None, 0, ctypes.byref(need), None)
+    words = (ctypes.c_int32 * need.value)()
+    sbeg = (ctypes.c_int * (grid + 1))()
+    assert L.uva_debug_generic_segments(kind, h, w, grid, words, need.value, ctypes.byref(need), sbeg) == 0, L.uva_last_error()
+    segs = np.frombuffer(words, np.int32).reshape(-1, 8)
+    return segs, list(sbeg)
+
+
+@pytest.mark.parametrize("h,w", [(970, 970), (130, 970), (1080, 1920), (52, 42), (7, 45), (20, 12), (333, 97), (2160, 3840)])
+def test_rdb4_work_list_covers_every_pixel_once(h, w):
+    """rdb4_kernel's segments (a dense block's first four convolutions in one launch): every plane pixel owned by exactly
+    one segment; a segment's own columns lie where its 48 computed columns are still right after four convolutions (three
+    columns in from a cut edge, up to the plane's edge otherwise); at most one segment per workgroup unless there are
+    more strips than workgroups."""
+    segs, sbeg = _segments(0, h, w)
+    cover = np.zeros((h, w), np.int32)
+    for c0, yb, ye, own0, own1 in segs[:, :5]:
+        assert 0 <= yb < ye <= h and 0 <= own0 < own1 <= w and c0 >= 0
+        assert own0 >= (c0 + 3 if c0 > 0 else 0) and own1 <= (c0 + 45 if c0 + 48 < w else w)
+        cover[yb:ye, own0:own1] += 1
+    assert (cover == 1).all()
+    assert sbeg[0] == 0 and sbeg[-1] == len(segs) and all(b >= a for a, b in zip(sbeg, sbeg[1:]))
+    per_wg = np.diff(sbeg)
+    nstrips = len({int(c) for c in segs[:, 0]})
+    assert per_wg.max() == (1 if nstrips <= 256 else -(-nstrips // 256))
+    rows = np.array([sum(int(s[2] - s[1]) for s in segs[sbeg[g]:sbeg[g + 1]]) for g in range(256)])
+    busy = rows[rows > 0]
+    assert busy.max() - busy.min() <= 1 or nstrips > 256
+
+
+@pytest.mark.parametrize("kind,cols", [(1, 32), (2, 64)])
+@pytest.mark.parametrize("h,w", [(970, 970), (130, 970), (3880, 3880), (75, 64), (9, 200)])
+def test_conv3_sw_work_list_covers_every_pixel_once(kind, cols, h, w):
+    """g_conv3_sw's segments: strips of 32 / 64 columns cut into runs of 4-row blocks, every pixel in exactly one, runs
+    of equal length (+-1 block) per workgroup."""
+    segs, sbeg = _segments(kind, h, w)
+    cover = np.zeros((h, w), np.int32)
+    for c0, y0, y1 in segs[:, :3]:
+        assert c0 % cols == 0 and y0 % 4 == 0 and (y1 % 4 == 0 or y1 == h) and 0 <= y0 < y1 <= h
+        cover[y0:y1, c0:min(w, c0 + cols)] += 1
+    assert (cover == 1).all()
+    blocks = np.array([sum(-(-int(s[2] - s[1]) // 4) for s in segs[sbeg[g]:sbeg[g + 1]]) for g in range(256)])
+    assert blocks.max() - blocks.min() <= 1
+
+
+def test_valar_dense_blocks_are_recognised(uva):
+    """find_rdbs: 68 of 4x_Valar_v1's 69 residual dense blocks run their first four convolutions as one launch (the very
+    first block's x comes from the 3-channel head convolution and is copied into the chain's array after conv1)."""
+    L = _lib.load()
+    net = uva.Net()
+    assert net.load_param(VALAR) == 0, getattr(net, "last_error", "")
+    info = (ctypes.c_int * 8)()
+    assert L.uva_net_debug_generic_plan(net._h, info) == 0, L.uva_last_error()
+    assert info[6] == 68

@@ -27,6 +27,9 @@ def frames():
         "1x1": np.array([[[1, 2, 3]]], np.uint8),
         "one_row": rng.integers(0, 256, (1, 500, 3), dtype=np.uint8),
         "many_blocks": rng.integers(0, 256, (40, 5000, 3), dtype=np.uint8),      # 3 rows per block, ragged last block
+        # 3 pixels wide -- a raw row takes 12 bytes in the staging area for its 10 filtered ones, so the rows of a
+        # block are bounded by the staging area, not by the filtered bytes
+        "narrow_tall": rng.integers(0, 256, (5200, 3, 3), dtype=np.uint8),
     }
 
 

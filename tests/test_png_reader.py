@@ -86,6 +86,28 @@ def test_inflate_rejects_damage_without_crashing():
     assert L.uva_last_error()
 
 
+def test_inflate_fixed_block_then_truncated_stored_block():
+    """the fast loop of a fixed-Huffman block used to leave the read pointer past the end of its input (two
+    8-byte refills per iteration behind one bounds check), after which a stored block's length check compared a negative
+    distance as unsigned and copied from beyond the buffer.  Streams cut at every position of the tail -- each in a heap
+    buffer of exactly its own size -- must be refused, never read past, and the whole stream must still inflate."""
+    rng = np.random.default_rng(23)
+    lits = rng.integers(0, 144, 4000, dtype=np.uint8).tobytes()           # 8-bit codes in the fixed table: literals only
+    c = zlib.compressobj(9, zlib.DEFLATED, -15, 9, zlib.Z_FIXED)
+    fixed = c.compress(lits) + c.flush(zlib.Z_SYNC_FLUSH)                   # fixed block(s) + an empty stored block
+    tail = rng.integers(0, 256, 3000, dtype=np.uint8).tobytes()
+    raw = fixed + b"\x01" + struct.pack("<HH", len(tail), len(tail) ^ 0xffff) + tail     # final stored block
+    data = lits + tail
+    whole = b"\x78\x01" + raw + struct.pack(">I", zlib.adler32(data))
+    assert zlib.decompress(whole) == data
+    rc, out = inflate(whole, len(data))
+    assert rc == 0 and out == data
+    for cut in list(range(len(fixed) - 12, len(fixed) + 24)) + [len(raw) - 1, len(raw) - 700]:
+        stream = bytes(bytearray(b"\x78\x01" + raw[:cut]))                  # its own allocation: reads past it are ASan / valgrind errors
+        rc, _ = inflate(stream, len(data))
+        assert rc != 0, cut
+
+
 def png_of(arr, mode, **kw):
     from PIL import Image
     buf = io.BytesIO()

@@ -1130,6 +1130,54 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
             }
         }
     }
+    // g_conv3_sw (the 192 -> 64 and 64 -> 64 convolutions on planes wide enough for its strips) also takes a SECOND sum
+    // behind the first -- the `rrdb_in*1.0 + rdb_out*0.2` that closes every third dense block of 4x_Valar_v1
+    // (models/4x_Valar_v1.param:55-56): the first sum's result then never goes to memory either.
+    static const bool sw_on = [] { const char* e = std::getenv("UVA_GENERIC_SW"); return !e || std::atoi(e) != 0; }();
+    auto sw_cols_of = [&](size_t li) -> int {      // strip width g_conv3_sw would use for layer li on this plane, 0: not its case
+        const GLayer& l = g.layers[li];
+        if (!sw_on || !n->generic_lds_conv || l.kind != GLayer::CONV || l.ksize != 3) return 0;
+        const GenericDevice::ConvDev& cd = n->gd.convs[l.conv];
+        if (cd.cout_pad != 64 || g.blobs[l.out[0]].channels != 64 || (cd.cin_pad != 64 && cd.cin_pad != 192)) return 0;
+        const int cols = cd.cin_pad == 192 ? sw_cols<1>() : sw_cols<2>();
+        return w * g.blobs[l.out[0]].scale >= cols ? cols : 0;
+    };
+    // the instantiations of g_conv3_sw that exist (what 4x_Valar_v1 needs): -1 = none, the layer-by-layer kernel takes it
+    auto sw_variant = [](int cin_pad, bool act, int rm, int rm2) -> int {
+        if (cin_pad == 192 && !act && rm == 2 && rm2 == 0) return 0;
+        if (cin_pad == 192 && !act && rm == 2 && rm2 == 2) return 1;
+        if (cin_pad == 64 && !act && rm == 1 && rm2 == 0) return 2;
+        if (cin_pad == 64 && act && rm == 0 && rm2 == 0) return 3;
+        if (cin_pad == 192 && !act && rm == 0 && rm2 == 0) return 4;     // (UVA_GENERIC_FUSE_ADD=0: the sums as launches of their own)
+        if (cin_pad == 64 && !act && rm == 0 && rm2 == 0) return 5;
+        return -1;
+    };
+    std::vector<int> fuse_add2(g.layers.size(), -1), fuse_pos2(g.layers.size(), 0);
+    static const bool add2_on = [] { const char* e = std::getenv("UVA_GENERIC_FUSE_ADD2"); return !e || std::atoi(e) != 0; }();
+    if (n->generic_lds_conv && n->generic_fuse_add && add2_on) {
+        std::vector<int> producer(g.blobs.size(), -1);
+        std::vector<std::vector<int>> readers(g.blobs.size());
+        for (size_t li = 0; li < g.layers.size(); ++li) {
+            if (g.layers[li].kind == GLayer::SPLIT) continue;
+            if (!g.layers[li].out.empty()) producer[g.layers[li].out[0]] = (int)li;
+            for (int b : g.layers[li].in) readers[root(b)].push_back((int)li);
+        }
+        for (size_t li = 0; li < g.layers.size(); ++li) {
+            if (fuse_add[li] < 0 || !sw_cols_of(li)) continue;
+            const int o1 = root(g.layers[fuse_add[li]].out[0]);
+            if (g.blobs[o1].consumers != 1 || readers[o1].size() != 1 || group_of(o1) >= 0 || o1 == root(g.out_blob)) continue;
+            const int ri = readers[o1][0];
+            const GLayer& r = g.layers[ri];
+            if ((r.kind != GLayer::ADD && r.kind != GLayer::ELTWISE_SUM) || r.in.size() != 2 || r.coeffs.size() != 2 || skip[ri]) continue;
+            const int k = root(r.in[0]) == o1 ? 0 : 1, ob3 = root(r.in[1 - k]);
+            if (ob3 == o1 || producer[ob3] < 0 || producer[ob3] >= (int)li) continue;
+            const GLayer& cl = g.layers[li];
+            if (sw_variant(n->gd.convs[cl.conv].cin_pad, cl.has_act, fuse_pos[li] == 1 ? 1 : 2, k == 1 ? 1 : 2) < 0) continue;
+            fuse_add2[li] = ri;
+            fuse_pos2[li] = k;
+            skip[ri] = 1;
+        }
+    }
     // residual dense blocks whose first four convolutions run as one rdb4_kernel launch at the first one (UVA_GENERIC_RDB=0:
     // layer by layer, the A/B switch): the other six layers are bookkeeping only, and none of their sums is fused elsewhere
     static const bool rdb_on = [] { const char* e = std::getenv("UVA_GENERIC_RDB"); return !e || std::atoi(e) != 0; }();
@@ -1170,8 +1218,9 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
             continue;
         }
         const GLayer* const sum = fuse_add[layer_i] >= 0 ? &g.layers[fuse_add[layer_i]] : nullptr;
+        const GLayer* const sum2 = fuse_add2[layer_i] >= 0 ? &g.layers[fuse_add2[layer_i]] : nullptr;
         GBuf o;
-        if (acquire_out(sum ? *sum : gl, &o)) return 1;       // (a fused convolution writes the sum's array, it has none of its own)
+        if (acquire_out(sum2 ? *sum2 : sum ? *sum : gl, &o)) return 1;       // (a fused convolution writes the last sum's array, it has none of its own)
         auto in = [&](int k) -> const GBuf& { return buf[root(gl.in[k])]; };
         switch (gl.kind) {
         case GLayer::INPUT:
@@ -1214,10 +1263,8 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
             }
             // 3x3 convolutions with 64 output channels from 64 or 192 input channels: weights stationary in registers
             // (g_conv3_sw, uva_rdb.hip.h).  UVA_GENERIC_SW=0: the layer-by-layer kernel below (the A/B switch).
-            static const bool sw_on = [] { const char* e = std::getenv("UVA_GENERIC_SW"); return !e || std::atoi(e) != 0; }();
-            if (sw_on && n->generic_lds_conv && gl.ksize == 3 && cd.cout_pad == 64 && o.c == 64 && (cd.cin_pad == 64 || cd.cin_pad == 192)) {
-                const int cols = cd.cin_pad == 192 ? sw_cols<1>() : sw_cols<2>();
-                if (a.w + 2 >= cols + 2) {
+            if (const int cols = sw_cols_of(layer_i)) {
+                if (sw_variant(cd.cin_pad, gl.has_act, !sum ? 0 : fuse_pos[layer_i] == 1 ? 1 : 2, !sum2 ? 0 : fuse_pos2[layer_i] == 1 ? 1 : 2) >= 0) {
                     GenericDevice::SwPlan& plan = n->gd.sw_plans[std::make_tuple(a.h, a.w, cols)];
                     if (!plan.segs) {
                         std::vector<GSwSeg> segs;
@@ -1236,8 +1283,13 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
                     sa.slope = gl.act_slope;
                     if (sum) {
                         const GBuf& other = buf[root(sum->in[1 - fuse_pos[layer_i]])];
-                        sa.res = other.p; sa.res_stride = other.cpad; sa.res_first = fuse_pos[layer_i] == 1;
+                        sa.res = other.p; sa.res_stride = other.cpad;
                         sa.ca = sum->coeffs[0]; sa.cb = sum->coeffs[1];
+                    }
+                    if (sum2) {
+                        const GBuf& other = buf[root(sum2->in[1 - fuse_pos2[layer_i]])];
+                        sa.res2 = other.p; sa.res2_stride = other.cpad;
+                        sa.ca2 = sum2->coeffs[0]; sa.cb2 = sum2->coeffs[1];
                     }
                     sa.segs = plan.segs; sa.seg_begin = plan.seg_begin; sa.sink = n->d_sink;
                     auto launch_sw = [&](auto kern, int slot, size_t lds) -> int {
@@ -1248,10 +1300,14 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
                         hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(256), lds, n->stream, sa);
                         return 0;
                     };
-                    if (cd.cin_pad == 192 && gl.has_act) { if (launch_sw(g_conv3_sw<6, 1, true>, 24, sw_lds_bytes<6, 1>())) return 1; }
-                    else if (cd.cin_pad == 192) { if (launch_sw(g_conv3_sw<6, 1, false>, 25, sw_lds_bytes<6, 1>())) return 1; }
-                    else if (gl.has_act) { if (launch_sw(g_conv3_sw<2, 2, true>, 26, sw_lds_bytes<2, 2>())) return 1; }
-                    else { if (launch_sw(g_conv3_sw<2, 2, false>, 27, sw_lds_bytes<2, 2>())) return 1; }
+                    const int rm = !sum ? 0 : fuse_pos[layer_i] == 1 ? 1 : 2, rm2 = !sum2 ? 0 : fuse_pos2[layer_i] == 1 ? 1 : 2;
+                    const int variant = sw_variant(cd.cin_pad, gl.has_act, rm, rm2);
+                    if (variant == 0) { if (launch_sw(g_conv3_sw<6, 1, false, 2, 0>, 24, sw_lds_bytes<6, 1>())) return 1; }
+                    else if (variant == 1) { if (launch_sw(g_conv3_sw<6, 1, false, 2, 2>, 25, sw_lds_bytes<6, 1>())) return 1; }
+                    else if (variant == 2) { if (launch_sw(g_conv3_sw<2, 2, false, 1, 0>, 26, sw_lds_bytes<2, 2>())) return 1; }
+                    else if (variant == 3) { if (launch_sw(g_conv3_sw<2, 2, true, 0, 0>, 27, sw_lds_bytes<2, 2>())) return 1; }
+                    else if (variant == 4) { if (launch_sw(g_conv3_sw<6, 1, false, 0, 0>, 29, sw_lds_bytes<6, 1>())) return 1; }
+                    else { if (launch_sw(g_conv3_sw<2, 2, false, 0, 0>, 30, sw_lds_bytes<2, 2>())) return 1; }
                     break;
                 }
             }
@@ -1358,6 +1414,7 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
         HIP_TRY(hipGetLastError());
         for (int b : gl.in) done_with(b);
         if (sum) done_with(sum->in[1 - fuse_pos[layer_i]]);
+        if (sum2) done_with(sum2->in[1 - fuse_pos2[layer_i]]);
     }
     const GBuf& res = buf[root(g.out_blob)];
     const int s = g.scale;
@@ -2413,6 +2470,29 @@ int uva_debug_sub10_rows(int h, int w, int grid, uint32_t* rows_words, size_t ca
     if (!rows_words || capacity_words < rows.size() * 4) return fail("rows buffer too small");
     std::memcpy(rows_words, rows.data(), rows.size() * sizeof(uint4));
     if (nrows) std::copy(nr.begin(), nr.end(), nrows);
+    return 0;
+}
+
+int uva_debug_generic_segments(int kind, int h, int w, int grid, int32_t* out, size_t capacity_words, size_t* needed_words, int* seg_begin)
+{
+    if (h <= 0 || w <= 0 || grid <= 0) return fail("bad argument");
+    std::vector<int32_t> words;
+    std::vector<int> sbeg;
+    if (kind == 0) {
+        std::vector<RdbSeg> segs;
+        rdb_segments(h, w, grid, segs, sbeg);
+        for (const RdbSeg& sg : segs) words.insert(words.end(), {sg.c0, sg.yb, sg.ye, sg.own0, sg.own1, 0, 0, 0});
+    } else if (kind == 1 || kind == 2) {
+        std::vector<GSwSeg> segs;
+        sw_segments(h, w, kind == 1 ? sw_cols<1>() : sw_cols<2>(), grid, segs, sbeg);
+        for (const GSwSeg& sg : segs) words.insert(words.end(), {sg.c0, sg.y0, sg.y1, sg.c0, sg.c0 + (kind == 1 ? sw_cols<1>() : sw_cols<2>()), 0, 0, 0});
+    } else {
+        return fail("bad kind");
+    }
+    if (needed_words) *needed_words = words.size();
+    if (!out || capacity_words < words.size()) return fail("segment buffer too small");
+    std::memcpy(out, words.data(), words.size() * sizeof(int32_t));
+    if (seg_begin) std::copy(sbeg.begin(), sbeg.end(), seg_begin);
     return 0;
 }
 

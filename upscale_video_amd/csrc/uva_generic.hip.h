@@ -502,20 +502,31 @@ inline void rdb_segments(int h, int w, int grid, std::vector<RdbSeg>& segs, std:
         strips.push_back(s);
         own0 = s.own1;
     }
-    const long long total = (long long)strips.size() * h;
+    // Every segment costs RA_LAG steps of pipeline fill, so a workgroup gets ONE: each strip is cut into k = grid / strips
+    // equal row ranges (a few workgroups stay idle; with more strips than workgroups, whole strips are dealt out in turn).
     segs.clear();
     seg_begin.assign(1, 0);
+    const int ns = (int)strips.size();
+    if (ns >= grid) {
+        for (int g = 0; g < grid; ++g) {
+            for (int s = g; s < ns; s += grid) {
+                RdbSeg sg = strips[s];
+                sg.yb = 0;
+                sg.ye = h;
+                segs.push_back(sg);
+            }
+            seg_begin.push_back((int)segs.size());
+        }
+        return;
+    }
+    const int k = std::max(1, std::min(grid / ns, (h + 7) / 8));     // (ranges of fewer than ~8 rows are all pipeline fill)
     for (int g = 0; g < grid; ++g) {
-        long long u = total * g / grid;
-        const long long u1 = total * (g + 1) / grid;
-        while (u < u1) {
-            const int s = (int)(u / h), y0 = (int)(u - (long long)s * h);
-            const int y1 = (int)std::min<long long>(h, y0 + (u1 - u));
+        const int s = g / k, j = g - s * k;
+        if (s < ns) {
             RdbSeg sg = strips[s];
-            sg.yb = y0;
-            sg.ye = y1;
-            segs.push_back(sg);
-            u += y1 - y0;
+            sg.yb = (int)((long long)h * j / k);
+            sg.ye = (int)((long long)h * (j + 1) / k);
+            if (sg.ye > sg.yb) segs.push_back(sg);
         }
         seg_begin.push_back((int)segs.size());
     }

@@ -202,7 +202,14 @@ inline const PngTables& png_tables()
     return T;
 }
 
-inline int png_rows_per_block(int w) { return std::max(1, PNG_FILT_CAP / (3 * w + 1)); }
+// Rows of one deflate block: its filtered bytes (3w + 1 per row) fit PNG_FILT_CAP, and its RAW rows -- staged in the
+// `stage` area at a pitch of (3w + 3) & ~3 bytes before they are filtered -- fit PNG_STAGE_BYTES (for very narrow frames
+// the pitch's padding makes that the tighter bound: w = 3, 4 900 rows would overrun the stage area into the tables).
+inline int png_rows_per_block(int w)
+{
+    const int rawp = (3 * w + 3) & ~3;
+    return std::max(1, std::min(PNG_FILT_CAP / (3 * w + 1), PNG_STAGE_BYTES / rawp));
+}
 inline int png_num_blocks(int h, int w) { const int r = png_rows_per_block(w); return (h + r - 1) / r; }
 // bytes of the workspace a frame needs, in HBM ([meta: nblocks x 32 B, padded to 4 KiB][nblocks slots]) and in page-locked
 // host memory ([the same meta][the blocks' bytes, concatenated]: the same bound)

@@ -22,18 +22,21 @@ namespace {
 inline uint32_t rd_be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 
 uint32_t crc_table[8][256];
-bool crc_ready = false;
+// The decode threads of a worker (frame_pool.py, the GIL released inside the call) all come here on their first frame:
+// a function-local static is initialised exactly once and its stores are visible to every thread that passes it.
 void crc_init()
 {
-    if (crc_ready) return;
-    for (uint32_t i = 0; i < 256; ++i) {
-        uint32_t c = i;
-        for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-        crc_table[0][i] = c;
-    }
-    for (uint32_t i = 0; i < 256; ++i)
-        for (int t = 1; t < 8; ++t) crc_table[t][i] = (crc_table[t - 1][i] >> 8) ^ crc_table[0][crc_table[t - 1][i] & 0xff];
-    crc_ready = true;
+    static const bool ready = [] {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            crc_table[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int t = 1; t < 8; ++t) crc_table[t][i] = (crc_table[t - 1][i] >> 8) ^ crc_table[0][crc_table[t - 1][i] & 0xff];
+        return true;
+    }();
+    (void)ready;
 }
 uint32_t crc32(uint32_t crc, const uint8_t* p, size_t n)
 {
@@ -240,7 +243,7 @@ bool inflate_raw(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_len,
             }
             if (b.ran_dry()) { err = "inflate: truncated stream"; return false; }
             if (left) {
-                if ((size_t)(b.end - b.p) < left) { err = "inflate: truncated stream"; return false; }
+                if (b.p > b.end || (size_t)(b.end - b.p) < left) { err = "inflate: truncated stream"; return false; }
                 if ((size_t)(oend - o) < left) { err = "inflate: more data than the image holds"; return false; }
                 std::memcpy(o, b.p, left);
                 o += left; b.p += left;
@@ -295,15 +298,17 @@ bool inflate_raw(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_len,
             const uint32_t* const LT = lit.e.data();
             const uint32_t* const DT = dist.e.data();
             bool block_done = false;
-            // Fast loop: while 8 input bytes and FAST_OUT output bytes remain, nothing in it needs a bounds check -- one
+            // Fast loop: while 16 input bytes and FAST_OUT output bytes remain, nothing in it needs a bounds check -- one
             // iteration emits at most 56 literals (one bit each from one refill) and one match of 258 bytes, whose
-            // word-wise copy may overshoot by 7.  The bit buffer lives in registers.
+            // word-wise copy may overshoot by 7.  An iteration refills TWICE (top of the loop, and in front of the distance
+            // code), each an 8-byte read after advancing by at most 7: p <= end - 16 at the top keeps both inside the
+            // input and leaves p <= end on exit.  The bit buffer lives in registers.
             constexpr ptrdiff_t FAST_OUT = 56 + 258 + 8 + 8;
-            if (b.end - b.p >= 8 && oend - o >= FAST_OUT) {
+            if (b.end - b.p >= 16 && oend - o >= FAST_OUT) {
                 uint64_t buf = b.buf;
                 int nb = b.n;
                 const uint8_t* p = b.p;
-                const uint8_t* const in_safe = b.end - 8;
+                const uint8_t* const in_safe = b.end - 16;
                 uint8_t* const out_safe = oend - FAST_OUT;
                 const uint32_t LIT = (uint32_t)K_LITERAL << 4, LITMASK = 0x70u;       // one literal or two
                 while (p <= in_safe && o <= out_safe) {
@@ -336,7 +341,7 @@ bool inflate_raw(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_len,
                     const uint32_t xl = (e >> 8) & 31;
                     const uint32_t len = (e >> 16) + (uint32_t)(buf & ((1u << xl) - 1));
                     buf >>= xl; nb -= (int)xl;
-                    std::memcpy(&v, p, 8);                       // p <= in_safe still holds: p moved by at most 7
+                    std::memcpy(&v, p, 8);                       // p <= in_safe + 7 = end - 9: inside the input
                     buf |= v << nb;
                     p += (63 - nb) >> 3;
                     nb |= 56;

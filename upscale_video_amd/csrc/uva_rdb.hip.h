@@ -52,8 +52,12 @@ struct GSwArgs {
     float slope;                  // LeakyReLU (template ACT)
     // the element-wise sum behind the convolution (GConvArgs::res in uva_generic.hip.h: same expression, same rounding)
     const _Float16* res;
-    int res_stride, res_first;
+    int res_stride;
     float ca, cb;
+    // ... and a second sum behind the first: out = x2*ca2 + y2*cb2, one of them the first sum's result
+    const _Float16* res2;
+    int res2_stride;
+    float ca2, cb2;
     const GSwSeg* segs;           // this launch's segments; workgroup g owns segs[seg_begin[g] .. seg_begin[g+1])
     const int* seg_begin;
     _Float16* sink;               // >= 64 * 8 bytes: where lanes outside the plane store to
@@ -73,9 +77,19 @@ __device__ __forceinline__ void sw_barrier() { asm volatile("s_waitcnt vmcnt(0) 
 // for every kernel that computes it (g_axpby, g_axpby_strided and the convolution epilogues that absorb a sum), so that a
 // sum gives the same bytes whichever kernel does it -- left to the compiler, `x*ca + y*cb` contracts into an fma around
 // either product
-__device__ __forceinline__ _Float16 g_axpby1(float x, float ca, float y, float cb) { return (_Float16)__builtin_fmaf(x, ca, y * cb); }
+__device__ __forceinline__ _Float16 g_axpby1(float x, float ca, float y, float cb)
+{
+    // The fp32 result is made opaque before it is rounded to fp16: where the compiler sees both steps it may pick
+    // v_fma_mixlo_f16, which rounds the exact fma ONCE -- other call sites round twice (fp32, then fp16), and the two
+    // differ in rare ties.
+    float t = __builtin_fmaf(x, ca, y * cb);
+    asm volatile("" : "+v"(t));
+    return (_Float16)t;
+}
 
-template <int KC, int MBW, bool ACT>
+// RES / RES2: the first / second fused sum -- 0 none, 1 the other operand is the sum's x (out = res*ca + conv*cb), 2 the
+// convolution's side is (out = conv*ca + res*cb); g_axpby1 is not symmetric in x and y, so the order is part of the bytes
+template <int KC, int MBW, bool ACT, int RES, int RES2>
 __global__ __launch_bounds__(256, 1) void g_conv3_sw(GSwArgs a)
 {
     constexpr int C = sw_cols<MBW>(), RC = C + 2, NP = sw_np<KC, MBW>(), ROWB = sw_rowb<KC, MBW>();
@@ -141,6 +155,106 @@ __global__ __launch_bounds__(256, 1) void g_conv3_sw(GSwArgs a)
 #pragma unroll
             for (int m = 0; m < MBW; ++m) wgt[t][c][m] = a.wpk[((size_t)(t * KC + c) * 4 + mb0 + m) * 64 + lane];
 
+    // The epilogue of block b (LeakyReLU, fp16, the fused sums, the stores) runs INSIDE the k-loop of block b+1, one tile
+    // every few steps: a wave has its SIMD to itself, so whatever is not between MFMAs is matrix-pipe idle time.  Two
+    // accumulator sets alternate; the sums' other operands are fetched tile by tile, each right after the previous
+    // block's value in the same registers has been used (a whole k-loop ahead of its own use).
+    constexpr int NT = SW_R * NF * MBW;        // tiles per wave and block
+    constexpr int NLD = NT * ((RES != 0) + (RES2 != 0));
+    constexpr int NSTEP = KC * 3 * NIR;
+    constexpr int E0 = NSTEP * 2 / 5, ES = (NSTEP - 2 - E0) / NT > 0 ? (NSTEP - 2 - E0) / NT : 1;   // tile j after step E0 + j*ES
+    static_assert(E0 + (NT - 1) * ES < NSTEP, "epilogue tiles fit the k-loop");
+    half4 rsv[RES ? NT : 1], rsw[RES2 ? NT : 1];
+
+    // tile j = (r, f, m) of block b of the segment (c0, y0, y1): is this lane's pixel a real one, where it sits in the arrays
+    auto tile_pos = [&](int j, int c0, int y0, int y1, int b, bool* inside) -> size_t {
+        const int m = j % MBW, f = (j / MBW) % NF, r = j / (MBW * NF);
+        const int y = y0 + SW_R * b + r, x = c0 + cw + 16 * f + p;
+        *inside = y < y1 && x < a.w;
+        return ((size_t)(min(y, a.h - 1) + 1) * (a.w + 2) + 1 + min(x, a.w - 1));      // (clamped: lanes outside read a real pixel)
+    };
+    auto load_res = [&](int j, int c0, int y0, int y1, int b) {
+        if constexpr (RES != 0 || RES2 != 0) {
+            bool in;
+            const size_t pos = tile_pos(j, c0, y0, y1, b, &in);
+            const int ch = 16 * (mb0 + j % MBW) + 4 * o;
+            if constexpr (RES != 0) rsv[j] = *(const half4*)(a.res + pos * a.res_stride + ch);
+            if constexpr (RES2 != 0) rsw[j] = *(const half4*)(a.res2 + pos * a.res2_stride + ch);
+        }
+    };
+    auto epi_tile = [&](auto Jc, const f32x4 (&acc)[SW_R][NF][MBW], int c0, int y0, int y1, int b) {
+        constexpr int j = decltype(Jc)::value, m = j % MBW, f = (j / MBW) % NF, r = j / (MBW * NF);
+        f32x4 v = acc[r][f][m];
+        if constexpr (ACT) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
+        }
+        half4 cv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        if constexpr (RES != 0) {
+            const half4 rv = rsv[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                cv[e] = RES == 1 ? g_axpby1((float)rv[e], a.ca, (float)cv[e], a.cb) : g_axpby1((float)cv[e], a.ca, (float)rv[e], a.cb);
+        }
+        if constexpr (RES2 != 0) {
+            const half4 rv = rsw[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                cv[e] = RES2 == 1 ? g_axpby1((float)rv[e], a.ca2, (float)cv[e], a.cb2) : g_axpby1((float)cv[e], a.ca2, (float)rv[e], a.cb2);
+        }
+        bool in;
+        const size_t pos = tile_pos(j, c0, y0, y1, b, &in);
+        _Float16* const dst = (UVA_SW_DBG < 1 && in) ? a.out + pos * a.out_stride + a.out_coff + 16 * (mb0 + m) + 4 * o : sink;
+        if (UVA_SW_DBG >= 1) { asm volatile("" ::"v"(cv)); return; }
+        asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(cv) : "memory");
+    };
+    // the k-loop of block b into acc: (chunk, tap column) x input row x fragment, fragments read D steps ahead; side(j)
+    // = tile j of the previous block's epilogue
+    auto kloop = [&](f32x4 (&acc)[SW_R][NF][MBW], const int b, auto&& side) {
+        unsigned rowb[NIR];                    // input row ir of the block = ring row 4b + ir
+#pragma unroll
+        for (int ir = 0; ir < NIR; ++ir) rowb[ir] = (unsigned)((SW_R * b + ir) % SW_SLOTS) * ROWB;
+#pragma unroll
+        for (int m = 0; m < MBW; ++m) {        // start from the bias: lane (o, p) accumulates channels 16(mb0 + m) + 4o .. +3
+            const f32x4 bs = *(const f32x4*)(lbias + 16 * (mb0 + m) + 4 * o);
+#pragma unroll
+            for (int r = 0; r < SW_R; ++r)
+#pragma unroll
+                for (int f = 0; f < NF; ++f) acc[r][f][m] = bs;
+        }
+        constexpr int D = UVA_SW_D;
+        half8 bq[D + 1][NF];
+        auto rd = [&](int idx, half8 (&dst)[NF]) {      // idx = (c * 3 + dx) * NIR + ir
+            const int cd = idx / NIR, ir = idx - cd * NIR, c = cd / 3, dx = cd - 3 * c;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) dst[f] = *(const half8*)(ring + rowb[ir] + offdx[dx] + c * (RC * 64) + f * 1024);
+        };
+        __builtin_amdgcn_sched_barrier(0);                       // nothing else's LDS reads count as the pipeline's
+#pragma unroll
+        for (int i = 0; i < D; ++i) rd(i, bq[i]);
+        __builtin_amdgcn_sched_group_barrier(0x100, D * NF, 0);
+        static_for<NSTEP>([&](auto I) {
+            constexpr int idx = decltype(I)::value;
+            constexpr int cd = idx / NIR, ir = idx - cd * NIR, c = cd / 3, dx = cd - 3 * c;
+            if constexpr (idx + D < NSTEP) rd(idx + D, bq[(idx + D) % (D + 1)]);
+            constexpr int ndy = (ir < 3 ? ir + 1 : 3) - (ir >= SW_R ? ir - SW_R + 1 : 0);     // tap rows with an output row in the block
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int r = ir - dy;
+                if (r < 0 || r >= SW_R) continue;
+#pragma unroll
+                for (int f = 0; f < NF; ++f)
+#pragma unroll
+                    for (int m = 0; m < MBW; ++m)
+                        acc[r][f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wgt[dy * 3 + dx][c][m], bq[idx % (D + 1)][f], acc[r][f][m], 0, 0, 0);
+            }
+            if constexpr (idx + D < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, NF, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, ndy * NF * MBW, 0);
+            if constexpr (idx >= E0 && (idx - E0) % ES == 0 && (idx - E0) / ES < NT) side(std::integral_constant<int, (idx - E0) / ES>{});
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
     for (int si = sb; si < se; ++si) {
         const GSwSeg seg = a.segs[si];
         const int c0 = __builtin_amdgcn_readfirstlane(seg.c0), y0 = __builtin_amdgcn_readfirstlane(seg.y0),
@@ -151,101 +265,37 @@ __global__ __launch_bounds__(256, 1) void g_conv3_sw(GSwArgs a)
         }
         sw_barrier();
         const int nblk = (y1 - y0 + SW_R - 1) / SW_R;
-        for (int b = 0; b < nblk; ++b) {
-            // (1) the next block's four new rows: LDS-DMA, in flight during this block's k-loop
-            if (UVA_SW_DBG < 2 && b + 1 < nblk)
-                for (int rr = 0; rr < SW_R; ++rr) dma_row(c0, y0, SW_R * (b + 1) + 2 + rr);
-            // (2) the fused sum's other operand for this block's pixels: 8 bytes per lane, output row, fragment and block
-            size_t pos[SW_R][NF];
-            bool inside[SW_R][NF];
-            half4 rsv[SW_R][NF][MBW];
-#pragma unroll
-            for (int r = 0; r < SW_R; ++r)
-#pragma unroll
-                for (int f = 0; f < NF; ++f) {
-                    const int y = y0 + SW_R * b + r, x = c0 + cw + 16 * f + p;
-                    inside[r][f] = y < y1 && x < a.w;
-                    pos[r][f] = (size_t)(y + 1) * (a.w + 2) + 1 + x;
-#pragma unroll
-                    for (int m = 0; m < MBW; ++m) {
-                        rsv[r][f][m] = half4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
-                        if (UVA_SW_DBG < 1 && a.res && inside[r][f]) rsv[r][f][m] = *(const half4*)(a.res + pos[r][f] * a.res_stride + 16 * (mb0 + m) + 4 * o);
-                    }
-                }
-            // input row ir of the block = ring row 4b + ir
-            unsigned rowb[NIR];
-#pragma unroll
-            for (int ir = 0; ir < NIR; ++ir) rowb[ir] = (unsigned)((SW_R * b + ir) % SW_SLOTS) * ROWB;
-            f32x4 acc[SW_R][NF][MBW];         // start from the bias: lane (o, p) accumulates channels 16(mb0 + m) + 4o .. +3
-#pragma unroll
-            for (int m = 0; m < MBW; ++m) {
-                const f32x4 bs = *(const f32x4*)(lbias + 16 * (mb0 + m) + 4 * o);
-#pragma unroll
-                for (int r = 0; r < SW_R; ++r)
-#pragma unroll
-                    for (int f = 0; f < NF; ++f) acc[r][f][m] = bs;
-            }
-            // (3) k-loop: (chunk, tap column) x input row x fragment; fragments are read D steps ahead of their MFMAs
-            constexpr int D = UVA_SW_D;
-            half8 bq[D + 1][NF];
-            auto rd = [&](int idx, half8 (&dst)[NF]) {      // idx = (c * 3 + dx) * NIR + ir
-                const int cd = idx / NIR, ir = idx - cd * NIR, c = cd / 3, dx = cd - 3 * c;
-#pragma unroll
-                for (int f = 0; f < NF; ++f) dst[f] = *(const half8*)(ring + rowb[ir] + offdx[dx] + c * (RC * 64) + f * 1024);
-            };
-            constexpr int NSTEP = KC * 3 * NIR;
-            __builtin_amdgcn_sched_barrier(0);                       // nothing else's LDS reads count as the pipeline's
-#pragma unroll
-            for (int i = 0; i < D; ++i) rd(i, bq[i]);
-            __builtin_amdgcn_sched_group_barrier(0x100, D * NF, 0);  // (the pipeline below counts its own reads only)
-            static_for<NSTEP>([&](auto I) {
-                constexpr int idx = decltype(I)::value;
-                constexpr int cd = idx / NIR, ir = idx - cd * NIR, c = cd / 3, dx = cd - 3 * c;
-                if constexpr (idx + D < NSTEP) rd(idx + D, bq[(idx + D) % (D + 1)]);
-                constexpr int ndy = (ir < 3 ? ir + 1 : 3) - (ir >= SW_R ? ir - SW_R + 1 : 0);     // tap rows with an output row in the block
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    const int r = ir - dy;
-                    if (r < 0 || r >= SW_R) continue;
-#pragma unroll
-                    for (int f = 0; f < NF; ++f)
-#pragma unroll
-                        for (int m = 0; m < MBW; ++m)
-                            acc[r][f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wgt[dy * 3 + dx][c][m], bq[idx % (D + 1)][f], acc[r][f][m], 0, 0, 0);
-                }
-                if constexpr (idx + D < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, NF, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, ndy * NF * MBW, 0);
+        f32x4 accA[SW_R][NF][MBW], accB[SW_R][NF][MBW];
+        // one iteration: the DMA of block b+1's rows, the k-loop of block b into `cur`, the epilogue of block b-1 from `prev`
+        // (its tiles' other operands replaced by block b's as they are used).  Exactly NT stores and NLD loads follow the
+        // DMA pieces, so "all but the newest NT + NLD memory operations have completed" proves the DMA (operations
+        // complete in issue order) and leaves the stores and the loads in flight across the barrier.
+        auto iteration = [&](f32x4 (&cur)[SW_R][NF][MBW], f32x4 (&prev)[SW_R][NF][MBW], const int b) {
+            if (UVA_SW_DBG < 2)
+                for (int rr = 0; rr < SW_R; ++rr) dma_row(c0, y0, SW_R * (b + 1) + 2 + rr);      // (past the last block: rows nobody reads)
+            kloop(cur, b, [&](auto J) {
+                epi_tile(J, prev, c0, y0, y1, b - 1);
+                load_res(decltype(J)::value, c0, y0, y1, b);
             });
-            __builtin_amdgcn_sched_barrier(0);
-            // (4) LeakyReLU (ncnn activation_type 2), fp16, the fused sum, 8-byte stores: lane (o, p) holds channels
-            // 16(mb0 + m) + 4o .. +3 of pixel (y0 + 4b + r, c0 + cw + 16f + p)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(UVA_SW_DBG >= 1 ? 0 : NT + NLD) : "memory");
+        };
+        // block 0: nothing to finish yet; its operands are fetched up front
+        if (UVA_SW_DBG < 2)
+            for (int rr = 0; rr < SW_R; ++rr) dma_row(c0, y0, SW_R + 2 + rr);
 #pragma unroll
-            for (int m = 0; m < MBW; ++m) {
-                const int ch = 16 * (mb0 + m) + 4 * o;
-#pragma unroll
-                for (int r = 0; r < SW_R; ++r)
-#pragma unroll
-                    for (int f = 0; f < NF; ++f) {
-                        f32x4 v = acc[r][f][m];
-                        if constexpr (ACT) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * a.slope;
-                        }
-                        half4 cv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                        if (a.res) {
-                            const half4 rv = rsv[r][f][m];
-                            const half4 xx = a.res_first ? rv : cv, yy = a.res_first ? cv : rv;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) cv[j] = g_axpby1((float)xx[j], a.ca, (float)yy[j], a.cb);
-                        }
-                        _Float16* const dst = (UVA_SW_DBG < 1 && inside[r][f]) ? a.out + pos[r][f] * a.out_stride + a.out_coff + ch : sink;
-                        if (UVA_SW_DBG >= 1) { asm volatile("" :: "v"(acc[r][f][m])); continue; }
-                        asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(cv) : "memory");
-                    }
-            }
-            // (5) everything but this block's NST stores has landed (memory operations complete in issue order: the DMA
-            // pieces and the loads are older), LDS drained; the stores stay in flight across the barrier
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(UVA_SW_DBG >= 1 ? 0 : NST) : "memory");
+        for (int j = 0; j < NT; ++j) load_res(j, c0, y0, y1, 0);
+        kloop(accA, 0, [](auto) {});
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(UVA_SW_DBG >= 1 ? 0 : NLD) : "memory");
+        int b = 1;
+        for (; b + 1 < nblk; b += 2) {
+            iteration(accB, accA, b);
+            iteration(accA, accB, b + 1);
+        }
+        if (b < nblk) {
+            iteration(accB, accA, b);
+            static_for<NT>([&](auto J) { epi_tile(J, accB, c0, y0, y1, nblk - 1); });
+        } else {
+            static_for<NT>([&](auto J) { epi_tile(J, accA, c0, y0, y1, nblk - 1); });
         }
     }
 }
@@ -320,18 +370,24 @@ __global__ __launch_bounds__(256, 1) void rdb4_kernel(RdbArgs a)
         const int k = threadIdx.x >> 5, c = threadIdx.x & 31;
         prm[threadIdx.x] = (k == 0 ? a.b1 : k == 1 ? a.b2 : k == 2 ? a.b3 : a.b4)[c];
     }
-    // per-lane LDS offsets: B fragments (three tap columns) and this lane's 8 bytes of a result pixel (channel block m)
+    // per-lane LDS offsets: B fragments (three tap columns) and this lane's 8 bytes of a result pixel (channel block m).
+    // Recomputed from the lane id at every step (lane_offsets(opaque(lane))): as loop invariants they are hoisted and,
+    // with the weights filling the register file, spilled to scratch -- whose reloads would wait for the stores in flight.
     unsigned offdx[3], wroff[2];
+    auto lane_offsets = [&](const int ln) {
+        const int oo = ln >> 4, pp = ln & 15;
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-        const int rc = p + dx;
-        offdx[dx] = (unsigned)(rc * 64 + ((o ^ (((rc >> 2) & 1) << 1)) * 16));
-    }
+        for (int dx = 0; dx < 3; ++dx) {
+            const int rc = pp + dx;
+            offdx[dx] = (unsigned)(rc * 64 + ((oo ^ (((rc >> 2) & 1) << 1)) * 16));
+        }
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int rc = p + 1, u = 2 * m + (o >> 1);
-        wroff[m] = (unsigned)(rc * 64 + ((u ^ (((rc >> 2) & 1) << 1)) * 16) + (o & 1) * 8);
-    }
+        for (int m = 0; m < 2; ++m) {
+            const int rc = pp + 1, u = 2 * m + (oo >> 1);
+            wroff[m] = (unsigned)(rc * 64 + ((u ^ (((rc >> 2) & 1) << 1)) * 16) + (oo & 1) * 8);
+        }
+    };
+    lane_offsets(lane);
     const unsigned smem_lds = lds_offset(smem);
     const size_t pitch = (size_t)(a.w + 2) * a.stride;               // elements per array row
     _Float16* const sink = a.sink + lane * 4;
@@ -345,7 +401,7 @@ __global__ __launch_bounds__(256, 1) void rdb4_kernel(RdbArgs a)
                       : RA_X3_OFF + (unsigned)(q % RA_3S) * RA_CHB;
     };
     // k-steps [K0, K1) of a convolution whose k-step k = chunk * 9 + tap reads chunk 0, 1 = x, 2.. = x1.. ; row q
-    auto kpart = [&](auto K0c, auto K1c, const auto& wg, f32x4 (&acc)[RA_NF][2], const int q) {
+    auto kpart = [&](auto K0c, auto K1c, const auto& wg, f32x4 (&acc)[RA_NF][2], const int q, auto&& side) {
         constexpr int K0 = decltype(K0c)::value, K1 = decltype(K1c)::value, N = K1 - K0, D = 2;
         constexpr int G0 = (K0 / 9 < 2) ? 0 : K0 / 9 - 1, G1 = ((K1 - 1) / 9 < 2) ? 0 : (K1 - 1) / 9 - 1;
         unsigned ra[4][3];
@@ -373,9 +429,13 @@ __global__ __launch_bounds__(256, 1) void rdb4_kernel(RdbArgs a)
                     acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wg[i][m], bq[i % (D + 1)][f], acc[f][m], 0, 0, 0);
             if constexpr (i + D < N) __builtin_amdgcn_sched_group_barrier(0x100, RA_NF, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, RA_NF * 2, 0);
+            // the previous part's epilogue, one tile behind every second k-step: VALU, LDS writes and stores that the
+            // scheduler may place between this part's MFMAs (no LDS READS in there: they would count as the pipeline's)
+            if constexpr ((i & 1) && i / 2 < RA_NF * 2) side(std::integral_constant<int, i / 2>{});
         });
         __builtin_amdgcn_sched_barrier(0);
     };
+    auto no_side = [](auto) {};
     auto acc_bias = [&](f32x4 (&acc)[RA_NF][2], int conv) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -406,10 +466,11 @@ __global__ __launch_bounds__(256, 1) void rdb4_kernel(RdbArgs a)
 #pragma unroll
             for (int m = 0; m < 2; ++m) *(f32x4*)(pb + (f * 2 + m) * 1024) = acc[f][m];
     };
+    // LeakyReLU with a slope in (0, 1) (the host checks) is max(v, slope * v); then fp16
     auto lrelu16 = [&](const f32x4 v) -> half4 {
         half4 r;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = (_Float16)(v[j] > 0.f ? v[j] : v[j] * a.slope);
+        for (int j = 0; j < 4; ++j) r[j] = (_Float16)__builtin_fmaxf(v[j], v[j] * a.slope);
         return r;
     };
     auto weights = [&](auto K0c, auto K1c, auto NCHc, const half8* wpk, auto& wg) {
@@ -426,33 +487,42 @@ __global__ __launch_bounds__(256, 1) void rdb4_kernel(RdbArgs a)
     const int sb = a.seg_begin[blockIdx.x], se = a.seg_begin[blockIdx.x + 1];
     __syncthreads();
 
-    // result row `row` of convolution `conv` (1..4): value v16 (4 channels of this lane's pixel per tile) -> zero outside
-    // the plane -> the ring (conv < 4) and, for the segment's own rows and columns, the array
-    auto emit = [&](const half4 (&v16)[RA_NF][2], const int conv, const int row, const int q, const RdbSeg& sg) {
-        if (UVA_RA_DBG & 2) {
-#pragma unroll
-            for (int f = 0; f < RA_NF; ++f)
-#pragma unroll
-                for (int m = 0; m < 2; ++m) asm volatile("" ::"v"(v16[f][m]));
-            return;
-        }
-        const bool row_in = row >= 0 && row < a.h, row_own = row >= sg.yb && row < sg.ye;
-        char* const rbase = smem + (conv == 1 ? rowaddr(1, q) : conv == 2 ? rowaddr(2, q) : rowaddr(3, q));
-        _Float16* const grow = a.arr + (size_t)(row + 1) * pitch + 64 + 32 * (conv - 1) + 4 * o;
+    // Per segment and lane: which of its three pixels (fragment f) are inside the plane (bit f) and the segment's own
+    // (bit 4 + f), and where its 8 bytes of channel block m go in the array's row (without the row and fragment terms).
+    unsigned pmask = 0;
+    _Float16* gptr[2];
+    auto seg_setup = [&](const RdbSeg& sg) {
+        pmask = 0;
 #pragma unroll
         for (int f = 0; f < RA_NF; ++f) {
             const int x = sg.c0 + 16 * f + p;
-            const bool in = row_in && x < a.w;
-            const bool own = row_own && in && x >= sg.own0 && x < sg.own1;
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                half4 v = v16[f][m];
-                if (!in) v = half4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
-                if (conv < 4) *(half4*)(rbase + wroff[m] + f * 1024) = v;
-                _Float16* const dst = own ? grow + (size_t)(x + 1) * a.stride + 16 * m : sink;
-                if (!(UVA_RA_DBG & 1)) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
-            }
+            pmask |= (x < a.w ? 1u : 0u) << f;
+            pmask |= (x < a.w && x >= sg.own0 && x < sg.own1 ? 1u : 0u) << (4 + f);
         }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) gptr[m] = a.arr + (size_t)(sg.c0 + p + 1) * a.stride + 64 + 16 * m + 4 * o;
+    };
+    struct RowOut { unsigned rbase; size_t goff; unsigned keep; };     // keep: pmask's bits that count for this row
+    // result row `row` (ring row q) of convolution `conv` (1..4)
+    auto row_out = [&](const int conv, const int row, const int q, const RdbSeg& sg) -> RowOut {
+        RowOut r;
+        r.rbase = conv == 1 ? rowaddr(1, q) : conv == 2 ? rowaddr(2, q) : rowaddr(3, q);
+        r.goff = (size_t)(row + 1) * pitch + 32 * (conv - 1);
+        r.keep = ((row >= 0) & (row < a.h) ? 0x0fu : 0u) | ((row >= sg.yb) & (row < sg.ye) ? 0xf0u : 0u);
+        return r;
+    };
+    // one tile (fragment f, channel block m) of a result row: zero outside the plane -> the ring (conv < 4) and, for the
+    // segment's own rows and columns, the array.  Always exactly one store (lanes that own nothing -> the sink).
+    auto emit = [&](const half4 v16, auto Jc, const int conv, const RowOut& r) {
+        constexpr int j = decltype(Jc)::value, f = j >> 1, m = j & 1;
+        if (UVA_RA_DBG & 2) { asm volatile("" ::"v"(v16)); return; }
+        const unsigned pm = pmask & r.keep;
+        const bool in = (pm >> f) & 1, own = (pm >> (4 + f)) & 1;
+        const uint2 raw = __builtin_bit_cast(uint2, v16);
+        const half4 v = __builtin_bit_cast(half4, make_uint2(in ? raw.x : 0u, in ? raw.y : 0u));
+        if (conv < 4) *(half4*)(smem + r.rbase + wroff[m] + f * 1024) = v;
+        _Float16* const dst = own ? gptr[m] + r.goff + (size_t)(16 * f) * a.stride : sink;
+        if (!(UVA_RA_DBG & 1)) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
     };
 
     // x row `row` -> ring row q, by LDS-DMA (wave 3 only): rows outside [-1, h] come from the array's zero border row
@@ -479,36 +549,39 @@ __global__ __launch_bounds__(256, 1) void rdb4_kernel(RdbArgs a)
     // Every wave runs the same sequence of barriers: two per segment, then one per step.  The segment loop sits INSIDE a
     // wave's role so that its weights are fetched once per launch and stay where they are.
 #define RA_STEP_BARRIER() asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((UVA_RA_DBG & 3) ? 0 : 2 * RA_NF) : "memory")
+    // k-step ranges: conv1 [0,18) and conv2 [0,16) on wave 0; conv2 [16,27) + the 1x1 and conv3 [0,21) on wave 1; conv3
+    // [21,36) and conv4 [0,19) on wave 2; conv4 [19,45) on wave 3 -- 34, 34, 34 and 26 k-steps: wave 3's epilogue (the
+    // residual from LDS, nothing to hide it behind) and the DMA make up for the difference.
     if (wave == 0) {
-        half8 wa[18][2], wb[14][2];
+        half8 wa[18][2], wb[16][2];
         weights(IC(0), IC(18), IC(2), a.w1, wa);
-        weights(IC(0), IC(14), IC(3), a.w2, wb);
+        weights(IC(0), IC(16), IC(3), a.w2, wb);
         for (int si = sb; si < se; ++si) {
             const RdbSeg sg = a.segs[si];
             const int R0 = sg.yb - 3, nsteps = sg.ye - sg.yb + RA_LAG;      // conv1's row at step 0; ring row index q = row - R0 + 8
+            seg_setup(sg);
             sw_barrier();
             sw_barrier();
 #pragma clang loop unroll(disable)
             for (int s = 0; s < nsteps; ++s) {
-                f32x4 acc[RA_NF][2];
+                lane_offsets(opaque(lane));
+                f32x4 acc[RA_NF][2], acc2[RA_NF][2];
                 acc_bias(acc, 0);
-                kpart(IC(0), IC(18), wa, acc, s + 8);
-                half4 v16[RA_NF][2];
-#pragma unroll
-                for (int f = 0; f < RA_NF; ++f)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) v16[f][m] = lrelu16(acc[f][m]);
-                emit(v16, 1, R0 + s, s + 8, sg);
-                acc_bias(acc, 1);
-                kpart(IC(0), IC(14), wb, acc, s + 7);
-                acc_store(acc, 0, s & 1);
+                acc_bias(acc2, 1);
+                kpart(IC(0), IC(18), wa, acc, s + 8, no_side);
+                const RowOut ro = row_out(1, R0 + s, s + 8, sg);
+                kpart(IC(0), IC(16), wb, acc2, s + 7, [&](auto J) {
+                    constexpr int j = decltype(J)::value;
+                    emit(lrelu16(acc[j >> 1][j & 1]), J, 1, ro);
+                });
+                acc_store(acc2, 0, s & 1);
                 RA_STEP_BARRIER();
             }
         }
     } else if (wave == 1) {
-        half8 wa[13][2], ws[2][2], wb[17][2];
-        weights(IC(14), IC(27), IC(3), a.w2, wa);
-        weights(IC(0), IC(17), IC(4), a.w3, wb);
+        half8 wa[11][2], ws[2][2], wb[21][2];
+        weights(IC(16), IC(27), IC(3), a.w2, wa);
+        weights(IC(0), IC(21), IC(4), a.w3, wb);
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -516,80 +589,78 @@ __global__ __launch_bounds__(256, 1) void rdb4_kernel(RdbArgs a)
         for (int si = sb; si < se; ++si) {
             const RdbSeg sg = a.segs[si];
             const int R0 = sg.yb - 3, nsteps = sg.ye - sg.yb + RA_LAG;
+            seg_setup(sg);
             sw_barrier();
             sw_barrier();
 #pragma clang loop unroll(disable)
             for (int s = 0; s < nsteps; ++s) {
-                f32x4 acc[RA_NF][2];
-                acc_load(acc, 0, (s + 1) & 1);
-                kpart(IC(14), IC(27), wa, acc, s + 6);
-                half4 c3[RA_NF][2];
-#pragma unroll
-                for (int f = 0; f < RA_NF; ++f)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) c3[f][m] = lrelu16(acc[f][m]);
-                // the 1x1 convolution of x, same row: centre tap of both chunks (the accumulators are free again)
+                lane_offsets(opaque(lane));
+                f32x4 acc[RA_NF][2], side[RA_NF][2], acc2[RA_NF][2];
+                // the 1x1 convolution of x (no bias), row s-2: centre tap of both chunks
                 {
                     const unsigned rx = rowaddr(0, s + 6);
 #pragma unroll
                     for (int f = 0; f < RA_NF; ++f)
 #pragma unroll
-                        for (int m = 0; m < 2; ++m) acc[f][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        for (int m = 0; m < 2; ++m) side[f][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int c = 0; c < 2; ++c)
 #pragma unroll
                         for (int f = 0; f < RA_NF; ++f) {
                             const half8 b = *(const half8*)(smem + rx + c * RA_CHB + offdx[1] + f * 1024);
 #pragma unroll
-                            for (int m = 0; m < 2; ++m) acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ws[c][m], b, acc[f][m], 0, 0, 0);
+                            for (int m = 0; m < 2; ++m) side[f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ws[c][m], b, side[f][m], 0, 0, 0);
                         }
                 }
-                half4 v16[RA_NF][2];
+                acc_load(acc, 0, (s + 1) & 1);
+                acc_bias(acc2, 2);
+                kpart(IC(16), IC(27), wa, acc, s + 6, no_side);
+                const RowOut ro = row_out(2, R0 + s - 2, s + 6, sg);
+                kpart(IC(0), IC(21), wb, acc2, s + 5, [&](auto J) {
+                    constexpr int j = decltype(J)::value;
+                    const half4 c3 = lrelu16(acc[j >> 1][j & 1]);
+                    half4 v;
 #pragma unroll
-                for (int f = 0; f < RA_NF; ++f)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v16[f][m][j] = g_axpby1((float)c3[f][m][j], 1.f, (float)(_Float16)acc[f][m][j], 1.f);
-                emit(v16, 2, R0 + s - 2, s + 6, sg);
-                acc_bias(acc, 2);
-                kpart(IC(0), IC(17), wb, acc, s + 5);
-                acc_store(acc, 1, s & 1);
+                    for (int e = 0; e < 4; ++e) v[e] = g_axpby1((float)c3[e], 1.f, (float)(_Float16)side[j >> 1][j & 1][e], 1.f);
+                    emit(v, J, 2, ro);
+                });
+                acc_store(acc2, 1, s & 1);
                 RA_STEP_BARRIER();
             }
         }
     } else if (wave == 2) {
-        half8 wa[19][2], wb[13][2];
-        weights(IC(17), IC(36), IC(4), a.w3, wa);
-        weights(IC(0), IC(13), IC(5), a.w4, wb);
+        half8 wa[15][2], wb[19][2];
+        weights(IC(21), IC(36), IC(4), a.w3, wa);
+        weights(IC(0), IC(19), IC(5), a.w4, wb);
         for (int si = sb; si < se; ++si) {
             const RdbSeg sg = a.segs[si];
             const int R0 = sg.yb - 3, nsteps = sg.ye - sg.yb + RA_LAG;
+            seg_setup(sg);
             sw_barrier();
             sw_barrier();
 #pragma clang loop unroll(disable)
             for (int s = 0; s < nsteps; ++s) {
-                f32x4 acc[RA_NF][2];
+                lane_offsets(opaque(lane));
+                f32x4 acc[RA_NF][2], acc2[RA_NF][2];
                 acc_load(acc, 1, (s + 1) & 1);
-                kpart(IC(17), IC(36), wa, acc, s + 4);
-                half4 v16[RA_NF][2];
-#pragma unroll
-                for (int f = 0; f < RA_NF; ++f)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) v16[f][m] = lrelu16(acc[f][m]);
-                emit(v16, 3, R0 + s - 4, s + 4, sg);
-                acc_bias(acc, 3);
-                kpart(IC(0), IC(13), wb, acc, s + 3);
-                acc_store(acc, 2, s & 1);
+                acc_bias(acc2, 3);
+                kpart(IC(21), IC(36), wa, acc, s + 4, no_side);
+                const RowOut ro = row_out(3, R0 + s - 4, s + 4, sg);
+                kpart(IC(0), IC(19), wb, acc2, s + 3, [&](auto J) {
+                    constexpr int j = decltype(J)::value;
+                    emit(lrelu16(acc[j >> 1][j & 1]), J, 3, ro);
+                });
+                acc_store(acc2, 2, s & 1);
                 RA_STEP_BARRIER();
             }
         }
     } else {
-        half8 wa[32][2];
-        weights(IC(13), IC(45), IC(5), a.w4, wa);
+        half8 wa[26][2];
+        weights(IC(19), IC(45), IC(5), a.w4, wa);
         for (int si = sb; si < se; ++si) {
             const RdbSeg sg = a.segs[si];
             const int R0 = sg.yb - 3, nsteps = sg.ye - sg.yb + RA_LAG;
+            seg_setup(sg);
             dma_setup(sg);
             sw_barrier();                                           // the previous segment is done with the rings
             dma_x(R0 - 1, R0);
@@ -598,23 +669,27 @@ __global__ __launch_bounds__(256, 1) void rdb4_kernel(RdbArgs a)
             sw_barrier();
 #pragma clang loop unroll(disable)
             for (int s = 0; s < nsteps; ++s) {
+                lane_offsets(opaque(lane));
                 if (!(UVA_RA_DBG & 4)) dma_x(R0 + s + 2, R0);
                 f32x4 acc[RA_NF][2];
-                acc_load(acc, 2, (s + 1) & 1);
-                kpart(IC(13), IC(45), wa, acc, s + 2);
-                // + x2 of the same pixels (BinaryOp Add_14), from its ring
+                // x2 of the same pixels (BinaryOp Add_14), from its ring, fetched ahead of the k-loop
                 const char* const r2 = smem + rowaddr(2, s + 2);
-                half4 v16[RA_NF][2];
+                half4 x2[RA_NF][2];
 #pragma unroll
                 for (int f = 0; f < RA_NF; ++f)
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) {
-                        const half4 c4 = lrelu16(acc[f][m]);
-                        const half4 x2 = *(const half4*)(r2 + wroff[m] + f * 1024);
+                    for (int m = 0; m < 2; ++m) x2[f][m] = *(const half4*)(r2 + wroff[m] + f * 1024);
+                acc_load(acc, 2, (s + 1) & 1);
+                kpart(IC(19), IC(45), wa, acc, s + 2, no_side);
+                const RowOut ro = row_out(4, R0 + s - 6, s + 2, sg);
+                static_for<RA_NF * 2>([&](auto J) {
+                    constexpr int j = decltype(J)::value;
+                    const half4 c4 = lrelu16(acc[j >> 1][j & 1]);
+                    half4 v;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v16[f][m][j] = g_axpby1((float)c4[j], 1.f, (float)x2[j], 1.f);
-                    }
-                emit(v16, 4, R0 + s - 6, s + 2, sg);
+                    for (int e = 0; e < 4; ++e) v[e] = g_axpby1((float)c4[e], 1.f, (float)x2[j >> 1][j & 1][e], 1.f);
+                    emit(v, J, 4, ro);
+                });
                 RA_STEP_BARRIER();
             }
         }

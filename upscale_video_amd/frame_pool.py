@@ -320,6 +320,12 @@ class FramePool:
             self.next_id += 1
             pending[tid] = t
             wire = {k: v for k, v in t.items() if k not in ("log_ok", "log_error")}   # callables stay here
+            # The workers keep the directory they were spawned in; the caller does not (the reference's orchestrator
+            # changes into every file's temp dir, upscale/upscale_processing.py:842, back at :971, and hands out names
+            # relative to it): paths are made absolute HERE, against the caller's directory at the time of the call.
+            for key in ("src", "dst", "model_path"):
+                if wire.get(key):
+                    wire[key] = os.path.abspath(wire[key])
             wire["id"] = tid
             self.task_q.put(wire)
         done = 0
