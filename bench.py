@@ -181,6 +181,8 @@ def main():
                     help="reference tile size; 0 = whole frame.  Default: what the reference does for the workload's model -- "
                          "960 (upscale_image, :499-516) for the 2x / 4x nets, 0 (apply_model, whole frame, :263-288) for the 1x net")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="skip the 128x96 parity probe (profiling runs: every launch in the trace is then a full-size one)")
     args = ap.parse_args()
 
     import torch
@@ -349,7 +351,8 @@ def main():
             if pre is None:
                 ref_out = net.process_u8(host_in, tile_size=args.tile, border=10)
                 assert np.array_equal(pin_out[(n_host - 1) % depth], ref_out), "pipelined host route differs from the synchronous one"
-            result["parity"] = parity_probe(net, key, args.tile) if pre is None else chain_parity_probe(pre, net)
+            if not args.no_parity:
+                result["parity"] = parity_probe(net, key, args.tile) if pre is None else chain_parity_probe(pre, net)
             if not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(key, h, w, args.tile)
         print(json.dumps(result), flush=True)

@@ -52,7 +52,9 @@ def time_pool(gpu_list, scale, runs, png):
     used = workers_spawned_so_far()        # 0 + 1 in a fresh process; later pools of a long-lived caller continue the count
     workers = mp.get_context("spawn").Pool(
         len(gpu_list), init_worker, (gpu_list, used, models, "x_Compact_Pretrain", scale, "input", "output"))
-    for line in ("", "Starting test runs", RULE):
+    for line in ("", "Starting test runs", RULE,
+                 "(what is timed, as in the reference's harness: every run's PNG decode and worker start-up -- the pool's spawn "
+                 "and model load fall inside the total; a host-side figure, not the GPUs' rate, which is bench.py's)", RULE):
         logging.info(line)
     t0 = time.perf_counter()
     for _ in range(runs):

@@ -80,6 +80,23 @@ def test_two_batches_from_two_directories_on_one_pool(fake, tmp_path, monkeypatc
     assert not [f for f in os.listdir(fake) if f.endswith(".png")]
 
 
+def test_persistent_route_reports_the_tile_lines(fake, caplog):
+    """upscale_image logs one "Processing Tile: i/n" debug item per reference tile before the frame's progress line
+    (upscale/upscale_processing.py:507, :524-540); the persistent route builds them from the size the worker decoded."""
+    import logging
+    _imageio.imwrite("1.extract.png", _frame(1, h=7, w=23))
+    up_tile = up.TILE_SIZE
+    try:
+        up.TILE_SIZE = 10                 # 3 x 1 tiles
+        with caplog.at_level(logging.DEBUG):
+            up.upscale_frames(None, 1, 1, "extract", 2, [0], 0, fake, "x_fake", "input", "output")
+    finally:
+        up.TILE_SIZE = up_tile
+    msgs = [r.getMessage() for r in caplog.records]
+    assert [m for m in msgs if m.startswith("Processing Tile")] == ["Processing Tile: %d/3" % i for i in (1, 2, 3)]
+    assert msgs.index("Processing Tile: 3/3") < msgs.index("Upscaled 1/1")
+
+
 def test_process_model_then_upscale_chain(fake):
     for n in (1, 2, 3):
         _imageio.imwrite("%d.extract.png" % n, _frame(n))

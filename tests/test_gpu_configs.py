@@ -170,3 +170,32 @@ def test_narrow_strip_kloop_equals_the_full_one():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "narrow_check.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "differing: none" in r.stdout
+
+
+@pytest.mark.gpu
+def test_bench_under_torch_distributed_run_one_rank(tmp_path):
+    """the N > 1 code path of bench.py -- RCCL process group, the barrier + max-reduce around both
+    timed regions, NUMA pinning, the per-rank host route -- run on the GPU box before the driver's scaling run does:
+    `python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`, one JSON line, and a frame rate within 10 % of
+    the same command without the launcher."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--gpus", "1", "--steps", "60", "--warmup", "10", "--no-cpu-baseline", "--no-parity"]
+
+    def last_json(out):
+        lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, out[-2000:]
+        return json.loads(lines[0])
+
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29531", os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["steps"] == 60
+    assert d["config"]["host_route_fps_pcie_inclusive"] > 0 and "roofline" in d and "parity" not in d
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, timeout=900, env=env)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-4000:]
+    d2 = last_json(r2.stdout)
+    assert abs(d["value"] - d2["value"]) <= 0.10 * d2["value"], (d["value"], d2["value"])

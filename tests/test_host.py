@@ -155,6 +155,25 @@ def test_mat_from_pixels_and_normalize_match_oracle(uva, oracle):
         uva.Mat.from_pixels(img, uva.Mat.PixelType.PIXEL_BGR, 9, 13)
 
 
+def test_extractor_takes_the_graph_s_blob_names(uva, tmp_path):
+    """ex.input / ex.extract check their names against the loaded graph's input and output blobs (the reference passes
+    model_input / model_output through, upscale_processing.py:72-73, :278-280), not against fixed strings."""
+    from upscale_video_amd import ncnn
+    p, _ = model_paths("1x")
+    assert ncnn._param_blob_names(p) == ("input", "output")
+    renamed = open(p).read().replace(" input", " data_in").replace("output", "result")
+    (tmp_path / "renamed.param").write_text(renamed)
+    assert ncnn._param_blob_names(str(tmp_path / "renamed.param")) == ("data_in", "result")
+    net = load_net(uva, "1x")
+    ex = net.create_extractor()
+    assert net.blob_names == ("input", "output")
+    assert ex.input("data", uva.Mat(np.zeros((3, 4, 4), np.float32))) == -1
+    assert ex.extract("output") == (-1, None)            # nothing was fed
+    net.blob_names = ("data_in", "result")               # as load_param of such a graph would have left it
+    assert ex.input("input", uva.Mat(np.zeros((3, 4, 4), np.float32))) == -1
+    assert ex.input("data_in", uva.Mat(np.zeros((3, 4, 4), np.float32))) == 0
+
+
 def test_compute_fails_loudly_without_gpu(uva):
     if uva.get_gpu_count() > 0:
         pytest.skip("a GPU is present")

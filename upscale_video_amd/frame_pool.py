@@ -194,6 +194,7 @@ class _Worker:
                 if err is not None:
                     self.finish(task, err)
                     continue
+                task["_shape"] = (int(img.shape[0]), int(img.shape[1]))     # for the caller's per-tile log lines
                 try:
                     key, net = self.net_for(task)
                     s = net.scale
@@ -254,7 +255,7 @@ class _Worker:
 
     def finish(self, task, err):
         self.resident.release()
-        self.result_q.put((task["id"], self.slot, None if err is None else "%s: %s" % (type(err).__name__, err)))
+        self.result_q.put((task["id"], self.slot, None if err is None else "%s: %s" % (type(err).__name__, err), task.get("_shape")))
 
     def run(self):
         t = threading.Thread(target=self.puller, daemon=True)
@@ -309,7 +310,8 @@ class FramePool:
 
     def run(self, tasks, callback=None, poll=0.2):
         """Queues `tasks` (dicts: src, dst, model_path, model_file, scale, tile_size, border, remove,
-        log) and blocks until every one of them has been reported.  `callback(log_items)` runs in the
+        log_ok -- a list of log items or a function of the decoded frame's (height, width) returning one --, log_error)
+        and blocks until every one of them has been reported.  `callback(log_items)` runs in the
         caller's thread once per frame, errors included.  Raises WorkerDied if a worker process ends
         while frames are outstanding (the frames it held are left for the next run)."""
         if self.closed:
@@ -331,7 +333,7 @@ class FramePool:
         done = 0
         while pending:
             try:
-                tid, slot, err = self.result_q.get(timeout=poll)
+                tid, slot, err, *rest = self.result_q.get(timeout=poll)
             except queue.Empty:
                 dead = [i for i, p in enumerate(self.procs) if not p.is_alive()]
                 if dead:
@@ -346,6 +348,8 @@ class FramePool:
                 continue        # a frame of an aborted earlier run
             done += 1
             items = task["log_error"](err) if err is not None else task["log_ok"]
+            if callable(items):     # log_ok(shape): the frame's (height, width) as the worker decoded it (None for stand-ins)
+                items = items(rest[0] if rest else None)
             if callback is not None:
                 callback(items)
         return done

@@ -164,20 +164,39 @@ class _Option:
         self.use_vulkan_compute = False  # accepted for source compatibility; HIP is always used
 
 
+def _param_blob_names(path):
+    """(input blob, output blob) of an ncnn text .param: the Input layer's top and the last layer's top (what the
+    reference passes as model_input / model_output, upscale_processing.py:72-73, always "input" / "output" there)."""
+    try:
+        with open(path) as f:
+            lines = [ln.split() for ln in f.read().splitlines()[2:] if len(ln.split()) >= 4]
+    except OSError:
+        return None
+    first_in = next((p for p in lines if p[0] == "Input"), None)
+    if first_in is None or not lines:
+        return None
+    last = lines[-1]
+    nin, nout = int(last[2]), int(last[3])
+    if nout < 1 or int(first_in[3]) < 1:
+        return None
+    return first_in[4 + int(first_in[2])], last[4 + nin + nout - 1]
+
+
 class Extractor:
     def __init__(self, net):
         self._net = net
         self._in = None
 
     def input(self, name, mat):
-        if name != "input":
+        """ex.input(model_input, mat): the name must be the loaded graph's input blob (:278, :450)"""
+        if name != self._net.blob_names[0]:
             return -1
         self._in = mat
         return 0
 
     def extract(self, name):
-        """-> (ret, Mat).  upscale_processing.py:280, :452"""
-        if name != "output" or self._in is None:
+        """-> (ret, Mat).  upscale_processing.py:280, :452; the name must be the loaded graph's output blob"""
+        if name != self._net.blob_names[1] or self._in is None:
             return -1, None
         out = self._net._extract(np.asarray(self._in))
         return 0, Mat(out)
@@ -199,10 +218,14 @@ class Net:
     def set_vulkan_device(self, device_index):
         _lib.check(self._L.uva_net_set_device(self._h, int(device_index)))
 
+    blob_names = ("input", "output")     # of the loaded graph (load_param)
+
     def load_param(self, path):
         rc = self._L.uva_net_load_param(self._h, str(path).encode())
         if rc:
             self.last_error = self._L.uva_last_error().decode()
+        else:
+            self.blob_names = _param_blob_names(str(path)) or ("input", "output")
         return rc
 
     def load_model(self, path):

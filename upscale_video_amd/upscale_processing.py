@@ -426,6 +426,15 @@ def upscale_image(input_file_name, output_file_name, scale, frame_batch, frame, 
     return logging_items
 
 
+def _tile_items(shape, tile_size=None):
+    """upscale_image's per-tile debug lines (:499-509) for a frame of `shape` = (height, width)"""
+    if not shape:
+        return []
+    ts = tile_size or TILE_SIZE
+    n = math.ceil(shape[1] / ts) * math.ceil(shape[0] / ts)
+    return [["debug", "Processing Tile: %d/%d" % (i, n)] for i in range(1, n + 1)]
+
+
 def _progress_item(frame_batch, frame, end_frame, output_file_name):
     """the reference's per-frame progress line (:524-540)"""
     if frame_batch:
@@ -449,11 +458,11 @@ def upscale_frames(frame_batch, start_frame, end_frame, input_file_tag, scale, g
             src = "%s.%s.png" % (frame, input_file_tag)
             dst = "%s.png" % frame
             if os.path.exists(src):
-                # the tile lines of upscale_image (:508) cannot be known before the PNG is decoded in the
-                # worker; the frame's progress line is what the orchestrator's log shows at info level
+                # upscale_image's items (:507, :524-540): one "Processing Tile: i/n" debug line per reference tile -- the
+                # worker reports the decoded frame's size with its result -- then the frame's progress line
                 tasks.append(dict(src=src, dst=dst, model_path=model_path, model_file=model_file, scale=scale,
                                   tile_size=TILE_SIZE, border=TILE_BORDER, remove=remove,
-                                  log_ok=[_progress_item(frame_batch, frame, end_frame, dst)],
+                                  log_ok=lambda shape, item=_progress_item(frame_batch, frame, end_frame, dst): _tile_items(shape) + [item],
                                   log_error=lambda e: [["error", "Upscale failed"], ["error", e]]))
         _run_persistent(gpus, tasks)
         return
