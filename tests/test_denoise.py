@@ -1,7 +1,8 @@
 """`-m n=K`: cv2.fastNlMeansDenoisingColored(img, None, K, K, 5, 9) restated
-(oracle/nlm_oracle.py) and on the MI355X (csrc/uva_denoise.hip.h).  The integer non-local-means stage must be
-bit-exact against the restatement; the fp32 Lab conversions within an LSB.  Parity with OpenCV itself is
-unpinned (not installable here) and is probed opportunistically."""
+(oracle/nlm_oracle.py) and on the MI355X (csrc/uva_denoise.hip.h).  Every stage is integer arithmetic -- the Lab
+conversions are OpenCV's fixed-point table code for 8-bit images, restated from memory -- and the kernels must be
+bit-exact against the restatement, stage by stage (the Lab stages on all 2^24 colours) and end to end.  Parity with
+OpenCV itself is unpinned (not installable here) and is probed opportunistically."""
 import ctypes
 import os
 
@@ -38,7 +39,7 @@ def test_restatement_properties():
     img = rng.integers(0, 256, (20, 23, 3), dtype=np.uint8)
     lab = no.bgr2lab(img)
     back = no.lab2bgr(lab)
-    assert np.abs(back.astype(int) - img.astype(int)).max() <= 3            # 8-bit Lab is lossy by a few LSB
+    assert np.abs(back.astype(int) - img.astype(int)).max() <= 5            # 8-bit Lab is lossy by a few LSB
     grey = np.repeat(rng.integers(0, 256, (9, 9, 1), dtype=np.uint8), 3, axis=2)
     g = no.bgr2lab(grey)
     assert np.abs(g[..., 1].astype(int) - 128).max() <= 1 and np.abs(g[..., 2].astype(int) - 128).max() <= 1
@@ -60,18 +61,33 @@ def test_nlm_stage_is_bit_exact(uva, h, w, strength):
     assert np.array_equal(_stage(uva, 3, noisy, strength), no.nlm_plane(noisy, strength))
 
 
-@pytest.mark.gpu
-def test_lab_conversions_within_an_lsb(uva):
+def test_table_code_against_the_cie_formulas():
+    """What the fixed-point path is worth against the colour science it encodes (measured, not
+    asserted), on all 2^24 colours: forward within 1 (L, b) / 2 (a) of the rounded CIE values; BGR -> Lab -> BGR
+    loses at most 5 levels (the linear inverse gamma table truncates); the inverse on identical Lab input is the
+    formulas' value or one below it."""
     from oracle import nlm_oracle as no
-    rng = np.random.default_rng(9)
-    img = rng.integers(0, 256, (64, 96, 3), dtype=np.uint8)
-    lab = _stage(uva, 0, img)
-    want = no.bgr2lab(img)
-    d = np.abs(lab.astype(int) - want.astype(int))
-    assert d.max() <= 1 and (d > 0).mean() < 0.01, (int(d.max()), float((d > 0).mean()))
-    back = _stage(uva, 1, want)
-    d = np.abs(back.astype(int) - no.lab2bgr(want).astype(int))
-    assert d.max() <= 1 and (d > 0).mean() < 0.01
+    g = np.arange(256, dtype=np.uint8)
+    img = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(256 * 256, 256, 3)
+    lab = no.bgr2lab(img)
+    d = np.abs(lab.astype(int) - no.bgr2lab_cie(img).astype(int)).reshape(-1, 3)
+    assert tuple(d.max(0)) <= (1, 2, 1) and (d > 0).mean() < 0.09
+    rt = np.abs(no.lab2bgr(lab).astype(int) - img.astype(int))
+    assert rt.max() <= 5 and (rt.max(-1) > 3).mean() < 0.001
+    di = no.lab2bgr_cie(lab).astype(int) - no.lab2bgr(lab).astype(int)
+    assert di.min() >= -1 and di.max() <= 1
+    assert no.lab_to_yf_b()[1].min() == 2260 and tuple(no.ab_to_xz(np.array([no.MIN_AB, no.LAB_BASE * 9 // 4 + no.MIN_AB - 1]))) == (-1335, 88231)
+
+
+@pytest.mark.gpu
+def test_lab_stages_are_bit_exact_on_every_colour(uva):
+    """COLOR_LBGR2Lab on all 2^24 BGR triples, COLOR_Lab2LBGR on all 2^24 Lab triples: kernel == restatement."""
+    from oracle import nlm_oracle as no
+    g = np.arange(256, dtype=np.uint8)
+    for k in range(0, 256, 32):                     # 32 planes of 256 x 256 colours per call
+        img = np.stack(np.meshgrid(g[k:k + 32], g, g, indexing="ij"), -1).reshape(32 * 256, 256, 3)
+        assert np.array_equal(_stage(uva, 0, img), no.bgr2lab(img)), k
+        assert np.array_equal(_stage(uva, 1, img), no.lab2bgr(img)), k
 
 
 @pytest.mark.gpu
@@ -91,8 +107,7 @@ def test_apply_denoise_end_to_end(uva, tmp_path, monkeypatch, oracle):
     assert items == [["info", "Processed Denoise: 1.denoise.png"]] and os.path.exists("1.extract.png")
     got = _imageio.imread("1.denoise.png")
     want = no.denoise_colored(frames[1], 3, 3)
-    d = np.abs(got.astype(int) - want.astype(int))
-    assert d.max() <= 3 and (d > 1).mean() < 0.01, (int(d.max()), float((d > 1).mean()))   # Lab round trips amplify an LSB
+    assert np.array_equal(got, want)                                                       # integer arithmetic end to end
     assert np.abs(got.astype(float) - frames[1]).mean() > 0.5                              # something was removed
     os.remove("1.denoise.png")
     n_workers = up.process_denoise(4, "extract", 3, remove=True, gpus=[0], workers_per_gpu=2)

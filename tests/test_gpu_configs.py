@@ -199,3 +199,96 @@ def test_bench_under_torch_distributed_run_one_rank(tmp_path):
     assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-4000:]
     d2 = last_json(r2.stdout)
     assert abs(d["value"] - d2["value"]) <= 0.10 * d2["value"], (d["value"], d2["value"])
+
+
+def _window_check(got, img, om_apply, rad, s, wins, win=24, max_lsb=2, min_psnr=50):
+    """locality: an output window equals the oracle run on the window plus `rad` pixels of context"""
+    h, w = img.shape[:2]
+    for (y0, x0) in wins:
+        cy0, cx0, cy1, cx1 = max(0, y0 - rad), max(0, x0 - rad), min(h, y0 + win + rad), min(w, x0 + win + rad)
+        want = om_apply(np.ascontiguousarray(img[cy0:cy1, cx0:cx1]))[(y0 - cy0) * s:(y0 - cy0 + win) * s, (x0 - cx0) * s:(x0 - cx0 + win) * s]
+        g = got[y0 * s:(y0 + win) * s, x0 * s:(x0 + win) * s]
+        d = np.abs(g.astype(int) - want.astype(int))
+        assert d.max() <= max_lsb and psnr_u8(g, want) >= min_psnr, ((y0, x0), int(d.max()), psnr_u8(g, want))
+
+
+def test_config3_chain_at_1080p(uva, net2x, oracle_models, oracle):
+    """BASELINE config 3 at its own size: 1920x1080 through the 1x HurrDeblur pass (whole frame, apply_model), the u8
+    hop, and the 2x net (whole frame here, so that a window's context is bounded) -- on the device without the hop
+    leaving HBM, equal to the host-route chain; windows at the corners, the centre and two edges against the oracle's
+    chain on the window plus the two nets' combined receptive radius; the reference-tiled result differs from it only
+    near the tile seams."""
+    pre = load_net(uva, "1x")
+    h, w = 1080, 1920
+    img = oracle.synthetic_frame(h, w, seed=33)
+    mid = pre.process_u8(img, tile_size=0)
+    whole = net2x.process_u8(mid, tile_size=0)
+    assert whole.shape == (2 * h, 2 * w, 3)
+    o1, o2 = oracle_models["1x"], oracle_models["2x"]
+    rad = pre.num_convs + net2x.num_convs
+    wins = [(0, 0), (0, w - 24), (h - 24, 0), (h - 24, w - 24), (h // 2, w // 2), (500, 0), (h - 24, 950)]
+    _window_check(whole, img, lambda c: o2.apply_model(o1.apply_model(c)), rad, 2, wins, max_lsb=3, min_psnr=48)
+    tiled = net2x.process_u8(mid, tile_size=960, border=10)
+    d = np.abs(tiled.astype(int) - whole.astype(int))
+    ys, xs = np.nonzero(d.max(axis=2))
+    assert d.max() <= 2 and ((np.abs(ys - 1920) <= 40) | (np.abs(xs - 1920) <= 40)).all()
+    if torch is not None and torch.cuda.is_available():
+        d_in = torch.from_numpy(img).cuda()
+        d_mid = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda")
+        d_out = torch.empty((2 * h, 2 * w, 3), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        pre.wait_for(net2x)
+        pre.process_u8_device(d_in.data_ptr(), h, w, d_mid.data_ptr(), tile_size=0)
+        net2x.wait_for(pre)
+        net2x.process_u8_device(d_mid.data_ptr(), h, w, d_out.data_ptr(), tile_size=960, border=10)
+        pre.synchronize()
+        net2x.synchronize()
+        assert np.array_equal(d_out.cpu().numpy(), tiled)
+
+
+def test_config4_valar_at_1080p(uva, tmp_path):
+    """BASELINE config 4 as named, once at full size under pytest (throughput: tools/valar_bench.py): 4x_Valar_v1,
+    synthetic weights (the real ones are a missing blob upstream), 1920x1080 -> 7680x4320 with the reference tiling.
+    Shape, finite and non-constant, and -- the tiling being a loop over independent planes -- the top-right tile's
+    part of the frame equals that tile run as a frame of its own (upscale_image's crop and paste, :464-477)."""
+    from oracle import generic_oracle as go
+    from upscale_video_amd import upscale_processing as up
+    from upscale_video_amd.synth import synthetic_frame
+    param = os.path.join(ROOT, "models", "4x_Valar_v1.param")
+    b = str(tmp_path / "4x_Valar_v1.bin")
+    go.write_synthetic_bin(param, b, seed=1, gain=0.5)
+    net = uva.Net()
+    net.set_vulkan_device(0)
+    assert net.load_param(param) == 0 and net.load_model(b) == 0, getattr(net, "last_error", "")
+    h, w = 1080, 1920
+    img = synthetic_frame(h, w, seed=4)
+    out = net.process_u8(img, tile_size=960, border=10)
+    assert out.shape == (4 * h, 4 * w, 3) and out.std() > 1
+    (y0, y1, x0, x1), (top, bottom, left, right) = up.tile_window(960, 1, 1, h, w)          # the 130 x 970 plane
+    tile = net.process_u8(np.ascontiguousarray(img[y0 - top:y1 + bottom, x0 - left:x1 + right]), tile_size=0)
+    assert np.array_equal(out[4 * y0:4 * y1, 4 * x0:4 * x1], tile[4 * top:4 * (top + y1 - y0), 4 * left:4 * (left + x1 - x0)])
+
+
+def test_frame_pool_four_workers_at_1080p(tmp_path, oracle, oracle_models, monkeypatch):
+    """The PNG route as config 5's harness line names it on one GPU, `-g 0,0,0,0`: eight 1920x1080 frames through
+    upscale_frames on the persistent workers (GPU-deflated PNGs), every result decoded again and checked against the
+    oracle on windows (corners, a tile seam, the centre); inputs gone, outputs complete."""
+    from upscale_video_amd import upscale_processing as up
+    from upscale_video_amd import _imageio
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(up, "PERSISTENT_WORKERS", True)
+    h, w = 1080, 1920
+    frames = {n: oracle.synthetic_frame(h, w, seed=700 + n) for n in range(1, 9)}
+    for n, f in frames.items():
+        _imageio.imwrite("%d.extract.png" % n, f)
+    try:
+        up.upscale_frames(1, 1, 8, "extract", 2, [0, 0, 0, 0], 0, os.path.join(ROOT, "models"), "x_Compact_Pretrain", "input", "output")
+    finally:
+        up.shutdown_workers()
+    om = oracle_models["2x"]
+    for n, f in frames.items():
+        assert not os.path.exists("%d.extract.png" % n)
+        out = _imageio.imread("%d.png" % n)
+        assert out is not None and out.shape == (2 * h, 2 * w, 3)
+        wins = [(0, 0), (h - 24, w - 24), (h // 2, w // 2 + 100)] if n > 1 else [(0, 0), (0, w - 24), (h - 24, 0), (h - 24, w - 24), (500, 1200), (100, 30)]
+        _window_check(out, f, om.apply_model, 18, 2, wins)

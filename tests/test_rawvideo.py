@@ -48,6 +48,24 @@ def test_stream_order_and_buffer_lifetimes_two_stages(nframes):
         assert np.array_equal(got[i], want), i
 
 
+@pytest.mark.parametrize("nlanes", [2, 3, 8])
+@pytest.mark.parametrize("nframes", [0, 1, 5, 16, 37])
+def test_several_workers_keep_frame_order_and_buffer_lifetimes(nlanes, nframes):
+    """`-g a,b,c`: one chain of nets per entry, frames dealt out round-robin, results written in frame order; every
+    net sees at most 3 frames in flight and intact input views (two-stage chains: the `-m a` case)."""
+    h, w = 6, 10
+    frames = _frames(nframes, h, w)
+    fin = io.BytesIO(b"".join(f.tobytes() for f in frames))
+    fout = io.BytesIO()
+    alloc = lambda shape: np.empty(shape, np.uint8)   # noqa: E731
+    lanes = [[(FakeNet(1), 0), (FakeNet(2), 960)] for _ in range(nlanes)]
+    assert rawvideo.stream(fin, fout, h, w, lanes, alloc=alloc) == nframes
+    got = np.frombuffer(fout.getvalue(), np.uint8).reshape(nframes, 2 * h, 2 * w, 3)
+    for i, f in enumerate(frames):
+        assert np.array_equal(got[i], np.repeat(np.repeat(f + 1, 2, 0), 2, 1) + 1), i
+    assert all(net.live == 0 for lane in lanes for net, _ in lane)
+
+
 def test_torn_last_frame_is_an_error():
     h, w = 4, 4
     fin = io.BytesIO(_frames(2, h, w)[0].tobytes() + b"\x00" * 10)
@@ -111,3 +129,7 @@ def test_stream_equals_per_frame_calls(tmp_path):
         assert d.max() <= 3 and (mse == 0 or 10 * np.log10(255.0 ** 2 / mse) >= 48), (i, int(d.max()))
         # ... and, bit for bit, against the synchronous per-frame calls of the same engine
         assert np.array_equal(got[i], net.process_u8(pre.process_u8(f), tile_size=32, border=10)), i
+    # two workers on the one GPU (`-g 0,0`, the reference's duplicate entries): same bytes, same order
+    dst2 = tmp_path / "out2.bgr24"
+    assert rawvideo.main(["-i", str(src), "-o", str(dst2), "-W", str(w), "-H", str(h), "-s", "2", "-m", "a", "--tile", "32", "-g", "0,0"]) == 0
+    assert dst2.read_bytes() == dst.read_bytes()

@@ -20,10 +20,10 @@ def wall(cmd, shell=False):
     return time.perf_counter() - t0
 
 
-for args in (["-s", "2"], ["-s", "2", "-m", "a"], ["-s", "4"], ["-s", "1", "-m", "a"]):
+for args in (["-s", "2"], ["-s", "2", "-g", "0,0"], ["-s", "2", "-m", "a"], ["-s", "2", "-m", "a", "-g", "0,0"], ["-s", "4"], ["-s", "1", "-m", "a"]):
     t1 = wall(base + args + ["-i", src, "-o", "/dev/null", "--frames", "1"])
     tn = wall(base + args + ["-i", src, "-o", "/dev/null"])
-    print(f"{' '.join(args):12s} file -> /dev/null : {N} frames in {tn:6.2f} s (start-up {t1:5.2f} s) = {(N - 1) / (tn - t1):7.1f} frames/s")
+    print(f"{' '.join(args):20s} file -> /dev/null : {N} frames in {tn:6.2f} s (start-up {t1:5.2f} s) = {(N - 1) / (tn - t1):7.1f} frames/s")
 t1 = wall(base + ["-s", "2", "-i", src, "-o", "/dev/null", "--frames", "1"])
 tn = wall(f"cat {src} | {' '.join(base)} -s 2 2>/dev/null | cat > /dev/null", shell=True)
 print(f"-s 2         pipe -> pipe      : {N} frames in {tn:6.2f} s = {(N - 1) / (tn - t1):7.1f} frames/s")

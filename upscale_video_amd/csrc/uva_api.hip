@@ -1571,6 +1571,7 @@ struct DenoiseCtx {
     int* d_table[2] = {nullptr, nullptr};
     int table_size[2] = {0, 0};
     float table_h[2] = {-1.f, -1.f};
+    LabTables* d_lab = nullptr;          // OpenCV's 8-bit Lab tables (uva_denoise.hip.h)
 };
 std::mutex g_denoise_mu;
 DenoiseCtx g_denoise[16];
@@ -1606,6 +1607,7 @@ void denoise_release_all()
             if (p) (void)hipFree(p);
         for (int* t : c.d_table)
             if (t) (void)hipFree(t);
+        if (c.d_lab) (void)hipFree(c.d_lab);
         if (c.stream) (void)hipStreamDestroy(c.stream);
         c = DenoiseCtx();
     }
@@ -1619,6 +1621,11 @@ int denoise_ctx(int device, size_t px, DenoiseCtx** out)
     HIP_TRY(hipSetDevice(device));
     DenoiseCtx& c = g_denoise[device];
     if (!c.stream) HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    if (!c.d_lab) {
+        static const LabTables host_tables = [] { LabTables t; lab_tables_host(t); return t; }();
+        HIP_TRY(hipMalloc((void**)&c.d_lab, sizeof(LabTables)));
+        HIP_TRY(hipMemcpy(c.d_lab, &host_tables, sizeof(LabTables), hipMemcpyHostToDevice));
+    }
     if (c.cap_px < px) {
         for (uint8_t** p : {&c.d_in, &c.d_out, &c.d_l, &c.d_l2, &c.d_ab, &c.d_ab2}) {
             if (*p) (void)hipFree(*p);
@@ -1668,10 +1675,10 @@ int uva_denoise_u8(int device, const uint8_t* in, int h, int w, size_t in_stride
     if (denoise_table(*c, 0, h_luma, 1) || denoise_table(*c, 1, h_color, 2)) return 1;
     HIP_TRY(hipMemcpy2DAsync(c->d_in, (size_t)w * 3, in, in_stride, (size_t)w * 3, h, hipMemcpyHostToDevice, c->stream));
     const dim3 rows((w + 255) / 256, h), tiles((w + NLM_BLK - 1) / NLM_BLK, (h + NLM_BLK - 1) / NLM_BLK);
-    hipLaunchKernelGGL(nlm_bgr2lab, rows, dim3(256), 0, c->stream, c->d_in, (size_t)w * 3, h, w, c->d_l, c->d_ab);
+    hipLaunchKernelGGL(nlm_bgr2lab, rows, dim3(256), 0, c->stream, c->d_in, (size_t)w * 3, h, w, c->d_l, c->d_ab, c->d_lab);
     hipLaunchKernelGGL(nlm_plane<1>, tiles, dim3(NLM_BLK * NLM_BLK), 0, c->stream, c->d_l, h, w, c->d_table[0], c->table_size[0], c->d_l2);
     hipLaunchKernelGGL(nlm_plane<2>, tiles, dim3(NLM_BLK * NLM_BLK), 0, c->stream, c->d_ab, h, w, c->d_table[1], c->table_size[1], c->d_ab2);
-    hipLaunchKernelGGL(nlm_lab2bgr, rows, dim3(256), 0, c->stream, c->d_l2, c->d_ab2, h, w, c->d_out, (size_t)w * 3);
+    hipLaunchKernelGGL(nlm_lab2bgr, rows, dim3(256), 0, c->stream, c->d_l2, c->d_ab2, h, w, c->d_out, (size_t)w * 3, c->d_lab);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy2DAsync(out, out_stride, c->d_out, (size_t)w * 3, (size_t)w * 3, h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1688,7 +1695,7 @@ int uva_debug_denoise_stage(int device, int stage, const uint8_t* in, int h, int
     const dim3 rows((w + 255) / 256, h), tiles((w + NLM_BLK - 1) / NLM_BLK, (h + NLM_BLK - 1) / NLM_BLK);
     if (stage == 0) {          // bgr [h][w][3] -> Lab interleaved [h][w][3]
         HIP_TRY(hipMemcpy(c->d_in, in, px * 3, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(nlm_bgr2lab, rows, dim3(256), 0, c->stream, c->d_in, (size_t)w * 3, h, w, c->d_l, c->d_ab);
+        hipLaunchKernelGGL(nlm_bgr2lab, rows, dim3(256), 0, c->stream, c->d_in, (size_t)w * 3, h, w, c->d_l, c->d_ab, c->d_lab);
         HIP_TRY(hipStreamSynchronize(c->stream));
         std::vector<uint8_t> l(px), ab(px * 2);
         HIP_TRY(hipMemcpy(l.data(), c->d_l, px, hipMemcpyDeviceToHost));
@@ -1699,7 +1706,7 @@ int uva_debug_denoise_stage(int device, int stage, const uint8_t* in, int h, int
         for (size_t i = 0; i < px; ++i) { l[i] = in[3 * i]; ab[2 * i] = in[3 * i + 1]; ab[2 * i + 1] = in[3 * i + 2]; }
         HIP_TRY(hipMemcpy(c->d_l, l.data(), px, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->d_ab, ab.data(), px * 2, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(nlm_lab2bgr, rows, dim3(256), 0, c->stream, c->d_l, c->d_ab, h, w, c->d_out, (size_t)w * 3);
+        hipLaunchKernelGGL(nlm_lab2bgr, rows, dim3(256), 0, c->stream, c->d_l, c->d_ab, h, w, c->d_out, (size_t)w * 3, c->d_lab);
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipMemcpy(out, c->d_out, px * 3, hipMemcpyDeviceToHost));
     } else if (stage == 2 || stage == 3) {   // NLM on a 1-channel (2) / 2-channel (3) u8 image

@@ -9,12 +9,15 @@
 //      round(F * exp(-(d * 32/25) / (h*h*channels))) with F = INT_MAX / (81 * 255) and weights below F/1000
 //      dropped, integer accumulation, rounded division by the weight sum;
 //   3. Lab -> BGR (COLOR_Lab2LBGR).
-// Step 2 is integer arithmetic and bit-exact against the numpy restatement the tests hold; steps 1 and 3 use the CIE formulas in
-// fp32 where OpenCV's 8-bit path uses fixed-point tables, so a frame can differ from OpenCV's by an LSB --
-// PARITY UNPINNED either way: opencv-python is not installable here.
+// All three steps are integer arithmetic (steps 1 and 3: OpenCV's fixed-point table code for 8-bit Lab, not the CIE
+// formulas) and bit-exact, end to end, against the numpy restatement the tests hold.  PARITY UNPINNED all the same:
+// opencv-python is not installable here, the table code is restated from memory, and the reference passes a cv2.UMat,
+// i.e. takes OpenCV's OpenCL branch where there is one.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <cmath>
 
 namespace uva {
 
@@ -32,47 +35,94 @@ __device__ __forceinline__ int reflect101(int i, int n)
     return i;
 }
 
-__device__ __forceinline__ float lab_f(float t) { return t > 0.008856f ? cbrtf(t) : 7.787f * t + 16.0f / 116.0f; }
+// ---- OpenCV's 8-bit Lab conversions: fixed-point table code, not the CIE formulas (modules/imgproc/src/color_lab.cpp:
+// RGB2Lab_b, Lab2RGBinteger, initLabTabs), restated from memory of the 4.x source -- oracle/nlm_oracle.py has the same
+// restatement in numpy and says what that is worth (PARITY UNPINNED).  Constants: lab_shift 12, gamma_shift 3,
+// lab_shift2 15, base_shift 14, inv_gamma_shift 12.
+constexpr int LAB_CBRT_TAB_SIZE_B = 256 * 3 / 2 * 8;
+struct LabTables {
+    int cbrt_tab[LAB_CBRT_TAB_SIZE_B];   // LabCbrtTab_b: round(32768 * f(i / (255 * 8)))
+    int fwd[9];                          // (X/Xn, Y, Z/Zn) from (R, G, B), << 12
+    int inv[9];                          // (R, G, B) from (x, y, z) with the white point folded in, << 12
+    int y_of_l[256], fy_of_l[256];       // LabToYF_b
+};
+inline void lab_tables_host(LabTables& t)
+{
+    // OpenCV builds these in softfloat / softdouble (IEEE, round to nearest even): plain float / double arithmetic, one
+    // operation per statement; mulAdd is a fused multiply-add (one rounding: through double); cv::cbrt -> libm's
+    const float scale = 1.0f / (255.0f * 8.0f), lthresh = 216.0f / 24389.0f, lscale = 841.0f / 108.0f, lbias = 16.0f / 116.0f;
+    for (int i = 0; i < LAB_CBRT_TAB_SIZE_B; ++i) {
+        const float x = scale * (float)i;
+        const float v = x < lthresh ? (float)((double)x * (double)lscale + (double)lbias) : (float)std::cbrt((double)x);
+        t.cbrt_tab[i] = (int)std::lrintf(32768.0f * v);
+    }
+    static const double rgb2xyz[9] = {0.412453, 0.357580, 0.180423, 0.212671, 0.715160, 0.072169, 0.019334, 0.119193, 0.950227};
+    static const double xyz2rgb[9] = {3.240479, -1.53715, -0.498535, -0.969256, 1.875991, 0.041556, 0.055648, -0.204043, 1.057311};
+    static const double d65[3] = {0.950456, 1.0, 1.088754};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            t.fwd[i * 3 + j] = (int)std::lrint(4096.0 * rgb2xyz[i * 3 + j] / d65[i]);
+            t.inv[i * 3 + j] = (int)std::lrint(4096.0 * xyz2rgb[i * 3 + j] * d65[j]);
+        }
+    const int base = 1 << 14;
+    for (int i = 0; i < 256; ++i) {
+        if (i <= 20) {
+            const float a = (float)(i * base * 20 * 9), b = (float)(17 * 29 * 29 * 29);
+            t.y_of_l[i] = (int)std::lrintf(a / b);
+            const float c = 16.0f / 116.0f, d = (float)(i * 5) / (float)(3 * 17 * 29), e = c + d;
+            t.fy_of_l[i] = (int)std::lrintf((float)base * e);
+        } else {
+            const float a = (float)(i * 100 * base) / (float)(255 * 116), b = (float)(16 * base) / 116.0f, fy = a + b;
+            t.fy_of_l[i] = (int)std::lrintf(fy);
+            const float f2 = fy * fy, f3 = f2 * fy;
+            t.y_of_l[i] = (int)std::lrintf(f3 / (float)(base * base));
+        }
+    }
+}
+__device__ __forceinline__ int lab_descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+__device__ __forceinline__ int lab_sat8(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
+// abToXZ_b[v - minABvalue]: C integer arithmetic (division towards zero), computed instead of looked up
+__device__ __forceinline__ int lab_ab_to_xz(int v)
+{
+    if (v <= 3390) return v * 108 / 841 - (16384 * 16 / 116 * 108 / 841);
+    return (int)(((long long)v * v / 16384) * v / 16384);
+}
 
-// planes: L [h][w] u8, ab [h][w][2] u8
-__global__ void nlm_bgr2lab(const uint8_t* bgr, size_t stride, int h, int w, uint8_t* L, uint8_t* ab)
+// planes: L [h][w] u8, ab [h][w][2] u8.  COLOR_LBGR2Lab: the frame is taken as LINEAR light (gamma table i << 3)
+__global__ void nlm_bgr2lab(const uint8_t* bgr, size_t stride, int h, int w, uint8_t* L, uint8_t* ab, const LabTables* t)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
     const uint8_t* s = bgr + (size_t)y * stride + (size_t)x * 3;
-    const float B = s[0] * (1.0f / 255.0f), G = s[1] * (1.0f / 255.0f), R = s[2] * (1.0f / 255.0f);
-    const float X = (0.412453f * R + 0.357580f * G + 0.180423f * B) / 0.950456f;
-    const float Y = 0.212671f * R + 0.715160f * G + 0.072169f * B;
-    const float Z = (0.019334f * R + 0.119193f * G + 0.950227f * B) / 1.088754f;
-    const float fx = lab_f(X), fy = lab_f(Y), fz = lab_f(Z);
-    const float Ls = Y > 0.008856f ? 116.0f * fy - 16.0f : 903.3f * Y;
-    const float a = 500.0f * (fx - fy), b = 200.0f * (fy - fz);
+    const int B = s[0] << 3, G = s[1] << 3, R = s[2] << 3;
+    const int fX = t->cbrt_tab[lab_descale(R * t->fwd[0] + G * t->fwd[1] + B * t->fwd[2], 12)];
+    const int fY = t->cbrt_tab[lab_descale(R * t->fwd[3] + G * t->fwd[4] + B * t->fwd[5], 12)];
+    const int fZ = t->cbrt_tab[lab_descale(R * t->fwd[6] + G * t->fwd[7] + B * t->fwd[8], 12)];
+    constexpr int Lscale = (116 * 255 + 50) / 100, Lshift = -((16 * 255 * (1 << 15) + 50) / 100);
     const size_t i = (size_t)y * w + x;
-    L[i] = (uint8_t)fminf(fmaxf(__builtin_rintf(Ls * 2.55f), 0.f), 255.f);
-    ab[2 * i] = (uint8_t)fminf(fmaxf(__builtin_rintf(a + 128.0f), 0.f), 255.f);
-    ab[2 * i + 1] = (uint8_t)fminf(fmaxf(__builtin_rintf(b + 128.0f), 0.f), 255.f);
+    L[i] = (uint8_t)lab_sat8(lab_descale(Lscale * fY + Lshift, 15));
+    ab[2 * i] = (uint8_t)lab_sat8(lab_descale(500 * (fX - fY) + 128 * (1 << 15), 15));
+    ab[2 * i + 1] = (uint8_t)lab_sat8(lab_descale(200 * (fY - fZ) + 128 * (1 << 15), 15));
 }
 
-__global__ void nlm_lab2bgr(const uint8_t* L, const uint8_t* ab, int h, int w, uint8_t* bgr, size_t stride)
+// COLOR_Lab2LBGR (Lab2RGBinteger; linear inverse gamma table (v * 255) >> 12)
+__global__ void nlm_lab2bgr(const uint8_t* L, const uint8_t* ab, int h, int w, uint8_t* bgr, size_t stride, const LabTables* t)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
     const size_t i = (size_t)y * w + x;
-    const float Ls = L[i] * (100.0f / 255.0f), a = (float)ab[2 * i] - 128.0f, b = (float)ab[2 * i + 1] - 128.0f;
-    float fy, Y;
-    if (Ls <= 8.0f) { Y = Ls / 903.3f; fy = 7.787f * Y + 16.0f / 116.0f; }
-    else { fy = (Ls + 16.0f) / 116.0f; Y = fy * fy * fy; }
-    const float fx = fy + a / 500.0f, fz = fy - b / 200.0f;
-    const float ft = 7.787f * 0.008856f + 16.0f / 116.0f;
-    const float X = (fx <= ft ? (fx - 16.0f / 116.0f) / 7.787f : fx * fx * fx) * 0.950456f;
-    const float Z = (fz <= ft ? (fz - 16.0f / 116.0f) / 7.787f : fz * fz * fz) * 1.088754f;
-    const float R = 3.240479f * X - 1.53715f * Y - 0.498535f * Z;
-    const float G = -0.969256f * X + 1.875991f * Y + 0.041556f * Z;
-    const float B = 0.055648f * X - 0.204043f * Y + 1.057311f * Z;
+    const int LL = L[i], aa = ab[2 * i], bb = ab[2 * i + 1];
+    const int yy = t->y_of_l[LL], ify = t->fy_of_l[LL];
+    const int adiv = ((5 * aa * 53687 + (1 << 7)) >> 13) - 128 * 16384 / 500;
+    const int bdiv = ((bb * 41943 + (1 << 4)) >> 9) - 128 * 16384 / 200 + 1;
+    const int xx = lab_ab_to_xz(ify + adiv), zz = lab_ab_to_xz(ify - bdiv);
     uint8_t* d = bgr + (size_t)y * stride + (size_t)x * 3;
-    d[0] = (uint8_t)fminf(fmaxf(__builtin_rintf(B * 255.0f), 0.f), 255.f);
-    d[1] = (uint8_t)fminf(fmaxf(__builtin_rintf(G * 255.0f), 0.f), 255.f);
-    d[2] = (uint8_t)fminf(fmaxf(__builtin_rintf(R * 255.0f), 0.f), 255.f);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {        // R, G, B rows of the matrix -> bytes 2, 1, 0
+        int v = lab_descale(t->inv[3 * k] * xx + t->inv[3 * k + 1] * yy + t->inv[3 * k + 2] * zz, 14);
+        v = v < 0 ? 0 : v > 4095 ? 4095 : v;
+        d[2 - k] = (uint8_t)((v * 255) >> 12);
+    }
 }
 
 // One workgroup = 16 x 16 output pixels; their 28 x 28 neighbourhood (reflect-101 at the image edge) is staged in

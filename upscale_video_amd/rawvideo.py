@@ -15,7 +15,8 @@ anime pass first (1x HurrDeblur, whole frame, re-quantised to u8 exactly like th
 upscale_processing.py:909), then the 2x/4x net with the reference's 960-px tiles.
 
 Flags follow upscale_video.py where they mean the same thing: -s/--scale 1|2|4, -m/--models a,
--g/--gpu one HIP ordinal.
+-g/--gpu a list of HIP ordinals, one worker per entry (duplicates allowed): one reader deals the frames
+out round-robin, one writer puts the results out in frame order.
 """
 import argparse
 import os
@@ -86,18 +87,61 @@ class Stage:
         return self.net.collect_u8(self.inflight.pop(0))
 
 
+class Lane:
+    """The chain of nets of ONE -g entry (one or two Stages on one GPU).  Frames go in with submit() and come out,
+    in the order they went in, with pop()."""
+
+    def __init__(self, nets_tiles, h, w, alloc):
+        self.stages = []
+        for net, tile in nets_tiles:
+            self.stages.append(Stage(net, h, w, tile, alloc))
+            h, w = h * net.scale, w * net.scale
+        self.count = 0                         # frames inside
+
+    def _shift(self):
+        """Finished frames move on to the next stage wherever that stage has room and this one is full."""
+        for k in range(len(self.stages) - 2, -1, -1):
+            while self.stages[k].full() and not self.stages[k + 1].full():
+                self.stages[k + 1].submit(self.stages[k].collect())
+
+    def full(self):
+        self._shift()
+        return self.stages[0].full()
+
+    def submit(self, frame):
+        assert not self.full()
+        self.stages[0].submit(frame)
+        self.count += 1
+
+    def pop(self):
+        """The oldest frame's result (blocks until the GPU is done with it)."""
+        def ensure(k):
+            if self.stages[k].inflight:
+                return
+            ensure(k - 1)
+            self.stages[k].submit(self.stages[k - 1].collect())
+        last = len(self.stages) - 1
+        ensure(last)
+        self.count -= 1
+        return self.stages[last].collect()
+
+
 def stream(fin, fout, h, w, nets_tiles, alloc=None, max_frames=None):
     """Reads u8 [h][w][3] frames from fin until EOF, pushes each through the nets in order, writes the
-    results to fout.  nets_tiles: list of (Net, tile_size).  Returns the number of frames written."""
+    results to fout.  nets_tiles: list of (Net, tile_size) -- one GPU worker -- or a list of such lists,
+    one per `-g` entry (duplicates allowed, as in the reference's worker list, README.md:45-61): ONE reader
+    deals the frames out round-robin (the partition of upscale_processing.py:565-598, frames being
+    independent units), every entry keeps up to PIPE_DEPTH frames in flight per net, and ONE writer puts
+    the results out in frame order.  Returns the number of frames written."""
     alloc = alloc or ncnn.pinned_empty
-    stages = []
-    sh, sw = h, w
-    for net, tile in nets_tiles:
-        stages.append(Stage(net, sh, sw, tile, alloc))
-        sh, sw = sh * net.scale, sw * net.scale
-    ins = [alloc((h, w, 3)) for _ in range(PIPE_DEPTH + 2)]
+    lanes_spec = nets_tiles if nets_tiles and isinstance(nets_tiles[0], list) else [nets_tiles]
+    lanes = [Lane(spec, h, w, alloc) for spec in lanes_spec]
+    nl = len(lanes)
+    # an input buffer is free again once its frame has left its lane's first stage: at most PIPE_DEPTH per lane are
+    # there, plus the one being read into
+    ins = [alloc((h, w, 3)) for _ in range(nl * PIPE_DEPTH + 2)]
 
-    # writer thread: the blocking write of frame i overlaps the read of frame i+k and the GPU
+    # writer thread: the blocking write of frame i overlaps the read of frame i+k and the GPUs
     wq = queue.Queue(maxsize=2)
     werr = []
 
@@ -117,21 +161,14 @@ def stream(fin, fout, h, w, nets_tiles, alloc=None, max_frames=None):
     wt.start()
     written = 0
 
-    def drain(k, everything):
-        """Advance stage k: move finished frames on to stage k+1 (or the writer)."""
+    def pop_next():
+        """frame number `written` comes out of its lane and goes to the writer"""
         nonlocal written
-        st = stages[k]
-        while st.inflight and (everything or st.full()):
-            res = st.collect()
-            if k + 1 < len(stages):
-                if stages[k + 1].full():
-                    drain(k + 1, False)
-                stages[k + 1].submit(res)
-            else:
-                if werr:
-                    raise werr[0]
-                wq.put(res)
-                written += 1
+        res = lanes[written % nl].pop()
+        if werr:
+            raise werr[0]
+        wq.put(res)
+        written += 1
 
     n_in = 0
     try:
@@ -139,12 +176,13 @@ def stream(fin, fout, h, w, nets_tiles, alloc=None, max_frames=None):
             buf = ins[n_in % len(ins)]
             if not read_exact(fin, memoryview(buf).cast("B")):
                 break
-            if stages[0].full():
-                drain(0, False)
-            stages[0].submit(buf)
+            lane = lanes[n_in % nl]
+            while lane.full():                 # frames leave in global order: at most nl pops free a slot of this lane
+                pop_next()
+            lane.submit(buf)
             n_in += 1
-        for k in range(len(stages)):
-            drain(k, True)
+        while written < n_in:
+            pop_next()
     finally:
         wq.put(None)
         wt.join()
@@ -189,7 +227,8 @@ def main(argv=None):
     ap.add_argument("-H", "--height", type=int, required=True)
     ap.add_argument("-s", "--scale", type=int, default=2, choices=[1, 2, 4])
     ap.add_argument("-m", "--models", default="", help="'a': 1x HurrDeblur pass first (upscale_video.py -m a)")
-    ap.add_argument("-g", "--gpu", type=int, default=0)
+    ap.add_argument("-g", "--gpu", default="0",
+                    help="HIP ordinals, one worker per entry, e.g. 0,1,2,3 or 0,0,1 (upscale_video.py -g; default 0)")
     ap.add_argument("--tile", type=int, default=TILE_SIZE, help="reference tile size of the final pass (960); 0 = whole frame")
     ap.add_argument("--frames", type=int, default=None, help="stop after this many frames")
     ap.add_argument("--model-path", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "models"))
@@ -203,11 +242,19 @@ def main(argv=None):
     # upscale_video.py: `-m a` runs the 1x HurrDeblur pass (process_model, :888-909), `-s 2|4` the Compact net
     # (upscale_frames, :930-944), and `-s 1` performs NO network pass of its own: its frames are only renamed
     # (:924-929).  So `-s 1` alone copies frames through, `-s 1 -m a` is the HurrDeblur pass alone.
-    nets = []
-    if "a" in models:
-        nets.append((load_net(MODEL_FILES[1], a.gpu, a.model_path), 0))          # apply_model: whole frame
-    if a.scale != 1:
-        nets.append((load_net(MODEL_FILES[a.scale], a.gpu, a.model_path), a.tile))
+    try:
+        gpus = [int(tok) for tok in str(a.gpu).split(",") if tok != ""] or [0]
+    except ValueError:
+        ap.error("-g takes a comma-separated list of GPU ordinals")
+    nets = []                     # one chain of nets per -g entry
+    for gpu in gpus:
+        chain = []
+        if "a" in models:
+            chain.append((load_net(MODEL_FILES[1], gpu, a.model_path), 0))          # apply_model: whole frame
+        if a.scale != 1:
+            chain.append((load_net(MODEL_FILES[a.scale], gpu, a.model_path), a.tile))
+        if chain:
+            nets.append(chain)
     fin = sys.stdin.buffer if a.input == "-" else open(a.input, "rb")
     fout = sys.stdout.buffer if a.output == "-" else open(a.output, "wb")
     for f in (fin, fout):
