@@ -192,6 +192,9 @@ int uva_net_kernel_stats(uva_net* net, int kind, long long* launches, double* to
  * power-limited state); *kernel_ms = mean launch time. */
 int uva_net_debug_trunk_stamps(uva_net* net, unsigned long long* out, int max_tiles, int* tiles, int ablate,
                                float* kernel_ms);
+/* Debug (generic graphs, UVA_RDB_STAMPS=1 in the environment): s_memtime stamps of rdb4_kernel's workgroup 0 in its last
+ * launch, out[(step * 4 + wave) * 4 + {0: step start, 1: first part done, 2: at the barrier, 3: barrier passed}]. */
+int uva_net_debug_rdb_stamps(uva_net* net, unsigned long long* out, int max_steps);
 #endif
 
 /* Test hook (host only, no device needed): the fp16 MFMA A-operand image convolution #conv_idx is

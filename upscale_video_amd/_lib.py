@@ -19,7 +19,7 @@ SYMBOLS = [
     "uva_net_debug_read_activation", "uva_net_set_profiling", "uva_net_kernel_stats",
     "uva_net_debug_packed_weights", "uva_last_error", "uva_abi_version",
 ]
-INSTRUMENT_SYMBOLS = ["uva_net_debug_trunk_stamps"]     # only in a -DUVA_INSTRUMENT build (build.py --instrument)
+INSTRUMENT_SYMBOLS = ["uva_net_debug_trunk_stamps", "uva_net_debug_rdb_stamps"]     # only in a -DUVA_INSTRUMENT build (build.py --instrument)
 
 _lib = None
 
@@ -104,6 +104,7 @@ def load():
     decl("uva_net_kernel_stats", [c_p, c_i, pll, ctypes.POINTER(ctypes.c_double)])
     decl("uva_net_debug_packed_weights", [c_p, c_i, c_p, c_sz, psz])
     decl("uva_net_debug_trunk_stamps", [c_p, c_p, c_i, pi, c_i, ctypes.POINTER(ctypes.c_float)])
+    decl("uva_net_debug_rdb_stamps", [c_p, c_p, c_i])
     _lib = L
     return L
 

@@ -1254,6 +1254,13 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
                 ra.slope = m.slope;
                 ra.h = a.h; ra.w = a.w;
                 ra.segs = plan.segs; ra.seg_begin = plan.seg_begin; ra.sink = n->d_sink;
+#ifdef UVA_INSTRUMENT
+                if (std::getenv("UVA_RDB_STAMPS")) {
+                    if (!n->gd.rdb_dbg) HIP_TRY(hipMalloc((void**)&n->gd.rdb_dbg, 1024 * 16 * 8));
+                    HIP_TRY(hipMemsetAsync(n->gd.rdb_dbg, 0, 1024 * 16 * 8, n->stream));
+                    ra.dbg = n->gd.rdb_dbg;
+                }
+#endif
                 if (!n->attr_set[28]) {
                     HIP_TRY(hipFuncSetAttribute((const void*)rdb4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                     n->attr_set[28] = true;
@@ -2410,6 +2417,16 @@ int uva_net_debug_trunk_stamps(uva_net* n, unsigned long long* out, int max_tile
     (void)hipFree(d);
     if (tiles) *tiles = per_block;
     return rc;
+}
+
+// debug: rdb4_kernel's in-kernel stamps of the last launch (UVA_RDB_STAMPS=1): out[(step * 4 + wave) * 4 + k]
+int uva_net_debug_rdb_stamps(uva_net* n, unsigned long long* out, int max_steps)
+{
+    if (!n || !out || !n->gd.rdb_dbg) return fail("no rdb4 stamps (UVA_RDB_STAMPS=1, a generic graph, one call)");
+    HIP_TRY(hipSetDevice(n->device));
+    HIP_TRY(hipStreamSynchronize(n->stream));
+    HIP_TRY(hipMemcpy(out, n->gd.rdb_dbg, (size_t)std::min(max_steps, 1024) * 16 * 8, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 #endif  // UVA_INSTRUMENT

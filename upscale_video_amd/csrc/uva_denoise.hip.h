@@ -36,8 +36,8 @@ __device__ __forceinline__ int reflect101(int i, int n)
 }
 
 // ---- OpenCV's 8-bit Lab conversions: fixed-point table code, not the CIE formulas (modules/imgproc/src/color_lab.cpp:
-// RGB2Lab_b, Lab2RGBinteger, initLabTabs), restated from memory of the 4.x source -- oracle/nlm_oracle.py has the same
-// restatement in numpy and says what that is worth (PARITY UNPINNED).  Constants: lab_shift 12, gamma_shift 3,
+// RGB2Lab_b, Lab2RGBinteger, initLabTabs), restated from memory of the 4.x source -- the tests hold the same restatement in numpy
+// and DESIGN.md section 5.6 says what that is worth (PARITY UNPINNED).  Constants: lab_shift 12, gamma_shift 3,
 // lab_shift2 15, base_shift 14, inv_gamma_shift 12.
 constexpr int LAB_CBRT_TAB_SIZE_B = 256 * 3 / 2 * 8;
 struct LabTables {

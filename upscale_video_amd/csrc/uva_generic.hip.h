@@ -550,6 +550,7 @@ struct GenericDevice {
     struct RdbPlan { RdbSeg* segs = nullptr; int* seg_begin = nullptr; int grid = 0; };
     std::map<std::pair<int, int>, RdbPlan> rdb_plans;                     // (h, w)
     std::vector<RdbMatch> rdbs;                                           // find_rdbs() of the loaded graph
+    unsigned long long* rdb_dbg = nullptr;                                // UVA_INSTRUMENT + UVA_RDB_STAMPS=1: rdb4_kernel's stamps
 
     static int pad32(int c) { return (c + 31) / 32 * 32; }
 
@@ -578,6 +579,8 @@ struct GenericDevice {
             if (kv.second.seg_begin) (void)hipFree(kv.second.seg_begin);
         }
         rdb_plans.clear();
+        if (rdb_dbg) (void)hipFree(rdb_dbg);
+        rdb_dbg = nullptr;
     }
 };
 

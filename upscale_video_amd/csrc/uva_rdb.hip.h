@@ -316,10 +316,13 @@ __global__ __launch_bounds__(256, 1) void g_conv3_sw(GSwArgs a)
 // split between two waves hands its partial sums over through LDS (fp32, one step later); a wave's own parts run in
 // program order, so a stage may read the row its predecessor has just written:
 //
-//     wave 0   conv1 (18)         row s     -> x1 ring, HBM      | conv2 k-steps  0..13 (x only)     row s-1 -> P2
-//     wave 1   conv2 14..26 + 1x1 row s-2   -> x2 ring, HBM      | conv3 k-steps  0..16 (x only)     row s-3 -> P3
-//     wave 2   conv3 17..35       row s-4   -> x3 ring, HBM      | conv4 k-steps  0..12 (x only)     row s-5 -> P4
-//     wave 3   conv4 13..44 + x2  row s-6   -> HBM               | the LDS-DMA of x row s+2
+//     wave 0   conv1 (18)         row s     -> x1 ring, HBM      | conv2 k-steps  0..17 (x only)     row s-1 -> P2
+//     wave 1   conv2 18..26 + 1x1 row s-2   -> x2 ring, HBM      | conv3 k-steps  0..17 (x only)     row s-3 -> P3
+//     wave 2   conv3 18..35       row s-4   -> x3 ring, HBM      | conv4 k-steps  0..14 (x only)     row s-5 -> P4
+//     wave 3   conv4 15..44 + x2  row s-6   -> HBM               | the LDS-DMA of x row s+2
+// A wave's first part's epilogue (LeakyReLU, fp16, masks, the ring and HBM stores) is spread over its second part's
+// k-loop, wave 3's over the next step's: nothing but MFMAs, their fragment reads and that epilogue's VALU work between
+// two barriers.
 //
 // Ring depths follow: x 10 rows (s-7 .. s+2), x1 8, x2 6, x3 4; 121.6 KB + 36 KB of hand-over buffers.  What a strip
 // computes correctly shrinks by one column per side and convolution (x1 on 48 columns, x4 on 42); pixels outside the plane
@@ -345,6 +348,8 @@ struct RdbArgs {
     const RdbSeg* segs;
     const int* seg_begin;
     _Float16* sink;
+    unsigned long long* dbg;      // UVA_INSTRUMENT builds: workgroup 0 stamps [step][wave][4] = {step start, first part done,
+                                  // at the barrier, barrier passed} of its first segment here (s_memtime ticks)
 };
 
 constexpr int RA_C = 48, RA_RC = 50, RA_NF = 3;
@@ -548,14 +553,20 @@ __global__ __launch_bounds__(256, 1) void rdb4_kernel(RdbArgs a)
     };
     // Every wave runs the same sequence of barriers: two per segment, then one per step.  The segment loop sits INSIDE a
     // wave's role so that its weights are fetched once per launch and stay where they are.
+#ifdef UVA_INSTRUMENT
+#define RA_STAMP(k) do { if (a.dbg && blockIdx.x == 0 && lane == 0 && si == sb && s < 1024) a.dbg[(s * 4 + wave) * 4 + (k)] = UVA_MEMTIME(); } while (0)
+#else
+#define RA_STAMP(k) do { } while (0)
+#endif
 #define RA_STEP_BARRIER() asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((UVA_RA_DBG & 3) ? 0 : 2 * RA_NF) : "memory")
-    // k-step ranges: conv1 [0,18) and conv2 [0,16) on wave 0; conv2 [16,27) + the 1x1 and conv3 [0,21) on wave 1; conv3
-    // [21,36) and conv4 [0,19) on wave 2; conv4 [19,45) on wave 3 -- 34, 34, 34 and 26 k-steps: wave 3's epilogue (the
-    // residual from LDS, nothing to hide it behind) and the DMA make up for the difference.
+    // k-step ranges: conv1 [0,18) and conv2 [0,18) on wave 0; conv2 [18,27) + the 1x1 and conv3 [0,18) on wave 1; conv3
+    // [18,36) and conv4 [0,15) on wave 2; conv4 [15,45) on wave 3 -- 36, 29, 33 and 30 k-steps, balanced by the in-kernel
+    // stamps (tools/rdb4_anatomy.py): wave 1's epilogue is the heaviest (two accumulator sets, the sum), wave 3 also
+    // issues the DMA.
     if (wave == 0) {
-        half8 wa[18][2], wb[16][2];
+        half8 wa[18][2], wb[18][2];
         weights(IC(0), IC(18), IC(2), a.w1, wa);
-        weights(IC(0), IC(16), IC(3), a.w2, wb);
+        weights(IC(0), IC(18), IC(3), a.w2, wb);
         for (int si = sb; si < se; ++si) {
             const RdbSeg sg = a.segs[si];
             const int R0 = sg.yb - 3, nsteps = sg.ye - sg.yb + RA_LAG;      // conv1's row at step 0; ring row index q = row - R0 + 8
@@ -565,23 +576,27 @@ __global__ __launch_bounds__(256, 1) void rdb4_kernel(RdbArgs a)
 #pragma clang loop unroll(disable)
             for (int s = 0; s < nsteps; ++s) {
                 lane_offsets(opaque(lane));
+                RA_STAMP(0);
                 f32x4 acc[RA_NF][2], acc2[RA_NF][2];
                 acc_bias(acc, 0);
                 acc_bias(acc2, 1);
                 kpart(IC(0), IC(18), wa, acc, s + 8, no_side);
+                RA_STAMP(1);
                 const RowOut ro = row_out(1, R0 + s, s + 8, sg);
-                kpart(IC(0), IC(16), wb, acc2, s + 7, [&](auto J) {
+                kpart(IC(0), IC(18), wb, acc2, s + 7, [&](auto J) {
                     constexpr int j = decltype(J)::value;
                     emit(lrelu16(acc[j >> 1][j & 1]), J, 1, ro);
                 });
                 acc_store(acc2, 0, s & 1);
+                RA_STAMP(2);
                 RA_STEP_BARRIER();
+                RA_STAMP(3);
             }
         }
     } else if (wave == 1) {
-        half8 wa[11][2], ws[2][2], wb[21][2];
-        weights(IC(16), IC(27), IC(3), a.w2, wa);
-        weights(IC(0), IC(21), IC(4), a.w3, wb);
+        half8 wa[9][2], ws[2][2], wb[18][2];
+        weights(IC(18), IC(27), IC(3), a.w2, wa);
+        weights(IC(0), IC(18), IC(4), a.w3, wb);
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -595,6 +610,7 @@ __global__ __launch_bounds__(256, 1) void rdb4_kernel(RdbArgs a)
 #pragma clang loop unroll(disable)
             for (int s = 0; s < nsteps; ++s) {
                 lane_offsets(opaque(lane));
+                RA_STAMP(0);
                 f32x4 acc[RA_NF][2], side[RA_NF][2], acc2[RA_NF][2];
                 // the 1x1 convolution of x (no bias), row s-2: centre tap of both chunks
                 {
@@ -614,9 +630,10 @@ __global__ __launch_bounds__(256, 1) void rdb4_kernel(RdbArgs a)
                 }
                 acc_load(acc, 0, (s + 1) & 1);
                 acc_bias(acc2, 2);
-                kpart(IC(16), IC(27), wa, acc, s + 6, no_side);
+                kpart(IC(18), IC(27), wa, acc, s + 6, no_side);
+                RA_STAMP(1);
                 const RowOut ro = row_out(2, R0 + s - 2, s + 6, sg);
-                kpart(IC(0), IC(21), wb, acc2, s + 5, [&](auto J) {
+                kpart(IC(0), IC(18), wb, acc2, s + 5, [&](auto J) {
                     constexpr int j = decltype(J)::value;
                     const half4 c3 = lrelu16(acc[j >> 1][j & 1]);
                     half4 v;
@@ -625,13 +642,15 @@ __global__ __launch_bounds__(256, 1) void rdb4_kernel(RdbArgs a)
                     emit(v, J, 2, ro);
                 });
                 acc_store(acc2, 1, s & 1);
+                RA_STAMP(2);
                 RA_STEP_BARRIER();
+                RA_STAMP(3);
             }
         }
     } else if (wave == 2) {
-        half8 wa[15][2], wb[19][2];
-        weights(IC(21), IC(36), IC(4), a.w3, wa);
-        weights(IC(0), IC(19), IC(5), a.w4, wb);
+        half8 wa[18][2], wb[15][2];
+        weights(IC(18), IC(36), IC(4), a.w3, wa);
+        weights(IC(0), IC(15), IC(5), a.w4, wb);
         for (int si = sb; si < se; ++si) {
             const RdbSeg sg = a.segs[si];
             const int R0 = sg.yb - 3, nsteps = sg.ye - sg.yb + RA_LAG;
@@ -641,22 +660,26 @@ __global__ __launch_bounds__(256, 1) void rdb4_kernel(RdbArgs a)
 #pragma clang loop unroll(disable)
             for (int s = 0; s < nsteps; ++s) {
                 lane_offsets(opaque(lane));
+                RA_STAMP(0);
                 f32x4 acc[RA_NF][2], acc2[RA_NF][2];
                 acc_load(acc, 1, (s + 1) & 1);
                 acc_bias(acc2, 3);
-                kpart(IC(21), IC(36), wa, acc, s + 4, no_side);
+                kpart(IC(18), IC(36), wa, acc, s + 4, no_side);
+                RA_STAMP(1);
                 const RowOut ro = row_out(3, R0 + s - 4, s + 4, sg);
-                kpart(IC(0), IC(19), wb, acc2, s + 3, [&](auto J) {
+                kpart(IC(0), IC(15), wb, acc2, s + 3, [&](auto J) {
                     constexpr int j = decltype(J)::value;
                     emit(lrelu16(acc[j >> 1][j & 1]), J, 3, ro);
                 });
                 acc_store(acc2, 2, s & 1);
+                RA_STAMP(2);
                 RA_STEP_BARRIER();
+                RA_STAMP(3);
             }
         }
     } else {
-        half8 wa[26][2];
-        weights(IC(19), IC(45), IC(5), a.w4, wa);
+        half8 wa[30][2];
+        weights(IC(15), IC(45), IC(5), a.w4, wa);
         for (int si = sb; si < se; ++si) {
             const RdbSeg sg = a.segs[si];
             const int R0 = sg.yb - 3, nsteps = sg.ye - sg.yb + RA_LAG;
@@ -667,34 +690,62 @@ __global__ __launch_bounds__(256, 1) void rdb4_kernel(RdbArgs a)
             dma_x(R0, R0);
             dma_x(R0 + 1, R0);
             sw_barrier();
+            // This wave has one part per step and nothing of its own to hide its epilogue behind: the epilogue of the row
+            // of step s-1 (LeakyReLU, + x2 of the same pixels -- BinaryOp Add_14 -- from its ring, the stores) runs inside
+            // the k-loop of step s.
+            f32x4 accp[RA_NF][2];
+#pragma unroll
+            for (int f = 0; f < RA_NF; ++f)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) accp[f][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            auto finish = [&](auto J, const half4 (&x2)[RA_NF][2], const RowOut& ro) {
+                constexpr int j = decltype(J)::value;
+                const half4 c4 = lrelu16(accp[j >> 1][j & 1]);
+                half4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = g_axpby1((float)c4[e], 1.f, (float)x2[j >> 1][j & 1][e], 1.f);
+                emit(v, J, 4, ro);
+            };
 #pragma clang loop unroll(disable)
             for (int s = 0; s < nsteps; ++s) {
                 lane_offsets(opaque(lane));
+                RA_STAMP(0);
                 if (!(UVA_RA_DBG & 4)) dma_x(R0 + s + 2, R0);
                 f32x4 acc[RA_NF][2];
-                // x2 of the same pixels (BinaryOp Add_14), from its ring, fetched ahead of the k-loop
-                const char* const r2 = smem + rowaddr(2, s + 2);
+                // x2 of the PREVIOUS step's row (ring row s + 1; it stays in its ring until the step after this one)
+                const char* const r2 = smem + rowaddr(2, s + 1);
                 half4 x2[RA_NF][2];
 #pragma unroll
                 for (int f = 0; f < RA_NF; ++f)
 #pragma unroll
                     for (int m = 0; m < 2; ++m) x2[f][m] = *(const half4*)(r2 + wroff[m] + f * 1024);
                 acc_load(acc, 2, (s + 1) & 1);
-                kpart(IC(19), IC(45), wa, acc, s + 2, no_side);
-                const RowOut ro = row_out(4, R0 + s - 6, s + 2, sg);
-                static_for<RA_NF * 2>([&](auto J) {
-                    constexpr int j = decltype(J)::value;
-                    const half4 c4 = lrelu16(acc[j >> 1][j & 1]);
-                    half4 v;
+                const RowOut ro = row_out(4, R0 + s - 7, s + 1, sg);
+                kpart(IC(15), IC(45), wa, acc, s + 2, [&](auto J) { finish(J, x2, ro); });
+                RA_STAMP(1);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = g_axpby1((float)c4[e], 1.f, (float)x2[j >> 1][j & 1][e], 1.f);
-                    emit(v, J, 4, ro);
-                });
+                for (int f = 0; f < RA_NF; ++f)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) accp[f][m] = acc[f][m];
+                RA_STAMP(2);
                 RA_STEP_BARRIER();
+                RA_STAMP(3);
+            }
+            {   // the last step's row
+                lane_offsets(opaque(lane));
+                const char* const r2 = smem + rowaddr(2, nsteps + 1);
+                half4 x2[RA_NF][2];
+#pragma unroll
+                for (int f = 0; f < RA_NF; ++f)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) x2[f][m] = *(const half4*)(r2 + wroff[m] + f * 1024);
+                const RowOut ro = row_out(4, R0 + nsteps - 7, nsteps + 1, sg);
+                static_for<RA_NF * 2>([&](auto J) { finish(J, x2, ro); });
             }
         }
     }
 #undef RA_STEP_BARRIER
+#undef RA_STAMP
 #undef IC
 }
 
