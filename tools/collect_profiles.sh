@@ -10,8 +10,8 @@ REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="python $REPO/bench.py --no-cpu-baseline"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o p -- $B --steps 20 --warmup 5 > "$OUT/stats.log" 2>&1
+B="python $REPO/bench.py --no-cpu-baseline --no-parity"     # no 128x96 probe launches: every row of the CSVs is a full-size launch
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o p -- $B --steps 120 --warmup 10 > "$OUT/stats.log" 2>&1
 cp "$OUT"/stats/p_kernel_stats.csv "$OUT/${TAG}_kernel_stats_rocprofv3.csv" 2>/dev/null || find "$OUT/stats" -name "*kernel_stats.csv" -exec cp {} "$OUT/${TAG}_kernel_stats_rocprofv3.csv" \;
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o p -- $B --steps 4 --warmup 2 > "$OUT/pmc_fetch.log" 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o p -- $B --steps 4 --warmup 2 > "$OUT/pmc_write.log" 2>&1

@@ -15,13 +15,22 @@ python bench.py --tile 0 --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG
 UVA_TRUNK_FUSION=0 python bench.py --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_unfused_trunk_kernel.json" 2>> "$OUT/bench.err"
 UVA_SUB10=0 python bench.py --workload 1x_hurrdeblur_1080p --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_1x_per_pair_kernels.json" 2>> "$OUT/bench.err"
 python bench.py --workload 1x_hurrdeblur_1080p --tile 960 --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_1x_tiled_960.json" 2>> "$OUT/bench.err"
-(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d /tmp/prof1x_$TAG -o p --output-format csv -- python $REPO/bench.py --workload 1x_hurrdeblur_1080p --tile 0 --steps 50 --warmup 5 --no-cpu-baseline > /dev/null 2>&1; cp $(find /tmp/prof1x_$TAG -name "*kernel_stats.csv" | head -1) "$OUT/${TAG}_kernel_stats_1x_rocprofv3.csv")
+(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d /tmp/prof1x_$TAG -o p --output-format csv -- python $REPO/bench.py --workload 1x_hurrdeblur_1080p --tile 0 --steps 120 --warmup 10 --no-cpu-baseline --no-parity > /dev/null 2>&1; cp $(find /tmp/prof1x_$TAG -name "*kernel_stats.csv" | head -1) "$OUT/${TAG}_kernel_stats_1x_rocprofv3.csv")
 bash tools/pmc_sub10.sh /tmp/pmc_sub10_$TAG > "$OUT/${TAG}_sub10_pmc.txt" 2>&1
 python tools/png_route_bench.py 384 > "$OUT/${TAG}_png_route_bench.txt" 2>&1
 python tools/png_gpu_route_bench.py 240 > "$OUT/${TAG}_png_gpu_route_bench.txt" 2>&1
 python tools/rawvideo_bench.py 600 > "$OUT/${TAG}_rawvideo_bench.txt" 2>&1
 python tools/denoise_bench.py > "$OUT/${TAG}_denoise_bench_now.txt" 2>&1
 python tools/valar_bench.py 3 > "$OUT/${TAG}_bench_valar.txt" 2>&1
+UVA_GENERIC_RDB=0 UVA_GENERIC_SW=0 python tools/valar_bench.py 3 2>&1 | sed 's/^/layer by layer (UVA_GENERIC_RDB=0 UVA_GENERIC_SW=0): /' >> "$OUT/${TAG}_bench_valar.txt"
+bash tools/pmc_valar.sh > "$OUT/${TAG}_valar_pmc.txt" 2>&1
+(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d /tmp/profval_$TAG -o p --output-format csv -- python $REPO/tools/valar_bench.py 3 > /dev/null 2>&1; cp $(find /tmp/profval_$TAG -name "*kernel_stats.csv" | head -1) "$OUT/${TAG}_kernel_stats_valar_rocprofv3.csv")
+UVA_RDB_STAMPS=1 UVA_LIB_PATH=$REPO/upscale_video_amd/libuva_instr.so python tools/rdb4_anatomy.py > "$OUT/${TAG}_rdb4_anatomy.txt" 2>&1
+python tools/valar_bench.py 60 > "$OUT/power_valar.txt" 2>/dev/null &
+sleep 5
+for i in 1 2 3 4; do rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power|sclk"; sleep 1; done > "$OUT/${TAG}_power_during_valar.txt"
+wait
+grep frames "$OUT/power_valar.txt" >> "$OUT/${TAG}_power_during_valar.txt"
 python test_gpus.py -g 0,0,0,0 -s 2 -r 16 > "$OUT/${TAG}_test_gpus_harness.txt" 2>&1
 # package power and shader clock while the bench runs (sustained state)
 python bench.py --steps 6000 --warmup 50 --no-cpu-baseline > "$OUT/power_bench.json" 2>/dev/null &

@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256, 1) void rdb4_kernel(RdbArgs a)
             constexpr int k = K0 + decltype(KK)::value, chunk = k / 9, tap = k % 9, dy = tap / 3, dx = tap % 3;
             constexpr int g = chunk < 2 ? 0 : chunk - 1, coff = chunk == 1 ? RA_CHB : 0;
 #pragma unroll
-            for (int f = 0; f < RA_NF; ++f) dst[f] = *(const half8*)(smem + ra[g][dy] + coff + offdx[dx] + f * 1024);
+            for (int f = 0; f < RA_NF; ++f) dst[f] = *(const half8*)(smem + ra[g][dy] + coff + offdx[dx] + ((UVA_RA_DBG & 16) ? 0 : f) * 1024);
         };
         __builtin_amdgcn_sched_barrier(0);                           // nothing else's LDS reads count as the pipeline's
         static_for<(D < N ? D : N)>([&](auto I) { rd(I, bq[decltype(I)::value]); });
