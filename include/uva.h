@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UVA_ABI_VERSION 9   /* 2: + uva_net_submit_u8 / uva_net_collect_u8 / uva_host_alloc / uva_host_free;
+#define UVA_ABI_VERSION 10  /* 2: + uva_net_submit_u8 / uva_net_collect_u8 / uva_host_alloc / uva_host_free;
                                3: + uva_get_gpu_pci_bus_id, uva_debug_trunk2_schedule;
                                4: + uva_denoise_u8, uva_debug_denoise_stage; generic graphs (4x_Valar_v1) load;
                                5: + uva_debug_sub10_rows;
@@ -33,7 +33,8 @@ extern "C" {
                                   uva_debug_png_deflate_host;
                                7: + uva_png_decode_bgr, uva_debug_zlib_decompress;
                                8: + uva_net_debug_generic_plan;
-                               9: + uva_debug_generic_segments (generic graphs: the fused residual-dense-block kernels) */
+                               9: + uva_debug_generic_segments (generic graphs: the fused residual-dense-block kernels);
+                               10: + uva_debug_generic_segments_planes (a frame's reference tiles through those kernels in one launch) */
 
 typedef struct uva_net uva_net;
 
@@ -220,10 +221,14 @@ int uva_net_debug_generic_plan(const uva_net* net, int* info);
 /* Test hook (host only): the work lists of the generic executor's persistent kernels for an h x w plane on `grid`
  * workgroups -- kind 0: rdb4_kernel (a residual dense block's first four convolutions, models/4x_Valar_v1.param:6-19),
  * kind 1 / 2: g_conv3_sw with 32 / 64-column strips (the 192 -> 64 and 64 -> 64 convolutions).  Every segment is 8 words
- * {c0, y_begin, y_end, own0, own1, 0, 0, 0}: the kernel computes columns c0.. of rows [y_begin, y_end) and writes
+ * {c0, y_begin, y_end, own0, own1, plane, 0, 0}: the kernel computes columns c0.. of rows [y_begin, y_end) and writes
  * columns [own0, own1) of them; seg_begin (grid + 1 ints): workgroup g owns segments seg_begin[g] .. seg_begin[g+1]. */
 int uva_debug_generic_segments(int kind, int h, int w, int grid, int32_t* segs_words, size_t capacity_words, size_t* needed_words,
                                int* seg_begin);
+/* The same for a BATCH of planes sharing one launch (the reference tiles of a frame, upscale_processing.py:499-516):
+ * dims = {h0, w0, h1, w1, ...}, nplanes <= 16; word 5 of a segment is the index of its plane. */
+int uva_debug_generic_segments_planes(int kind, const int* dims, int nplanes, int grid, int32_t* segs_words, size_t capacity_words,
+                                      size_t* needed_words, int* seg_begin);
 
 /* Test hook (host only): the row lists sub10_kernel (the whole 24-feature 1x net, one launch) walks for an h x w
  * frame on `grid` workgroups.  Every workgroup has `*stride` 16-byte entries of 4 words {y, x0, emit, 0}

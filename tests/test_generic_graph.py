@@ -317,6 +317,53 @@ def test_conv3_sw_work_list_covers_every_pixel_once(kind, cols, h, w):
     assert blocks.max() - blocks.min() <= 1
 
 
+def _segments_planes(kind, dims, grid=256):
+    L = _lib.load()
+    flat = (ctypes.c_int * (2 * len(dims)))(*[v for d in dims for v in d])
+    need = ctypes.c_size_t(0)
+    L.uva_debug_generic_segments_planes(kind, flat, len(dims), grid, None, 0, ctypes.byref(need), None)
+    words = (ctypes.c_int32 * need.value)()
+    sbeg = (ctypes.c_int * (grid + 1))()
+    assert L.uva_debug_generic_segments_planes(kind, flat, len(dims), grid, words, need.value, ctypes.byref(need), sbeg) == 0, L.uva_last_error()
+    return np.frombuffer(words, np.int32).reshape(-1, 8), list(sbeg)
+
+
+# the planes of a 1080p frame cut into the reference's tiles (upscale_processing.py:499-516), and odd mixes
+PLANE_SETS = [[(970, 970), (970, 970), (130, 970), (130, 970)], [(970, 960), (970, 970), (120, 960), (120, 970)],
+              [(64, 64), (64, 33), (17, 64), (17, 33)], [(300, 200)] * 16, [(7, 45), (1080, 1920)]]
+
+
+@pytest.mark.parametrize("dims", PLANE_SETS)
+def test_rdb4_work_list_of_a_plane_batch(dims):
+    """One rdb4 launch for several planes: every pixel of every plane owned by exactly one segment, the own-column rule
+    of the one-plane list, rows dealt evenly (+-1) over the workgroups."""
+    segs, sbeg = _segments_planes(0, dims)
+    cover = [np.zeros(d, np.int32) for d in dims]
+    for c0, yb, ye, own0, own1, pl in segs[:, :6]:
+        h, w = dims[pl]
+        assert 0 <= yb < ye <= h and 0 <= own0 < own1 <= w and c0 >= 0
+        assert own0 >= (c0 + 3 if c0 > 0 else 0) and own1 <= (c0 + 45 if c0 + 48 < w else w)
+        cover[pl][yb:ye, own0:own1] += 1
+    assert all((c == 1).all() for c in cover)
+    assert sbeg[0] == 0 and sbeg[-1] == len(segs) and all(b >= a for a, b in zip(sbeg, sbeg[1:]))
+    rows = np.array([sum(int(s[2] - s[1]) for s in segs[sbeg[g]:sbeg[g + 1]]) for g in range(256)])
+    assert rows.max() - rows.min() <= 1
+
+
+@pytest.mark.parametrize("kind,cols", [(1, 32), (2, 64)])
+@pytest.mark.parametrize("dims", PLANE_SETS)
+def test_conv3_sw_work_list_of_a_plane_batch(kind, cols, dims):
+    segs, sbeg = _segments_planes(kind, dims)
+    cover = [np.zeros(d, np.int32) for d in dims]
+    for c0, y0, y1, _, _, pl in segs[:, :6]:
+        h, w = dims[pl]
+        assert c0 % cols == 0 and y0 % 4 == 0 and (y1 % 4 == 0 or y1 == h) and 0 <= y0 < y1 <= h
+        cover[pl][y0:y1, c0:min(w, c0 + cols)] += 1
+    assert all((c == 1).all() for c in cover)
+    blocks = np.array([sum(-(-int(s[2] - s[1]) // 4) for s in segs[sbeg[g]:sbeg[g + 1]]) for g in range(256)])
+    assert blocks.max() - blocks.min() <= 1
+
+
 def test_valar_dense_blocks_are_recognised(uva):
     """find_rdbs: 68 of 4x_Valar_v1's 69 residual dense blocks run their first four convolutions as one launch (the very
     first block's x comes from the 3-channel head convolution and is copied into the chain's array after conv1)."""

@@ -1067,44 +1067,68 @@ void generic_release(uva_net* n, const GBuf& b)
     if (b.p) n->gd.pool[std::make_tuple(b.h, b.w, b.c)].push_back(b.p);
 }
 
-// One plane (a reference tile, or the whole frame) through the graph.  Arrays are recycled as soon as their last
-// reader has been queued (stream order makes that safe) and only ever for a blob of the same shape, so borders
-// and padding channels -- never written -- stay zero.
-int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, int sy0, int sx0, int h, int w, void* dst,
-                      size_t dst_stride, int cy0, int cy1, int cx0, int cx1)
+// One BATCH of planes (reference tiles, or the whole frame) through the graph in lockstep: layer by layer, every plane's
+// launch of that layer -- and for the residual-dense-block kernels (csrc/uva_rdb.hip.h) ONE launch for all planes, their
+// arrays in a table: a frame's small planes then share the workgroups with the large ones instead of under-filling the
+// chip in launches of their own.  Arrays are recycled as soon as their last reader has been queued (stream order makes
+// that safe) and only ever for a blob of the same shape, so borders and padding channels -- never written -- stay zero.
+// All planes of a batch take the same kernels (generic_plane_class: the same side of every width threshold).
+struct PlaneJob {
+    const void* src; size_t src_stride; int sy0, sx0, h, w;
+    void* dst; size_t dst_stride; int cy0, cy1, cx0, cx1;
+};
+inline int generic_plane_class(int w) { return (w >= 16) + (w >= 32) + (w >= 64); }
+
+int generic_run_planes(uva_net* n, bool f32, const std::vector<PlaneJob>& jobs)
 {
     const GenericGraph& g = n->gg;
-    std::vector<GBuf> buf(g.blobs.size());
-    std::vector<int> left(g.blobs.size(), 0);
+    const int np = (int)jobs.size();
+    if (np <= 0 || np > GEN_MAX_PLANES) return fail("generic executor: bad plane batch");
     auto root = [&](int b) { while (g.blobs[b].alias_of >= 0) b = g.blobs[b].alias_of; return b; };
-    for (size_t b = 0; b < g.blobs.size(); ++b) left[b] = g.blobs[b].consumers;
     // dense chains (uva_generic.h plan_concat_groups): the blobs of a chain are channel ranges of one shared array, which
     // goes back to the pool when the last of them has been read.  Needs g_conv3_lds (prefix reads, strided writes).
     const bool use_groups = n->generic_lds_conv;
-    std::vector<GBuf> garr(g.group_channels.size());
-    std::vector<int> glive(g.group_blobs.begin(), g.group_blobs.end());
     auto group_of = [&](int b) { return use_groups ? g.blobs[b].group : -1; };
-    auto done_with = [&](int b) {
+    struct PlaneState {
+        PlaneJob j;
+        std::vector<GBuf> buf, garr;
+        std::vector<int> left, glive;
+    };
+    std::vector<PlaneState> P(np);
+    int wmin = jobs[0].w;
+    for (int pi = 0; pi < np; ++pi) {
+        PlaneState& ps = P[pi];
+        ps.j = jobs[pi];
+        ps.buf.assign(g.blobs.size(), GBuf());
+        ps.left.assign(g.blobs.size(), 0);
+        for (size_t b = 0; b < g.blobs.size(); ++b) ps.left[b] = g.blobs[b].consumers;
+        ps.garr.assign(g.group_channels.size(), GBuf());
+        ps.glive.assign(g.group_blobs.begin(), g.group_blobs.end());
+        wmin = std::min(wmin, jobs[pi].w);
+    }
+    auto done_with = [&](PlaneState& ps, int b) {
         b = root(b);
-        if (--left[b] != 0) return;
+        if (--ps.left[b] != 0) return;
         const int gi = group_of(b);
         if (gi >= 0) {
-            buf[b].p = nullptr;
-            if (--glive[gi] == 0) { generic_release(n, garr[gi]); garr[gi].p = nullptr; }
+            ps.buf[b].p = nullptr;
+            if (--ps.glive[gi] == 0) { generic_release(n, ps.garr[gi]); ps.garr[gi].p = nullptr; }
         } else {
-            generic_release(n, buf[b]);
-            buf[b].p = nullptr;
+            generic_release(n, ps.buf[b]);
+            ps.buf[b].p = nullptr;
         }
     };
     struct Cleanup {
-        uva_net* n; std::vector<GBuf>* bufs; std::vector<GBuf>* groups; const GenericGraph* g; bool use_groups;
+        uva_net* n; std::vector<PlaneState>* P; const GenericGraph* g; bool use_groups;
         ~Cleanup()
         {
-            for (size_t b = 0; b < bufs->size(); ++b)
-                if ((*bufs)[b].p && !(use_groups && g->blobs[b].group >= 0)) generic_release(n, (*bufs)[b]);
-            for (auto& a : *groups) if (a.p) generic_release(n, a);
+            for (PlaneState& ps : *P) {
+                for (size_t b = 0; b < ps.buf.size(); ++b)
+                    if (ps.buf[b].p && !(use_groups && g->blobs[b].group >= 0)) generic_release(n, ps.buf[b]);
+                for (auto& a : ps.garr) if (a.p) generic_release(n, a);
+            }
         }
-    } cleanup{n, &buf, &garr, &g, use_groups};
+    } cleanup{n, &P, &g, use_groups};
     const int T = 256;
     // Element-wise sums that directly follow a convolution of g_conv3_lds are done in its epilogue (GConvArgs::res): the
     // convolution's own result never goes to memory, the sum layer is skipped.  Conditions: the convolution's result has
@@ -1140,7 +1164,7 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
         const GenericDevice::ConvDev& cd = n->gd.convs[l.conv];
         if (cd.cout_pad != 64 || g.blobs[l.out[0]].channels != 64 || (cd.cin_pad != 64 && cd.cin_pad != 192)) return 0;
         const int cols = cd.cin_pad == 192 ? sw_cols<1>() : sw_cols<2>();
-        return w * g.blobs[l.out[0]].scale >= cols ? cols : 0;
+        return wmin * g.blobs[l.out[0]].scale >= cols ? cols : 0;
     };
     // the instantiations of g_conv3_sw that exist (what 4x_Valar_v1 needs): -1 = none, the layer-by-layer kernel takes it
     auto sw_variant = [](int cin_pad, bool act, int rm, int rm2) -> int {
@@ -1178,12 +1202,32 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
             skip[ri] = 1;
         }
     }
+    // A nearest-neighbour 2x Interp whose only reader is a 64 -> 64 convolution of g_conv3_sw is folded into that
+    // convolution's row DMA (g_conv3_sw<..., UP>): the enlarged array is never written (models/4x_Valar_v1.param:1000-1003:
+    // at 4x it is 16x the 1x plane).  UVA_GENERIC_FUSE_INTERP=0: the Interp as a launch of its own, the A/B switch.
+    static const bool up_on = [] { const char* e = std::getenv("UVA_GENERIC_FUSE_INTERP"); return !e || std::atoi(e) != 0; }();
+    std::vector<int> up_of(g.layers.size(), -1);
+    if (up_on) {
+        std::vector<int> producer(g.blobs.size(), -1);
+        for (size_t li = 0; li < g.layers.size(); ++li)
+            if (g.layers[li].kind != GLayer::SPLIT && !g.layers[li].out.empty()) producer[g.layers[li].out[0]] = (int)li;
+        for (size_t li = 0; li < g.layers.size(); ++li) {
+            const GLayer& cl = g.layers[li];
+            if (!sw_cols_of(li) || fuse_add[li] >= 0 || cl.in.size() != 1) continue;
+            if (sw_variant(n->gd.convs[cl.conv].cin_pad, cl.has_act, 0, 0) != 3) continue;
+            const int ib = root(cl.in[0]), pi = producer[ib];
+            if (pi < 0 || g.layers[pi].kind != GLayer::INTERP_NEAREST || g.layers[pi].factor != 2 || g.blobs[ib].consumers != 1) continue;
+            if (group_of(ib) >= 0 || group_of(root(g.layers[pi].in[0])) >= 0 || ib == root(g.out_blob)) continue;
+            up_of[li] = pi;
+            skip[pi] = 1;
+        }
+    }
     // residual dense blocks whose first four convolutions run as one rdb4_kernel launch at the first one (UVA_GENERIC_RDB=0:
     // layer by layer, the A/B switch): the other six layers are bookkeeping only, and none of their sums is fused elsewhere
     static const bool rdb_on = [] { const char* e = std::getenv("UVA_GENERIC_RDB"); return !e || std::atoi(e) != 0; }();
     std::vector<int> rdb_at(g.layers.size(), -1);
     std::vector<char> rdb_skip(g.layers.size(), 0);
-    if (rdb_on && use_groups && w >= 16) {
+    if (rdb_on && use_groups && wmin >= 16) {
         for (size_t k = 0; k < n->gd.rdbs.size(); ++k) {
             const RdbMatch& m = n->gd.rdbs[k];
             rdb_at[m.c1] = (int)k;
@@ -1194,17 +1238,17 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
             }
         }
     }
-    auto acquire_out = [&](const GLayer& ly, GBuf* out) -> int {
+    auto acquire_out = [&](PlaneState& ps, const GLayer& ly, GBuf* out) -> int {
         const GBlob& ob = g.blobs[ly.out[0]];
         GBuf o;
         if (group_of(ly.out[0]) >= 0) {
-            GBuf& ga = garr[ob.group];
-            if (!ga.p && generic_acquire(n, h * ob.scale, w * ob.scale, g.group_channels[ob.group], &ga)) return 1;
+            GBuf& ga = ps.garr[ob.group];
+            if (!ga.p && generic_acquire(n, ps.j.h * ob.scale, ps.j.w * ob.scale, g.group_channels[ob.group], &ga)) return 1;
             o = ga;                                   // same geometry and pixel stride (cpad) ...
             o.p = ga.p + ob.group_off;                // ... starting at the blob's first channel
             o.c = ob.channels;
-        } else if (generic_acquire(n, h * ob.scale, w * ob.scale, ob.channels, &o)) return 1;
-        buf[ly.out[0]] = o;
+        } else if (generic_acquire(n, ps.j.h * ob.scale, ps.j.w * ob.scale, ob.channels, &o)) return 1;
+        ps.buf[ly.out[0]] = o;
         *out = o;
         return 0;
     };
@@ -1212,112 +1256,143 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
         const GLayer& gl = g.layers[layer_i];
         if (gl.kind == GLayer::SPLIT || skip[layer_i]) continue;
         if (rdb_skip[layer_i]) {          // done by the rdb4 launch at the block's first convolution: buffers and counts only
-            GBuf o;
-            if (group_of(gl.out[0]) >= 0 && acquire_out(gl, &o)) return 1;
-            for (int b : gl.in) done_with(b);
+            for (PlaneState& ps : P) {
+                GBuf o;
+                if (group_of(gl.out[0]) >= 0 && acquire_out(ps, gl, &o)) return 1;
+                for (int b : gl.in) done_with(ps, b);
+            }
             continue;
         }
         const GLayer* const sum = fuse_add[layer_i] >= 0 ? &g.layers[fuse_add[layer_i]] : nullptr;
         const GLayer* const sum2 = fuse_add2[layer_i] >= 0 ? &g.layers[fuse_add2[layer_i]] : nullptr;
+        const GLayer* const up = gl.kind == GLayer::CONV && up_of[layer_i] >= 0 ? &g.layers[up_of[layer_i]] : nullptr;
+        auto finish_layer = [&](PlaneState& ps) {
+            if (up) done_with(ps, up->in[0]);          // (the Interp's own result was never made)
+            else for (int b : gl.in) done_with(ps, b);
+            if (sum) done_with(ps, sum->in[1 - fuse_pos[layer_i]]);
+            if (sum2) done_with(ps, sum2->in[1 - fuse_pos2[layer_i]]);
+        };
+        // ---- the kernels that take all planes in one launch ----------------------------------------------------------
+        if (gl.kind == GLayer::CONV && rdb_at[layer_i] >= 0) {
+            const RdbMatch& m = n->gd.rdbs[rdb_at[layer_i]];
+            auto cdev = [&](int li) -> const GenericDevice::ConvDev& { return n->gd.convs[g.layers[li].conv]; };
+            RdbArgs ra;
+            std::memset(&ra, 0, sizeof ra);
+            std::vector<int> dims;
+            for (int pi = 0; pi < np; ++pi) {
+                GBuf o;
+                if (acquire_out(P[pi], gl, &o)) return 1;
+                const GBuf& arr = P[pi].garr[m.group];
+                ra.arr[pi] = arr.p; ra.ph[pi] = arr.h; ra.pw[pi] = arr.w; ra.stride = arr.cpad;
+                dims.push_back(arr.h); dims.push_back(arr.w);
+            }
+            GenericDevice::RdbPlan& plan = n->gd.rdb_plans[dims];
+            if (!plan.segs) {
+                std::vector<RdbSeg> segs;
+                std::vector<int> sbeg;
+                plan.grid = std::max(8, (n->ncu / 8) * 8);
+                rdb_segments(dims, plan.grid, segs, sbeg);
+                if (upload(&plan.segs, segs.data(), segs.size() * sizeof(RdbSeg), n->stream)) return 1;
+                if (upload(&plan.seg_begin, sbeg.data(), sbeg.size() * sizeof(int), n->stream)) return 1;
+                HIP_TRY(hipStreamSynchronize(n->stream));
+            }
+            ra.w1 = cdev(m.c1).wpk; ra.w2 = cdev(m.c2).wpk; ra.w2s = cdev(m.c2s).wpk; ra.w3 = cdev(m.c3).wpk; ra.w4 = cdev(m.c4).wpk;
+            ra.b1 = cdev(m.c1).bias; ra.b2 = cdev(m.c2).bias; ra.b3 = cdev(m.c3).bias; ra.b4 = cdev(m.c4).bias;
+            ra.slope = m.slope;
+            ra.segs = plan.segs; ra.seg_begin = plan.seg_begin; ra.sink = n->d_sink;
+#ifdef UVA_INSTRUMENT
+            if (std::getenv("UVA_RDB_STAMPS")) {
+                if (!n->gd.rdb_dbg) HIP_TRY(hipMalloc((void**)&n->gd.rdb_dbg, 1024 * 16 * 8));
+                HIP_TRY(hipMemsetAsync(n->gd.rdb_dbg, 0, 1024 * 16 * 8, n->stream));
+                ra.dbg = n->gd.rdb_dbg;
+            }
+#endif
+            if (!n->attr_set[28]) {
+                HIP_TRY(hipFuncSetAttribute((const void*)rdb4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                n->attr_set[28] = true;
+            }
+            hipLaunchKernelGGL(rdb4_kernel, dim3(plan.grid), dim3(256), rdb4_lds_bytes(), n->stream, ra);
+            HIP_TRY(hipGetLastError());
+            for (PlaneState& ps : P) finish_layer(ps);
+            continue;
+        }
+        if (gl.kind == GLayer::CONV && sw_cols_of(layer_i)) {
+            const GenericDevice::ConvDev& cd = n->gd.convs[gl.conv];
+            const int rm = !sum ? 0 : fuse_pos[layer_i] == 1 ? 1 : 2, rm2 = !sum2 ? 0 : fuse_pos2[layer_i] == 1 ? 1 : 2;
+            const int variant = sw_variant(cd.cin_pad, gl.has_act, rm, rm2);
+            if (variant >= 0) {
+                const int cols = sw_cols_of(layer_i);
+                GSwArgs sa;
+                std::memset(&sa, 0, sizeof sa);
+                std::vector<int> dims{cols};
+                for (int pi = 0; pi < np; ++pi) {
+                    PlaneState& ps = P[pi];
+                    GBuf o;
+                    if (acquire_out(ps, sum2 ? *sum2 : sum ? *sum : gl, &o)) return 1;
+                    const GBuf& a = ps.buf[root(up ? up->in[0] : gl.in[0])];
+                    sa.in[pi] = a.p; sa.out[pi] = o.p; sa.ph[pi] = o.h; sa.pw[pi] = o.w;
+                    sa.in_stride = a.cpad; sa.out_stride = o.cpad;
+                    if (sum) {
+                        const GBuf& other = ps.buf[root(sum->in[1 - fuse_pos[layer_i]])];
+                        sa.res[pi] = other.p; sa.res_stride = other.cpad;
+                    }
+                    if (sum2) {
+                        const GBuf& other = ps.buf[root(sum2->in[1 - fuse_pos2[layer_i]])];
+                        sa.res2[pi] = other.p; sa.res2_stride = other.cpad;
+                    }
+                    dims.push_back(o.h); dims.push_back(o.w);
+                }
+                GenericDevice::SwPlan& plan = n->gd.sw_plans[dims];
+                if (!plan.segs) {
+                    std::vector<GSwSeg> segs;
+                    std::vector<int> sbeg;
+                    plan.grid = std::max(8, (n->ncu / 8) * 8);
+                    sw_segments(std::vector<int>(dims.begin() + 1, dims.end()), cols, plan.grid, segs, sbeg);
+                    if (upload(&plan.segs, segs.data(), segs.size() * sizeof(GSwSeg), n->stream)) return 1;
+                    if (upload(&plan.seg_begin, sbeg.data(), sbeg.size() * sizeof(int), n->stream)) return 1;
+                    HIP_TRY(hipStreamSynchronize(n->stream));       // (the vectors go away)
+                }
+                sa.wpk = cd.wpk; sa.bias = cd.bias; sa.out_coff = 0; sa.slope = gl.act_slope;
+                if (sum) { sa.ca = sum->coeffs[0]; sa.cb = sum->coeffs[1]; }
+                if (sum2) { sa.ca2 = sum2->coeffs[0]; sa.cb2 = sum2->coeffs[1]; }
+                sa.segs = plan.segs; sa.seg_begin = plan.seg_begin; sa.sink = n->d_sink;
+                auto launch_sw = [&](auto kern, int slot, size_t lds) -> int {
+                    if (!n->attr_set[slot]) {
+                        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                        n->attr_set[slot] = true;
+                    }
+                    hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(256), lds, n->stream, sa);
+                    return 0;
+                };
+                if (variant == 0) { if (launch_sw(g_conv3_sw<6, 1, false, 2, 0>, 24, sw_lds_bytes<6, 1>())) return 1; }
+                else if (variant == 1) { if (launch_sw(g_conv3_sw<6, 1, false, 2, 2>, 25, sw_lds_bytes<6, 1>())) return 1; }
+                else if (variant == 2) { if (launch_sw(g_conv3_sw<2, 2, false, 1, 0>, 26, sw_lds_bytes<2, 2>())) return 1; }
+                else if (variant == 3 && up) { if (launch_sw(g_conv3_sw<2, 2, true, 0, 0, true>, 31, sw_lds_bytes<2, 2>())) return 1; }
+                else if (variant == 3) { if (launch_sw(g_conv3_sw<2, 2, true, 0, 0>, 27, sw_lds_bytes<2, 2>())) return 1; }
+                else if (variant == 4) { if (launch_sw(g_conv3_sw<6, 1, false, 0, 0>, 29, sw_lds_bytes<6, 1>())) return 1; }
+                else { if (launch_sw(g_conv3_sw<2, 2, false, 0, 0>, 30, sw_lds_bytes<2, 2>())) return 1; }
+                HIP_TRY(hipGetLastError());
+                for (PlaneState& ps : P) finish_layer(ps);
+                continue;
+            }
+        }
+        // ---- everything else: one launch per plane ------------------------------------------------------------------------
+        for (PlaneState& ps : P) {
+        std::vector<GBuf>& buf = ps.buf;
+        const int h = ps.j.h, w = ps.j.w;
         GBuf o;
-        if (acquire_out(sum2 ? *sum2 : sum ? *sum : gl, &o)) return 1;       // (a fused convolution writes the last sum's array, it has none of its own)
+        if (acquire_out(ps, sum2 ? *sum2 : sum ? *sum : gl, &o)) return 1;       // (a fused convolution writes the last sum's array, it has none of its own)
         auto in = [&](int k) -> const GBuf& { return buf[root(gl.in[k])]; };
         switch (gl.kind) {
         case GLayer::INPUT:
-            if (f32) hipLaunchKernelGGL(g_input_f32, dim3((w + T - 1) / T, h), dim3(T), 0, n->stream, (const float*)src, h, w, o.p, o.cpad);
-            else hipLaunchKernelGGL(g_input_u8, dim3((w + T - 1) / T, h), dim3(T), 0, n->stream, (const uint8_t*)src, src_stride, sy0, sx0, h, w, o.p, o.cpad);
+            if (f32) hipLaunchKernelGGL(g_input_f32, dim3((w + T - 1) / T, h), dim3(T), 0, n->stream, (const float*)ps.j.src, h, w, o.p, o.cpad);
+            else hipLaunchKernelGGL(g_input_u8, dim3((w + T - 1) / T, h), dim3(T), 0, n->stream, (const uint8_t*)ps.j.src, ps.j.src_stride, ps.j.sy0, ps.j.sx0, h, w, o.p, o.cpad);
             break;
         case GLayer::CONV: {
             const GenericDevice::ConvDev& cd = n->gd.convs[gl.conv];
             const GBuf& a = in(0);
             if ((group_of(gl.out[0]) >= 0 || group_of(root(gl.in[0])) >= 0) && !cd.wpk_lds)
                 return fail("generic executor: a dense-chain convolution without the LDS kernel (plan_concat_groups and ensure_device disagree)");
-            if (rdb_at[layer_i] >= 0) {
-                const RdbMatch& m = n->gd.rdbs[rdb_at[layer_i]];
-                const GBuf& arr = garr[m.group];
-                GenericDevice::RdbPlan& plan = n->gd.rdb_plans[std::make_pair(a.h, a.w)];
-                if (!plan.segs) {
-                    std::vector<RdbSeg> segs;
-                    std::vector<int> sbeg;
-                    plan.grid = std::max(8, (n->ncu / 8) * 8);
-                    rdb_segments(a.h, a.w, plan.grid, segs, sbeg);
-                    if (upload(&plan.segs, segs.data(), segs.size() * sizeof(RdbSeg), n->stream)) return 1;
-                    if (upload(&plan.seg_begin, sbeg.data(), sbeg.size() * sizeof(int), n->stream)) return 1;
-                    HIP_TRY(hipStreamSynchronize(n->stream));
-                }
-                auto cdev = [&](int li) -> const GenericDevice::ConvDev& { return n->gd.convs[g.layers[li].conv]; };
-                RdbArgs ra;
-                std::memset(&ra, 0, sizeof ra);
-                ra.arr = arr.p; ra.stride = arr.cpad;
-                ra.w1 = cdev(m.c1).wpk; ra.w2 = cdev(m.c2).wpk; ra.w2s = cdev(m.c2s).wpk; ra.w3 = cdev(m.c3).wpk; ra.w4 = cdev(m.c4).wpk;
-                ra.b1 = cdev(m.c1).bias; ra.b2 = cdev(m.c2).bias; ra.b3 = cdev(m.c3).bias; ra.b4 = cdev(m.c4).bias;
-                ra.slope = m.slope;
-                ra.h = a.h; ra.w = a.w;
-                ra.segs = plan.segs; ra.seg_begin = plan.seg_begin; ra.sink = n->d_sink;
-#ifdef UVA_INSTRUMENT
-                if (std::getenv("UVA_RDB_STAMPS")) {
-                    if (!n->gd.rdb_dbg) HIP_TRY(hipMalloc((void**)&n->gd.rdb_dbg, 1024 * 16 * 8));
-                    HIP_TRY(hipMemsetAsync(n->gd.rdb_dbg, 0, 1024 * 16 * 8, n->stream));
-                    ra.dbg = n->gd.rdb_dbg;
-                }
-#endif
-                if (!n->attr_set[28]) {
-                    HIP_TRY(hipFuncSetAttribute((const void*)rdb4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                    n->attr_set[28] = true;
-                }
-                hipLaunchKernelGGL(rdb4_kernel, dim3(plan.grid), dim3(256), rdb4_lds_bytes(), n->stream, ra);
-                break;
-            }
-            // 3x3 convolutions with 64 output channels from 64 or 192 input channels: weights stationary in registers
-            // (g_conv3_sw, uva_rdb.hip.h).  UVA_GENERIC_SW=0: the layer-by-layer kernel below (the A/B switch).
-            if (const int cols = sw_cols_of(layer_i)) {
-                if (sw_variant(cd.cin_pad, gl.has_act, !sum ? 0 : fuse_pos[layer_i] == 1 ? 1 : 2, !sum2 ? 0 : fuse_pos2[layer_i] == 1 ? 1 : 2) >= 0) {
-                    GenericDevice::SwPlan& plan = n->gd.sw_plans[std::make_tuple(a.h, a.w, cols)];
-                    if (!plan.segs) {
-                        std::vector<GSwSeg> segs;
-                        std::vector<int> sbeg;
-                        plan.grid = std::max(8, (n->ncu / 8) * 8);
-                        sw_segments(a.h, a.w, cols, plan.grid, segs, sbeg);
-                        if (upload(&plan.segs, segs.data(), segs.size() * sizeof(GSwSeg), n->stream)) return 1;
-                        if (upload(&plan.seg_begin, sbeg.data(), sbeg.size() * sizeof(int), n->stream)) return 1;
-                        HIP_TRY(hipStreamSynchronize(n->stream));       // (the vectors go away)
-                    }
-                    GSwArgs sa;
-                    std::memset(&sa, 0, sizeof sa);
-                    sa.in = a.p; sa.in_stride = a.cpad; sa.wpk = cd.wpk; sa.bias = cd.bias;
-                    sa.out = o.p; sa.out_stride = o.cpad; sa.out_coff = 0;
-                    sa.h = a.h; sa.w = a.w;
-                    sa.slope = gl.act_slope;
-                    if (sum) {
-                        const GBuf& other = buf[root(sum->in[1 - fuse_pos[layer_i]])];
-                        sa.res = other.p; sa.res_stride = other.cpad;
-                        sa.ca = sum->coeffs[0]; sa.cb = sum->coeffs[1];
-                    }
-                    if (sum2) {
-                        const GBuf& other = buf[root(sum2->in[1 - fuse_pos2[layer_i]])];
-                        sa.res2 = other.p; sa.res2_stride = other.cpad;
-                        sa.ca2 = sum2->coeffs[0]; sa.cb2 = sum2->coeffs[1];
-                    }
-                    sa.segs = plan.segs; sa.seg_begin = plan.seg_begin; sa.sink = n->d_sink;
-                    auto launch_sw = [&](auto kern, int slot, size_t lds) -> int {
-                        if (!n->attr_set[slot]) {
-                            HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                            n->attr_set[slot] = true;
-                        }
-                        hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(256), lds, n->stream, sa);
-                        return 0;
-                    };
-                    const int rm = !sum ? 0 : fuse_pos[layer_i] == 1 ? 1 : 2, rm2 = !sum2 ? 0 : fuse_pos2[layer_i] == 1 ? 1 : 2;
-                    const int variant = sw_variant(cd.cin_pad, gl.has_act, rm, rm2);
-                    if (variant == 0) { if (launch_sw(g_conv3_sw<6, 1, false, 2, 0>, 24, sw_lds_bytes<6, 1>())) return 1; }
-                    else if (variant == 1) { if (launch_sw(g_conv3_sw<6, 1, false, 2, 2>, 25, sw_lds_bytes<6, 1>())) return 1; }
-                    else if (variant == 2) { if (launch_sw(g_conv3_sw<2, 2, false, 1, 0>, 26, sw_lds_bytes<2, 2>())) return 1; }
-                    else if (variant == 3) { if (launch_sw(g_conv3_sw<2, 2, true, 0, 0>, 27, sw_lds_bytes<2, 2>())) return 1; }
-                    else if (variant == 4) { if (launch_sw(g_conv3_sw<6, 1, false, 0, 0>, 29, sw_lds_bytes<6, 1>())) return 1; }
-                    else { if (launch_sw(g_conv3_sw<2, 2, false, 0, 0>, 30, sw_lds_bytes<2, 2>())) return 1; }
-                    break;
-                }
-            }
             if (cd.wpk_lds && n->generic_lds_conv) {
                 GConvArgs ga;
                 std::memset(&ga, 0, sizeof ga);
@@ -1419,32 +1494,53 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
         default: return fail("generic executor: unhandled layer kind");
         }
         HIP_TRY(hipGetLastError());
-        for (int b : gl.in) done_with(b);
-        if (sum) done_with(sum->in[1 - fuse_pos[layer_i]]);
-        if (sum2) done_with(sum2->in[1 - fuse_pos2[layer_i]]);
+        finish_layer(ps);
+        }
     }
-    const GBuf& res = buf[root(g.out_blob)];
-    const int s = g.scale;
-    if (f32) hipLaunchKernelGGL(g_output_f32, dim3((w * s + T - 1) / T, h * s), dim3(T), 0, n->stream, res.p, h * s, w * s, res.cpad, (float*)dst);
-    else if (cx1 > cx0 && cy1 > cy0)
-        hipLaunchKernelGGL(g_output_u8, dim3(((cx1 - cx0) * s + T - 1) / T, (cy1 - cy0) * s), dim3(T), 0, n->stream, res.p, h * s, w * s, res.cpad,
-                           (uint8_t*)dst, dst_stride, sy0 * s, sx0 * s, cy0 * s, cy1 * s, cx0 * s, cx1 * s);
-    HIP_TRY(hipGetLastError());
-    done_with(g.out_blob);
+    const int T2 = 256;
+    for (PlaneState& ps : P) {
+        const PlaneJob& j = ps.j;
+        const GBuf& res = ps.buf[root(g.out_blob)];
+        const int s = g.scale;
+        if (f32) hipLaunchKernelGGL(g_output_f32, dim3((j.w * s + T2 - 1) / T2, j.h * s), dim3(T2), 0, n->stream, res.p, j.h * s, j.w * s, res.cpad, (float*)j.dst);
+        else if (j.cx1 > j.cx0 && j.cy1 > j.cy0)
+            hipLaunchKernelGGL(g_output_u8, dim3(((j.cx1 - j.cx0) * s + T2 - 1) / T2, (j.cy1 - j.cy0) * s), dim3(T2), 0, n->stream, res.p, j.h * s, j.w * s, res.cpad,
+                               (uint8_t*)j.dst, j.dst_stride, j.sy0 * s, j.sx0 * s, j.cy0 * s, j.cy1 * s, j.cx0 * s, j.cx1 * s);
+        HIP_TRY(hipGetLastError());
+        done_with(ps, g.out_blob);
+    }
     return 0;
 }
 
-// the u8 frame call for a generic graph: every reference tile (upscale_processing.py:499-516) is one plane, run in turn
+int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, int sy0, int sx0, int h, int w, void* dst,
+                      size_t dst_stride, int cy0, int cy1, int cx0, int cx1)
+{
+    return generic_run_planes(n, f32, std::vector<PlaneJob>{PlaneJob{src, src_stride, sy0, sx0, h, w, dst, dst_stride, cy0, cy1, cx0, cx1}});
+}
+
+// the u8 frame call for a generic graph: every reference tile (upscale_processing.py:499-516) is one plane; planes that
+// take the same kernels go through the graph together (UVA_GENERIC_BATCH=0: one after the other, the A/B switch)
 int generic_process_u8_device(uva_net* n, const void* d_in, int h, int w, size_t in_stride, void* d_out, size_t out_stride,
                               int tile_size, int border)
 {
     std::vector<PlaneDesc> planes;
     if (tile_size <= 0) { tile_size = 0; border = 0; }
     if (build_planes(h, w, tile_size, border, planes)) return 1;
-    for (const PlaneDesc& p : planes)
-        if (generic_run_plane(n, false, d_in, in_stride, p.src_y0, p.src_x0, p.h, p.w, d_out, out_stride, p.core_y0,
-                              std::min(p.core_y1, p.h), p.core_x0, std::min(p.core_x1, p.w)))
-            return 1;
+    static const bool batch_on = [] { const char* e = std::getenv("UVA_GENERIC_BATCH"); return !e || std::atoi(e) != 0; }();
+    std::vector<std::vector<PlaneJob>> batches;
+    std::vector<int> batch_class;
+    for (const PlaneDesc& p : planes) {
+        const PlaneJob j{d_in, in_stride, p.src_y0, p.src_x0, p.h, p.w, d_out, out_stride, p.core_y0, std::min(p.core_y1, p.h), p.core_x0,
+                         std::min(p.core_x1, p.w)};
+        const int cls = generic_plane_class(p.w);
+        size_t k = 0;
+        for (; batch_on && k < batches.size(); ++k)
+            if (batch_class[k] == cls && (int)batches[k].size() < GEN_MAX_PLANES) break;
+        if (!batch_on || k == batches.size()) { batches.emplace_back(); batch_class.push_back(cls); k = batches.size() - 1; }
+        batches[k].push_back(j);
+    }
+    for (const auto& b : batches)
+        if (generic_run_planes(n, false, b)) return 1;
     return 0;
 }
 
@@ -2497,19 +2593,24 @@ int uva_debug_sub10_rows(int h, int w, int grid, uint32_t* rows_words, size_t ca
     return 0;
 }
 
-int uva_debug_generic_segments(int kind, int h, int w, int grid, int32_t* out, size_t capacity_words, size_t* needed_words, int* seg_begin)
+int uva_debug_generic_segments_planes(int kind, const int* dims, int nplanes, int grid, int32_t* out, size_t capacity_words,
+                                      size_t* needed_words, int* seg_begin)
 {
-    if (h <= 0 || w <= 0 || grid <= 0) return fail("bad argument");
+    if (!dims || nplanes <= 0 || nplanes > GEN_MAX_PLANES || grid <= 0) return fail("bad argument");
+    for (int i = 0; i < 2 * nplanes; ++i)
+        if (dims[i] <= 0) return fail("bad argument");
+    const std::vector<int> d(dims, dims + 2 * nplanes);
     std::vector<int32_t> words;
     std::vector<int> sbeg;
     if (kind == 0) {
         std::vector<RdbSeg> segs;
-        rdb_segments(h, w, grid, segs, sbeg);
-        for (const RdbSeg& sg : segs) words.insert(words.end(), {sg.c0, sg.yb, sg.ye, sg.own0, sg.own1, 0, 0, 0});
+        rdb_segments(d, grid, segs, sbeg);
+        for (const RdbSeg& sg : segs) words.insert(words.end(), {sg.c0, sg.yb, sg.ye, sg.own0, sg.own1, sg.plane, 0, 0});
     } else if (kind == 1 || kind == 2) {
         std::vector<GSwSeg> segs;
-        sw_segments(h, w, kind == 1 ? sw_cols<1>() : sw_cols<2>(), grid, segs, sbeg);
-        for (const GSwSeg& sg : segs) words.insert(words.end(), {sg.c0, sg.y0, sg.y1, sg.c0, sg.c0 + (kind == 1 ? sw_cols<1>() : sw_cols<2>()), 0, 0, 0});
+        const int cols = kind == 1 ? sw_cols<1>() : sw_cols<2>();
+        sw_segments(d, cols, grid, segs, sbeg);
+        for (const GSwSeg& sg : segs) words.insert(words.end(), {sg.c0, sg.y0, sg.y1, sg.c0, sg.c0 + cols, sg.plane, 0, 0});
     } else {
         return fail("bad kind");
     }
@@ -2518,6 +2619,12 @@ int uva_debug_generic_segments(int kind, int h, int w, int grid, int32_t* out, s
     std::memcpy(out, words.data(), words.size() * sizeof(int32_t));
     if (seg_begin) std::copy(sbeg.begin(), sbeg.end(), seg_begin);
     return 0;
+}
+
+int uva_debug_generic_segments(int kind, int h, int w, int grid, int32_t* out, size_t capacity_words, size_t* needed_words, int* seg_begin)
+{
+    const int dims[2] = {h, w};
+    return uva_debug_generic_segments_planes(kind, dims, 1, grid, out, capacity_words, needed_words, seg_begin);
 }
 
 }  // extern "C"

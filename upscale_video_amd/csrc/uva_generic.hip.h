@@ -466,42 +466,66 @@ __global__ void g_output_f32(const _Float16* in, int ho, int wo, int cpad, float
     for (int c = 0; c < 3; ++c) dst[((size_t)c * ho + Y) * wo + X] = (float)s[c];
 }
 
-// g_conv3_sw's work list: the plane is cut into strips of `cols` columns, a strip into blocks of SW_R rows; the blocks,
-// strip after strip and top to bottom, are dealt out to `grid` workgroups in contiguous runs of equal length (+-1); a
-// run that crosses a strip's end becomes two segments.  seg_begin has grid + 1 entries.
-inline void sw_segments(int h, int w, int cols, int grid, std::vector<GSwSeg>& segs, std::vector<int>& seg_begin)
+// g_conv3_sw's work list: every plane (dims[2k], dims[2k+1] = its height, width) is cut into strips of `cols` columns, a
+// strip into blocks of SW_R rows; the blocks -- plane after plane, strip after strip, top to bottom -- are dealt out to
+// `grid` workgroups in contiguous runs of equal length (+-1); a run that crosses a strip's end becomes two segments.
+// seg_begin has grid + 1 entries.
+inline void sw_segments(const std::vector<int>& dims, int cols, int grid, std::vector<GSwSeg>& segs, std::vector<int>& seg_begin)
 {
-    const int ns = (w + cols - 1) / cols, nb = (h + SW_R - 1) / SW_R;
-    const long long total = (long long)ns * nb;
+    struct Strip { int plane, c0, nb, h; };
+    std::vector<Strip> strips;
+    long long total = 0;
+    for (size_t pl = 0; 2 * pl + 1 < dims.size(); ++pl) {
+        const int h = dims[2 * pl], w = dims[2 * pl + 1], nb = (h + SW_R - 1) / SW_R;
+        for (int c0 = 0; c0 < w; c0 += cols) { strips.push_back(Strip{(int)pl, c0, nb, h}); total += nb; }
+    }
     segs.clear();
     seg_begin.assign(1, 0);
+    size_t si = 0;
+    long long sbase = 0;                       // blocks before strip si
     for (int g = 0; g < grid; ++g) {
         long long u = total * g / grid;
         const long long u1 = total * (g + 1) / grid;
         while (u < u1) {
-            const int s = (int)(u / nb), b0 = (int)(u - (long long)s * nb);
-            const int b1 = (int)std::min<long long>(nb, b0 + (u1 - u));
-            segs.push_back(GSwSeg{s * cols, b0 * SW_R, std::min(h, b1 * SW_R), 0});
+            while (u >= sbase + strips[si].nb) { sbase += strips[si].nb; ++si; }
+            const Strip& st = strips[si];
+            const int b0 = (int)(u - sbase), b1 = (int)std::min<long long>(st.nb, b0 + (u1 - u));
+            segs.push_back(GSwSeg{st.c0, b0 * SW_R, std::min(st.h, b1 * SW_R), st.plane});
             u += b1 - b0;
         }
         seg_begin.push_back((int)segs.size());
     }
 }
+inline void sw_segments(int h, int w, int cols, int grid, std::vector<GSwSeg>& segs, std::vector<int>& seg_begin)
+{
+    sw_segments(std::vector<int>{h, w}, cols, grid, segs, seg_begin);
+}
 
 // rdb4_kernel's work list: strips of 48 computed columns that own 42 of them (45 at the plane's left edge, everything up
-// to the right edge in the last one), cut into row segments; the rows, strip after strip, are dealt out to `grid`
-// workgroups in contiguous runs of equal length (every segment costs RA_LAG extra steps, so runs are not cut finer).
-inline void rdb_segments(int h, int w, int grid, std::vector<RdbSeg>& segs, std::vector<int>& seg_begin)
+// to the right edge in the last one), cut into row segments.
+inline void rdb_strips(int h, int w, int plane, std::vector<RdbSeg>& strips)
 {
-    std::vector<RdbSeg> strips;
     for (int own0 = 0; own0 < w;) {
         RdbSeg s{};
         s.c0 = own0 == 0 ? 0 : own0 - 3;
         s.own0 = own0;
         s.own1 = s.c0 + RA_C >= w ? w : s.c0 + RA_C - 3;
+        s.yb = 0;
+        s.ye = h;
+        s.plane = plane;
         strips.push_back(s);
         own0 = s.own1;
     }
+}
+// Several planes in one launch (dims[2k], dims[2k+1] = height, width of plane k): the rows of all strips, plane after
+// plane and strip after strip, are dealt out to the workgroups in contiguous runs of equal length; a run that crosses a
+// strip's end becomes two segments (each costs RA_LAG steps of pipeline fill: with a whole frame's rows to share, runs are
+// a couple of hundred rows long).  One plane: rdb_segments(h, w, ...) below, one segment per workgroup.
+inline void rdb_segments(const std::vector<int>& dims, int grid, std::vector<RdbSeg>& segs, std::vector<int>& seg_begin);
+inline void rdb_segments(int h, int w, int grid, std::vector<RdbSeg>& segs, std::vector<int>& seg_begin)
+{
+    std::vector<RdbSeg> strips;
+    rdb_strips(h, w, 0, strips);
     // Every segment costs RA_LAG steps of pipeline fill, so a workgroup gets ONE: each strip is cut into k = grid / strips
     // equal row ranges (a few workgroups stay idle; with more strips than workgroups, whole strips are dealt out in turn).
     segs.clear();
@@ -532,6 +556,36 @@ inline void rdb_segments(int h, int w, int grid, std::vector<RdbSeg>& segs, std:
     }
 }
 
+inline void rdb_segments(const std::vector<int>& dims, int grid, std::vector<RdbSeg>& segs, std::vector<int>& seg_begin)
+{
+    if (dims.size() == 2) { rdb_segments(dims[0], dims[1], grid, segs, seg_begin); return; }
+    std::vector<RdbSeg> strips;
+    long long total = 0;
+    for (size_t pl = 0; 2 * pl + 1 < dims.size(); ++pl) {
+        const size_t n0 = strips.size();
+        rdb_strips(dims[2 * pl], dims[2 * pl + 1], (int)pl, strips);
+        total += (long long)(strips.size() - n0) * dims[2 * pl];
+    }
+    segs.clear();
+    seg_begin.assign(1, 0);
+    size_t si = 0;
+    long long sbase = 0;                       // rows before strip si
+    for (int g = 0; g < grid; ++g) {
+        long long u = total * g / grid;
+        const long long u1 = total * (g + 1) / grid;
+        while (u < u1) {
+            while (u >= sbase + strips[si].ye) { sbase += strips[si].ye; ++si; }
+            RdbSeg sg = strips[si];
+            const int y0 = (int)(u - sbase), y1 = (int)std::min<long long>(sg.ye, y0 + (u1 - u));
+            sg.yb = y0;
+            sg.ye = y1;
+            segs.push_back(sg);
+            u += y1 - y0;
+        }
+        seg_begin.push_back((int)segs.size());
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 struct GenericDevice {
     struct ConvDev {
@@ -546,9 +600,9 @@ struct GenericDevice {
     size_t pool_bytes = 0;
     // g_conv3_sw: the strip segments of an h x w plane, dealt out to `grid` workgroups (sw_segments)
     struct SwPlan { GSwSeg* segs = nullptr; int* seg_begin = nullptr; int grid = 0; };
-    std::map<std::tuple<int, int, int>, SwPlan> sw_plans;                 // (h, w, strip columns)
+    std::map<std::vector<int>, SwPlan> sw_plans;                          // (strip columns, h0, w0, h1, w1, ...)
     struct RdbPlan { RdbSeg* segs = nullptr; int* seg_begin = nullptr; int grid = 0; };
-    std::map<std::pair<int, int>, RdbPlan> rdb_plans;                     // (h, w)
+    std::map<std::vector<int>, RdbPlan> rdb_plans;                        // (h0, w0, h1, w1, ...)
     std::vector<RdbMatch> rdbs;                                           // find_rdbs() of the loaded graph
     unsigned long long* rdb_dbg = nullptr;                                // UVA_INSTRUMENT + UVA_RDB_STAMPS=1: rdb4_kernel's stamps
 

@@ -38,24 +38,25 @@
 
 namespace uva {
 
-struct GSwSeg { int c0, y0, y1, pad; };       // output columns [c0, c0 + SW_C) x rows [y0, y1) of the plane, y1 - y0 a multiple of 4
-                                              // except at the plane's bottom
+struct GSwSeg { int c0, y0, y1, plane; };     // output columns [c0, c0 + SW_C) x rows [y0, y1) of plane `plane`, y1 - y0 a multiple
+                                              // of 4 except at the plane's bottom
+constexpr int GEN_MAX_PLANES = 16;            // planes (reference tiles) of a frame that one launch of the kernels below takes
 
 struct GSwArgs {
-    const _Float16* in;           // zero-bordered array [(h+3)][(w+2)][in_stride]; pixel (y, x) at row y+1, column x+1
-    int in_stride;                // elements per pixel; channels read: [0, 32*KC)
+    // per plane (all planes of a launch: same layer, same strides): zero-bordered arrays [(h+3)][(w+2)][stride], pixel (y, x)
+    // at row y+1, column x+1
+    const _Float16* in[GEN_MAX_PLANES];     // channels read: [0, 32*KC)
+    _Float16* out[GEN_MAX_PLANES];
+    const _Float16* res[GEN_MAX_PLANES];    // the element-wise sum behind the convolution (GConvArgs::res: same expression, same rounding)
+    const _Float16* res2[GEN_MAX_PLANES];   // ... and a second sum behind the first: out = x2*ca2 + y2*cb2, one of them the first sum's result
+    int ph[GEN_MAX_PLANES], pw[GEN_MAX_PLANES];
+    int in_stride;                // elements per pixel
     const half8* wpk;             // pack_generic image (natural octet order): [tap][KC][4][64 lanes][8]
     const float* bias;            // [64]
-    _Float16* out;
     int out_stride, out_coff;
-    int h, w;
     float slope;                  // LeakyReLU (template ACT)
-    // the element-wise sum behind the convolution (GConvArgs::res in uva_generic.hip.h: same expression, same rounding)
-    const _Float16* res;
     int res_stride;
     float ca, cb;
-    // ... and a second sum behind the first: out = x2*ca2 + y2*cb2, one of them the first sum's result
-    const _Float16* res2;
     int res2_stride;
     float ca2, cb2;
     const GSwSeg* segs;           // this launch's segments; workgroup g owns segs[seg_begin[g] .. seg_begin[g+1])
@@ -89,7 +90,11 @@ __device__ __forceinline__ _Float16 g_axpby1(float x, float ca, float y, float c
 
 // RES / RES2: the first / second fused sum -- 0 none, 1 the other operand is the sum's x (out = res*ca + conv*cb), 2 the
 // convolution's side is (out = conv*ca + res*cb); g_axpby1 is not symmetric in x and y, so the order is part of the bytes
-template <int KC, int MBW, bool ACT, int RES, int RES2>
+// UP: the input is the nearest-neighbour 2x enlargement (ncnn Interp, resize_type 1) of the array `in` points at: ring
+// column / row r of the enlarged plane's array is column / row (r + 1) >> 1 of the source's (borders included: 0 -> 0,
+// 2n + 1 -> n + 1), so the row DMA just fetches from there -- every lane of an LDS-DMA has its own address -- and the
+// enlarged array (16x the bytes of the 1x plane at 4x) is never written or read.  ph, pw stay the OUTPUT plane's size.
+template <int KC, int MBW, bool ACT, int RES, int RES2, bool UP = false>
 __global__ __launch_bounds__(256, 1) void g_conv3_sw(GSwArgs a)
 {
     constexpr int C = sw_cols<MBW>(), RC = C + 2, NP = sw_np<KC, MBW>(), ROWB = sw_rowb<KC, MBW>();
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(256, 1) void g_conv3_sw(GSwArgs a)
         const int idx = min((wave + 4 * k) * 64 + lane, KC * RC * 4 - 1);
         const int ch = idx / (RC * 4), rem = idx - ch * (RC * 4), rc = rem >> 2, sl = rem & 3;
         const int u = sl ^ (((rc >> 2) & 1) << 1);
-        voff[k] = (unsigned)(rc * a.in_stride * 2 + ch * 64 + u * 16);
+        voff[k] = (unsigned)((UP ? (rc + 1) >> 1 : rc) * a.in_stride * 2 + ch * 64 + u * 16);        // (UP: c0 is even)
     }
     if (threadIdx.x < 64) lbias[threadIdx.x] = a.bias ? a.bias[threadIdx.x] : 0.f;
 
@@ -127,14 +132,25 @@ __global__ __launch_bounds__(256, 1) void g_conv3_sw(GSwArgs a)
         offdx[dx] = (unsigned)((cw + rc) * 64 + ((o ^ (((rc >> 2) & 1) << 1)) * 16));
     }
     const unsigned ring_lds = lds_offset(ring);
-    const size_t in_pitch = (size_t)(a.w + 2) * a.in_stride;       // elements per array row
     _Float16* const sink = a.sink + lane * 4;
+    // the plane of the current segment
+    const _Float16* pin = nullptr;
+    _Float16* pout = nullptr;
+    const _Float16* pres = nullptr;
+    const _Float16* pres2 = nullptr;
+    int ph = 0, pw = 0;
+    size_t in_pitch = 0;                                           // elements per array row
+    auto set_plane = [&](int pl) {
+        pin = a.in[pl]; pout = a.out[pl]; pres = a.res[pl]; pres2 = a.res2[pl];
+        ph = a.ph[pl]; pw = a.pw[pl];
+        in_pitch = (size_t)((UP ? pw >> 1 : pw) + 2) * a.in_stride;
+    };
 
     // ring row rr of a segment holds plane row y0 - 1 + rr = array row y0 + rr (rows below the bottom border: the border
     // row again -- zeros that only feed rows nobody stores) in slot rr % 10
     auto dma_row = [&](int c0, int y0, int rr) {
-        const int ay = min(y0 + rr, a.h + 1);
-        const char* const src = (const char*)(a.in + (size_t)ay * in_pitch + (size_t)c0 * a.in_stride);
+        const int ayo = min(y0 + rr, ph + 1), ay = UP ? (ayo + 1) >> 1 : ayo;
+        const char* const src = (const char*)(pin + (size_t)ay * in_pitch + (size_t)(UP ? c0 >> 1 : c0) * a.in_stride);
         const unsigned dst = ring_lds + (unsigned)(rr % SW_SLOTS) * ROWB + wave * 1024;
 #pragma unroll
         for (int k = 0; k < NPW; ++k)
@@ -144,6 +160,7 @@ __global__ __launch_bounds__(256, 1) void g_conv3_sw(GSwArgs a)
     const int sb = a.seg_begin[blockIdx.x], se = a.seg_begin[blockIdx.x + 1];
     if (sb < se) {        // the first segment's rows are on their way while the weights arrive
         const GSwSeg seg = a.segs[sb];
+        set_plane(__builtin_amdgcn_readfirstlane(seg.plane));
         for (int rr = 0; rr < NIR; ++rr) dma_row(seg.c0, seg.y0, rr);
     }
     // this wave's weights: k-step (tap, chunk) x its channel blocks
@@ -170,16 +187,16 @@ __global__ __launch_bounds__(256, 1) void g_conv3_sw(GSwArgs a)
     auto tile_pos = [&](int j, int c0, int y0, int y1, int b, bool* inside) -> size_t {
         const int m = j % MBW, f = (j / MBW) % NF, r = j / (MBW * NF);
         const int y = y0 + SW_R * b + r, x = c0 + cw + 16 * f + p;
-        *inside = y < y1 && x < a.w;
-        return ((size_t)(min(y, a.h - 1) + 1) * (a.w + 2) + 1 + min(x, a.w - 1));      // (clamped: lanes outside read a real pixel)
+        *inside = y < y1 && x < pw;
+        return ((size_t)(min(y, ph - 1) + 1) * (pw + 2) + 1 + min(x, pw - 1));      // (clamped: lanes outside read a real pixel)
     };
     auto load_res = [&](int j, int c0, int y0, int y1, int b) {
         if constexpr (RES != 0 || RES2 != 0) {
             bool in;
             const size_t pos = tile_pos(j, c0, y0, y1, b, &in);
             const int ch = 16 * (mb0 + j % MBW) + 4 * o;
-            if constexpr (RES != 0) rsv[j] = *(const half4*)(a.res + pos * a.res_stride + ch);
-            if constexpr (RES2 != 0) rsw[j] = *(const half4*)(a.res2 + pos * a.res2_stride + ch);
+            if constexpr (RES != 0) rsv[j] = *(const half4*)(pres + pos * a.res_stride + ch);
+            if constexpr (RES2 != 0) rsw[j] = *(const half4*)(pres2 + pos * a.res2_stride + ch);
         }
     };
     auto epi_tile = [&](auto Jc, const f32x4 (&acc)[SW_R][NF][MBW], int c0, int y0, int y1, int b) {
@@ -204,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void g_conv3_sw(GSwArgs a)
         }
         bool in;
         const size_t pos = tile_pos(j, c0, y0, y1, b, &in);
-        _Float16* const dst = (UVA_SW_DBG < 1 && in) ? a.out + pos * a.out_stride + a.out_coff + 16 * (mb0 + m) + 4 * o : sink;
+        _Float16* const dst = (UVA_SW_DBG < 1 && in) ? pout + pos * a.out_stride + a.out_coff + 16 * (mb0 + m) + 4 * o : sink;
         if (UVA_SW_DBG >= 1) { asm volatile("" ::"v"(cv)); return; }
         asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(cv) : "memory");
     };
@@ -261,6 +278,7 @@ __global__ __launch_bounds__(256, 1) void g_conv3_sw(GSwArgs a)
                   y1 = __builtin_amdgcn_readfirstlane(seg.y1);
         if (si > sb) {
             sw_barrier();                      // the previous segment's last reads are done
+            set_plane(__builtin_amdgcn_readfirstlane(seg.plane));
             for (int rr = 0; rr < NIR; ++rr) dma_row(c0, y0, rr);
         }
         sw_barrier();
@@ -329,10 +347,11 @@ __global__ __launch_bounds__(256, 1) void g_conv3_sw(GSwArgs a)
 // are written as zero (the next convolution's padding), rows above a segment's first output row are recomputed (3 of x1, 2
 // of x2, 1 of x3).  Rounding points are the layer-by-layer executor's: every convolution result -> fp16, the two sums as
 // g_axpby1 of fp16 operands.
-struct RdbSeg { int c0, yb, ye, own0, own1, pad0, pad1, pad2; };   // computed columns [c0, c0+48); output rows [yb, ye), columns [own0, own1)
+struct RdbSeg { int c0, yb, ye, own0, own1, plane, pad1, pad2; };   // of plane `plane`: computed columns [c0, c0+48); output rows [yb, ye), columns [own0, own1)
 
 struct RdbArgs {
-    _Float16* arr;                // the dense chain's array [(h+3)][(w+2)][stride]: channels 0..63 = x (read), 64..191 = x1..x4 (written)
+    _Float16* arr[GEN_MAX_PLANES];   // per plane: the dense chain's array [(h+3)][(w+2)][stride]: channels 0..63 = x (read), 64..191 = x1..x4 (written)
+    int ph[GEN_MAX_PLANES], pw[GEN_MAX_PLANES];
     int stride;
     const half8* w1;              // pack_generic images (natural order), cout_pad 32: [tap][cin/32][2][64][8]
     const half8* w2;
@@ -344,7 +363,6 @@ struct RdbArgs {
     const float* b3;
     const float* b4;
     float slope;
-    int h, w;
     const RdbSeg* segs;
     const int* seg_begin;
     _Float16* sink;
@@ -394,8 +412,11 @@ __global__ __launch_bounds__(256, 1) void rdb4_kernel(RdbArgs a)
     };
     lane_offsets(lane);
     const unsigned smem_lds = lds_offset(smem);
-    const size_t pitch = (size_t)(a.w + 2) * a.stride;               // elements per array row
     _Float16* const sink = a.sink + lane * 4;
+    // the plane of the current segment (seg_setup)
+    _Float16* parr = nullptr;
+    int ph = 0, pw = 0;
+    size_t pitch = 0;                                                // elements per array row
 
     // ---- building blocks -----------------------------------------------------------------------------------------
     // LDS address of ring row q (q = row - R0 + 8 >= 0) of ring g: 0 = x (two chunks), 1..3 = x1..x3
@@ -497,15 +518,18 @@ __global__ __launch_bounds__(256, 1) void rdb4_kernel(RdbArgs a)
     unsigned pmask = 0;
     _Float16* gptr[2];
     auto seg_setup = [&](const RdbSeg& sg) {
+        const int pl = __builtin_amdgcn_readfirstlane(sg.plane);
+        parr = a.arr[pl]; ph = a.ph[pl]; pw = a.pw[pl];
+        pitch = (size_t)(pw + 2) * a.stride;
         pmask = 0;
 #pragma unroll
         for (int f = 0; f < RA_NF; ++f) {
             const int x = sg.c0 + 16 * f + p;
-            pmask |= (x < a.w ? 1u : 0u) << f;
-            pmask |= (x < a.w && x >= sg.own0 && x < sg.own1 ? 1u : 0u) << (4 + f);
+            pmask |= (x < pw ? 1u : 0u) << f;
+            pmask |= (x < pw && x >= sg.own0 && x < sg.own1 ? 1u : 0u) << (4 + f);
         }
 #pragma unroll
-        for (int m = 0; m < 2; ++m) gptr[m] = a.arr + (size_t)(sg.c0 + p + 1) * a.stride + 64 + 16 * m + 4 * o;
+        for (int m = 0; m < 2; ++m) gptr[m] = parr + (size_t)(sg.c0 + p + 1) * a.stride + 64 + 16 * m + 4 * o;
     };
     struct RowOut { unsigned rbase; size_t goff; unsigned keep; };     // keep: pmask's bits that count for this row
     // result row `row` (ring row q) of convolution `conv` (1..4)
@@ -513,7 +537,7 @@ __global__ __launch_bounds__(256, 1) void rdb4_kernel(RdbArgs a)
         RowOut r;
         r.rbase = conv == 1 ? rowaddr(1, q) : conv == 2 ? rowaddr(2, q) : rowaddr(3, q);
         r.goff = (size_t)(row + 1) * pitch + 32 * (conv - 1);
-        r.keep = ((row >= 0) & (row < a.h) ? 0x0fu : 0u) | ((row >= sg.yb) & (row < sg.ye) ? 0xf0u : 0u);
+        r.keep = ((row >= 0) & (row < ph) ? 0x0fu : 0u) | ((row >= sg.yb) & (row < sg.ye) ? 0xf0u : 0u);
         return r;
     };
     // one tile (fragment f, channel block m) of a result row: zero outside the plane -> the ring (conv < 4) and, for the
@@ -538,12 +562,12 @@ __global__ __launch_bounds__(256, 1) void rdb4_kernel(RdbArgs a)
             const int idx = min(k * 64 + lane, 2 * RA_RC * 4 - 1);
             const int ch = idx / (RA_RC * 4), rem = idx - ch * (RA_RC * 4), rc = rem >> 2, sl = rem & 3;
             const int u = sl ^ (((rc >> 2) & 1) << 1);
-            voff[k] = (unsigned)(min(sg.c0 + rc, a.w + 1) * a.stride * 2 + ch * 64 + u * 16);
+            voff[k] = (unsigned)(min(sg.c0 + rc, pw + 1) * a.stride * 2 + ch * 64 + u * 16);
         }
     };
     auto dma_x = [&](int row, int R0) {
-        const int ay = (row < -1 || row > a.h) ? 0 : row + 1;
-        const char* const src = (const char*)(a.arr + (size_t)ay * pitch);
+        const int ay = (row < -1 || row > ph) ? 0 : row + 1;
+        const char* const src = (const char*)(parr + (size_t)ay * pitch);
         const unsigned dst = smem_lds + rowaddr(0, row - R0 + 8);
 #pragma unroll
         for (int k = 0; k < RA_NDMA; ++k) {
