@@ -41,3 +41,27 @@ for name, om in (("id", lambda o:o), ("0213", lambda o:[0,2,1,3][o])):
             f = lambda col, u, H=H, sh=sh: u ^ H[(col >> sh) & 3]
             if ok(4, f, gpix, om): found.append((H, sh))
     print("gpix", name, found[:10], len(found))
+
+# ---- rdb4_kernel: the same row layout is also WRITTEN (result rows, ds_write_b64: four groups of 16 contiguous lanes,
+# bank = (a / 4) mod 32, MI355X_MICROARCH.md LDS table): lane (oo, pp) stores bytes 8*(oo & 1).. of unit 2m + (oo >> 1) of
+# pixel pp + 1.  Among the read-conflict-free XOR tables, how many lanes of a group share a bank pair at worst?
+def write_ways(f):
+    worst = 0
+    for c0 in range(64):
+        for m in range(2):
+            for oo in range(4):
+                cnt = {}
+                for pp in range(16):
+                    rc = c0 + pp + 1
+                    a8 = (rc * 64 + f(rc, 2 * m + (oo >> 1)) * 16 + (oo & 1) * 8) // 8
+                    cnt[a8 % 16] = cnt.get(a8 % 16, 0) + 1
+                worst = max(worst, max(cnt.values()))
+    return worst
+res = []
+for H in itertools.product(range(4), repeat=4):
+    for sh in (0, 1, 2, 3):
+        f = lambda col, u, H=H, sh=sh: u ^ H[(col >> sh) & 3]
+        if ok(4, f): res.append((write_ways(f), H, sh))
+res.sort()
+print("read-conflict-free tables by worst ds_write_b64 multiplicity:", res[:4], "...", res[-1])
+# -> (2, (0, 1, 2, 3), 1) = u ^ ((col >> 1) & 3) is 2-way (rdb4_kernel's ra_swz); g_conv3_sw's (0, 2, 0, 2) at shift 2 is 4-way

@@ -375,6 +375,12 @@ constexpr int RA_CHB = RA_RC * 64;                                   // one chun
 constexpr int RA_XS = 10, RA_1S = 8, RA_2S = 6, RA_3S = 4;           // ring rows
 constexpr int RA_X_OFF = 0, RA_X1_OFF = RA_X_OFF + RA_XS * 2 * RA_CHB, RA_X2_OFF = RA_X1_OFF + RA_1S * RA_CHB,
               RA_X3_OFF = RA_X2_OFF + RA_2S * RA_CHB, RA_P_OFF = RA_X3_OFF + RA_3S * RA_CHB;
+// rdb4_kernel's rings use g_conv3_sw's row layout with a FOUR-valued slot swizzle, unit u of ring column rc in slot
+// u ^ ((rc >> 1) & 3): as conflict-free for the ds_read_b128 fragment reads as g_conv3_sw's two-valued one (the same brute
+// force over all origins), and the result rows' ds_write_b64 (16 contiguous lanes = 16 pixels, the same 8 bytes of each)
+// then land 2 to a bank pair instead of 4 -- within the cycles the store takes anyway (MI355X_MICROARCH.md, LDS table);
+// with the two-valued swizzle 10.8 % of the kernel's LDS cycles were conflict cycles (profiles/r03_b_valar_pmc.txt).
+__device__ __host__ constexpr int ra_swz(int rc) { return (rc >> 1) & 3; }
 constexpr int RA_PB = RA_NF * 2 * 1024;                              // one hand-over buffer: 6 accumulator tiles
 constexpr int RA_PRM_OFF = RA_P_OFF + 3 * 2 * RA_PB;
 constexpr int rdb4_lds_bytes() { return RA_PRM_OFF + 4 * 32 * 4; }
@@ -402,12 +408,12 @@ __global__ __launch_bounds__(256, 1) void rdb4_kernel(RdbArgs a)
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
             const int rc = pp + dx;
-            offdx[dx] = (unsigned)(rc * 64 + ((oo ^ (((rc >> 2) & 1) << 1)) * 16));
+            offdx[dx] = (unsigned)(rc * 64 + ((oo ^ ra_swz(rc)) * 16));
         }
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const int rc = pp + 1, u = 2 * m + (oo >> 1);
-            wroff[m] = (unsigned)(rc * 64 + ((u ^ (((rc >> 2) & 1) << 1)) * 16) + (oo & 1) * 8);
+            wroff[m] = (unsigned)(rc * 64 + ((u ^ ra_swz(rc)) * 16) + (oo & 1) * 8);
         }
     };
     lane_offsets(lane);
@@ -561,7 +567,7 @@ __global__ __launch_bounds__(256, 1) void rdb4_kernel(RdbArgs a)
         for (int k = 0; k < RA_NDMA; ++k) {
             const int idx = min(k * 64 + lane, 2 * RA_RC * 4 - 1);
             const int ch = idx / (RA_RC * 4), rem = idx - ch * (RA_RC * 4), rc = rem >> 2, sl = rem & 3;
-            const int u = sl ^ (((rc >> 2) & 1) << 1);
+            const int u = sl ^ ra_swz(rc);
             voff[k] = (unsigned)(min(sg.c0 + rc, pw + 1) * a.stride * 2 + ch * 64 + u * 16);
         }
     };
