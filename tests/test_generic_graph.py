@@ -227,7 +227,7 @@ from upscale_video_amd import ncnn
 from upscale_video_amd.synth import synthetic_frame
 net = ncnn.Net(); net.set_vulkan_device(0)
 assert net.load_param(sys.argv[2]) == 0 and net.load_model(sys.argv[3]) == 0
-outs = [net.process_u8(synthetic_frame(h, w, seed=h + w), tile_size=t, border=10) for h, w, t in ((12, 20, 0), (37, 45, 0), (50, 70, 32))]
+outs = [net.process_u8(synthetic_frame(h, w, seed=h + w), tile_size=t, border=10) for h, w, t in ((12, 20, 0), (37, 45, 0), (50, 70, 32), (40, 150, 64))]
 np.savez(sys.argv[4], *outs)
 """
 
@@ -246,6 +246,27 @@ def test_sums_done_in_the_convolution_epilogue_change_nothing(tmp_path):
     for v in ("1", "0"):
         f = str(tmp_path / ("o%s.npz" % v))
         subprocess.check_call([sys.executable, "-c", _FUSE_CHILD, ROOT, VALAR, b, f], env=dict(os.environ, UVA_GENERIC_FUSE_ADD=v))
+        res.append(np.load(f))
+    for k in res[0].files:
+        assert np.array_equal(res[0][k], res[1][k]), k
+        assert res[0][k].std() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("switch", ["UVA_GENERIC_BATCH", "UVA_GENERIC_FUSE_INTERP"])
+def test_plane_batches_and_the_folded_interp_change_nothing(tmp_path, switch):
+    """A frame's reference tiles go through the graph together (one rdb4 / g_conv3_sw launch per layer for all planes,
+    UVA_GENERIC_BATCH=0: one plane after the other) and the nearest 2x Interp is folded into the next convolution's row
+    DMA (UVA_GENERIC_FUSE_INTERP=0: a launch of its own): the same bytes either way, ragged tiles included."""
+    import subprocess
+    import sys
+    from oracle import generic_oracle as go
+    b = str(tmp_path / "4x_Valar_v1.bin")
+    go.write_synthetic_bin(VALAR, b, seed=11, gain=0.5)
+    res = []
+    for v in ("1", "0"):
+        f = str(tmp_path / ("o%s.npz" % v))
+        subprocess.check_call([sys.executable, "-c", _FUSE_CHILD, ROOT, VALAR, b, f], env=dict(os.environ, **{switch: v}))
         res.append(np.load(f))
     for k in res[0].files:
         assert np.array_equal(res[0][k], res[1][k]), k

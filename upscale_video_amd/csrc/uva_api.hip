@@ -1527,17 +1527,22 @@ int generic_process_u8_device(uva_net* n, const void* d_in, int h, int w, size_t
     if (tile_size <= 0) { tile_size = 0; border = 0; }
     if (build_planes(h, w, tile_size, border, planes)) return 1;
     static const bool batch_on = [] { const char* e = std::getenv("UVA_GENERIC_BATCH"); return !e || std::atoi(e) != 0; }();
+    // a batch holds every array of its planes at once (at 4x, 16x the plane's pixels x 64 channels): bounded to about
+    // two 1080p frames of input pixels, so that a 2160p frame goes through in four batches and not in one of 90 GB
+    static const long long batch_pixels = [] { const char* e = std::getenv("UVA_GENERIC_BATCH_PIXELS"); return e ? std::atoll(e) : 4200000ll; }();
     std::vector<std::vector<PlaneJob>> batches;
     std::vector<int> batch_class;
+    std::vector<long long> batch_px;
     for (const PlaneDesc& p : planes) {
         const PlaneJob j{d_in, in_stride, p.src_y0, p.src_x0, p.h, p.w, d_out, out_stride, p.core_y0, std::min(p.core_y1, p.h), p.core_x0,
                          std::min(p.core_x1, p.w)};
         const int cls = generic_plane_class(p.w);
         size_t k = 0;
         for (; batch_on && k < batches.size(); ++k)
-            if (batch_class[k] == cls && (int)batches[k].size() < GEN_MAX_PLANES) break;
-        if (!batch_on || k == batches.size()) { batches.emplace_back(); batch_class.push_back(cls); k = batches.size() - 1; }
+            if (batch_class[k] == cls && (int)batches[k].size() < GEN_MAX_PLANES && batch_px[k] + (long long)p.h * p.w <= batch_pixels) break;
+        if (!batch_on || k == batches.size()) { batches.emplace_back(); batch_class.push_back(cls); batch_px.push_back(0); k = batches.size() - 1; }
         batches[k].push_back(j);
+        batch_px[k] += (long long)p.h * p.w;
     }
     for (const auto& b : batches)
         if (generic_run_planes(n, false, b)) return 1;
