@@ -252,6 +252,31 @@ def test_sums_done_in_the_convolution_epilogue_change_nothing(tmp_path):
         assert res[0][k].std() > 0
 
 
+_GRID_CHILD = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import pytest
+sys.exit(pytest.main(["-x", "-q", "-m", "gpu", os.path.join(sys.argv[1], "tests", "test_generic_graph.py"), "-k", "multi_tile_frame_against or graph_with_synthetic_weights", "-p", "no:cacheprovider"]))
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sk", ["0", "1"])
+def test_long_segments_against_the_restatement(sk):
+    """The persistent kernels' loops over the blocks / rows of a segment, and several segments per workgroup: with one
+    workgroup per CU a frame small enough for the numpy restatement gives every workgroup at most one block, so the two
+    parity tests are run again on EIGHT workgroups (UVA_GENERIC_GRID=8: 6-7 four-row blocks and 17 rows per workgroup),
+    with g_conv3_sw<6, 1> and with the k-split 32x32x16 kernel (UVA_GENERIC_SK=1) for the 192 -> 64 convolutions."""
+    import subprocess
+    import sys
+    if os.environ.get("UVA_GENERIC_GRID"):
+        pytest.skip("already the child")
+    r = subprocess.run([sys.executable, "-c", _GRID_CHILD, ROOT], env=dict(os.environ, UVA_GENERIC_GRID="8", UVA_GENERIC_SK=sk),
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "2 passed" in r.stdout, r.stdout[-500:]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("switch", ["UVA_GENERIC_BATCH", "UVA_GENERIC_FUSE_INTERP"])
 def test_plane_batches_and_the_folded_interp_change_nothing(tmp_path, switch):

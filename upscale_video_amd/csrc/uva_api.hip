@@ -137,7 +137,7 @@ struct uva_net {
     float *d_fin = nullptr, *d_fout = nullptr;
     size_t d_fin_cap = 0, d_fout_cap = 0;
     _Float16* d_sink = nullptr;   // where out-of-image lanes of the trunk kernel store to
-    bool attr_set[32] = {false};  // hipFuncAttributeMaxDynamicSharedMemorySize done for kernel slot k on this net's device
+    bool attr_set[40] = {false};  // hipFuncAttributeMaxDynamicSharedMemorySize done for kernel slot k on this net's device
     int last_act_buf = 0;         // which ping-pong buffer the last run_graph() left its last trunk activation in
     bool generic_fuse_add = true; // generic graphs: sums that follow a convolution are done in its epilogue (UVA_GENERIC_FUSE_ADD=0: own launch)
     bool generic_lds_conv = true; // generic graphs: 3x3 convolutions through g_conv3_lds (UVA_GENERIC_LDS=0: the plain g_conv<3>)
@@ -1077,6 +1077,13 @@ struct PlaneJob {
     const void* src; size_t src_stride; int sy0, sx0, h, w;
     void* dst; size_t dst_stride; int cy0, cy1, cx0, cx1;
 };
+// workgroups of the persistent kernels: one per CU (UVA_GENERIC_GRID=K: a test hook -- few workgroups give long segments
+// and several of them per workgroup on frames small enough for the numpy restatement)
+inline int generic_grid(const uva_net* n)
+{
+    static const int forced = [] { const char* e = std::getenv("UVA_GENERIC_GRID"); return e ? std::atoi(e) : 0; }();
+    return forced > 0 ? forced : std::max(8, (n->ncu / 8) * 8);
+}
 inline int generic_plane_class(int w) { return (w >= 16) + (w >= 32) + (w >= 64); }
 
 int generic_run_planes(uva_net* n, bool f32, const std::vector<PlaneJob>& jobs)
@@ -1290,7 +1297,7 @@ int generic_run_planes(uva_net* n, bool f32, const std::vector<PlaneJob>& jobs)
             if (!plan.segs) {
                 std::vector<RdbSeg> segs;
                 std::vector<int> sbeg;
-                plan.grid = std::max(8, (n->ncu / 8) * 8);
+                plan.grid = generic_grid(n);
                 rdb_segments(dims, plan.grid, segs, sbeg);
                 if (upload(&plan.segs, segs.data(), segs.size() * sizeof(RdbSeg), n->stream)) return 1;
                 if (upload(&plan.seg_begin, sbeg.data(), sbeg.size() * sizeof(int), n->stream)) return 1;
@@ -1346,7 +1353,7 @@ int generic_run_planes(uva_net* n, bool f32, const std::vector<PlaneJob>& jobs)
                 if (!plan.segs) {
                     std::vector<GSwSeg> segs;
                     std::vector<int> sbeg;
-                    plan.grid = std::max(8, (n->ncu / 8) * 8);
+                    plan.grid = generic_grid(n);
                     sw_segments(std::vector<int>(dims.begin() + 1, dims.end()), cols, plan.grid, segs, sbeg);
                     if (upload(&plan.segs, segs.data(), segs.size() * sizeof(GSwSeg), n->stream)) return 1;
                     if (upload(&plan.seg_begin, sbeg.data(), sbeg.size() * sizeof(int), n->stream)) return 1;
@@ -1364,7 +1371,14 @@ int generic_run_planes(uva_net* n, bool f32, const std::vector<PlaneJob>& jobs)
                     hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(256), lds, n->stream, sa);
                     return 0;
                 };
-                if (variant == 0) { if (launch_sw(g_conv3_sw<6, 1, false, 2, 0>, 24, sw_lds_bytes<6, 1>())) return 1; }
+                // 192 inputs: UVA_GENERIC_SK=1 takes g_conv3_sk (32x32x16 MFMAs, the k-loop split between wave pairs) instead of
+                // g_conv3_sw<6, 1>.  Measured equal within 1 % (profiles/r03_ab_results.txt, block 10: both sit at the package's
+                // power limit), so the simpler kernel stays the default; the other is kept runnable for the next round's work.
+                static const bool sk_on = [] { const char* e = std::getenv("UVA_GENERIC_SK"); return e && std::atoi(e) != 0; }();
+                if (variant == 0 && sk_on) { if (launch_sw(g_conv3_sk<2, 0>, 32, sk_lds_bytes())) return 1; }
+                else if (variant == 1 && sk_on) { if (launch_sw(g_conv3_sk<2, 2>, 33, sk_lds_bytes())) return 1; }
+                else if (variant == 4 && sk_on) { if (launch_sw(g_conv3_sk<0, 0>, 34, sk_lds_bytes())) return 1; }
+                else if (variant == 0) { if (launch_sw(g_conv3_sw<6, 1, false, 2, 0>, 24, sw_lds_bytes<6, 1>())) return 1; }
                 else if (variant == 1) { if (launch_sw(g_conv3_sw<6, 1, false, 2, 2>, 25, sw_lds_bytes<6, 1>())) return 1; }
                 else if (variant == 2) { if (launch_sw(g_conv3_sw<2, 2, false, 1, 0>, 26, sw_lds_bytes<2, 2>())) return 1; }
                 else if (variant == 3 && up) { if (launch_sw(g_conv3_sw<2, 2, true, 0, 0, true>, 31, sw_lds_bytes<2, 2>())) return 1; }

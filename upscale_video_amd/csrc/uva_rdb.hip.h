@@ -29,6 +29,15 @@
 #ifndef UVA_SW_D
 #define UVA_SW_D 3
 #endif
+#ifndef UVA_RA_D
+#define UVA_RA_D 2       // rdb4_kernel: k-steps (of 3 fragment reads) the reads run ahead of the MFMAs
+#endif
+#ifndef UVA_SK_DBG
+#define UVA_SK_DBG 0      // g_conv3_sk timing experiments only (results are wrong): 1 no epilogue, 2 no exchange, 4 no DMA
+#endif
+#ifndef UVA_SW_HALFREAD
+#define UVA_SW_HALFREAD 0
+#endif
 #ifndef UVA_SW_DBG
 #define UVA_SW_DBG 0
 #endif
@@ -244,12 +253,15 @@ __global__ __launch_bounds__(256, 1) void g_conv3_sw(GSwArgs a)
         auto rd = [&](int idx, half8 (&dst)[NF]) {      // idx = (c * 3 + dx) * NIR + ir
             const int cd = idx / NIR, ir = idx - cd * NIR, c = cd / 3, dx = cd - 3 * c;
 #pragma unroll
-            for (int f = 0; f < NF; ++f) dst[f] = *(const half8*)(ring + rowb[ir] + offdx[dx] + c * (RC * 64) + f * 1024);
+            for (int f = 0; f < NF; ++f) {
+                if (UVA_SW_HALFREAD && f > 0) { dst[f] = dst[0]; continue; }       // timing experiment only (results are wrong)
+                dst[f] = *(const half8*)(ring + rowb[ir] + offdx[dx] + c * (RC * 64) + f * 1024);
+            }
         };
         __builtin_amdgcn_sched_barrier(0);                       // nothing else's LDS reads count as the pipeline's
 #pragma unroll
         for (int i = 0; i < D; ++i) rd(i, bq[i]);
-        __builtin_amdgcn_sched_group_barrier(0x100, D * NF, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, D * (UVA_SW_HALFREAD ? 1 : NF), 0);
         static_for<NSTEP>([&](auto I) {
             constexpr int idx = decltype(I)::value;
             constexpr int cd = idx / NIR, ir = idx - cd * NIR, c = cd / 3, dx = cd - 3 * c;
@@ -265,7 +277,7 @@ __global__ __launch_bounds__(256, 1) void g_conv3_sw(GSwArgs a)
                     for (int m = 0; m < MBW; ++m)
                         acc[r][f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wgt[dy * 3 + dx][c][m], bq[idx % (D + 1)][f], acc[r][f][m], 0, 0, 0);
             }
-            if constexpr (idx + D < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, NF, 0);
+            if constexpr (idx + D < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, UVA_SW_HALFREAD ? 1 : NF, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, ndy * NF * MBW, 0);
             if constexpr (idx >= E0 && (idx - E0) % ES == 0 && (idx - E0) / ES < NT) side(std::integral_constant<int, (idx - E0) / ES>{});
         });
@@ -316,6 +328,305 @@ __global__ __launch_bounds__(256, 1) void g_conv3_sw(GSwArgs a)
             static_for<NT>([&](auto J) { epi_tile(J, accA, c0, y0, y1, nblk - 1); });
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// g_conv3_sk: the 192 -> 64 convolution (a dense block's last one, with its fused sums) on v_mfma_f32_32x32x16_f16,
+// the k-loop SPLIT between wave pairs.
+//
+// What a one-wave-per-SIMD kernel pays for is ISSUE SLOTS.  A wave alone on its SIMD hides next to nothing behind a
+// 16-cycle v_mfma_f32_16x16x32_f16: every other instruction -- fragment read, address add, epilogue VALU -- costs its
+// 4-6 cycles on top (tools/mfma_read_ratio_bench.hip: one ds_read_b128 per MFMA -> 80 cycles per 64 of MFMA work, on
+// the 32-cycle v_mfma_f32_32x32x16_f16 the same bytes per flop -> 66; g_conv3_sw<6, 1>'s block = 432 MFMAs + ~1 100
+// other instructions takes 14.5k cycles for 6.9k of matrix work; profiles/r03_ab_results.txt, blocks 9-11).  So: the
+// 32-cycle shape (half the MFMA instructions, twice the shadow behind each) and fewer instructions beside them.
+//
+// Wave (mh, kh) owns 32 output channels (one 32-row MFMA block) and HALF the input channels (chunks 3kh .. 3kh + 2: 216
+// weight registers): a k-step is (chunk, tap column, input row) = two B fragments of 16 channels x 32 pixels (the whole
+// strip width), each feeding the MFMAs of up to three output rows -- 0.5 reads per 32-cycle MFMA.  The reduction: after a
+// block's k-loop the pair exchanges two of its four 32 x 32 partial tiles through LDS (fp32); wave kh finishes rows 2kh,
+// 2kh + 1 of the block (its own partial + the partner's; kh = 0 started from the bias) and does their epilogue inside
+// the next block's k-loop.
+//
+// LDS: ring rows packed (34 columns x 6 chunks x 64 B = 13 056 B, the 13th DMA piece is 48 lanes wide), unit u of ring
+// column rc in slot u ^ ((rc >> 2) & 3) -- lane l reads unit 2h + (l >> 5) of column (l & 31) + dx, conflict-free for
+// every origin under the ds_read_b128 lane groups (tools/lds_swizzle_search.py); 10 x 13 056 + 4 x 8 KiB of exchange
+// buffers + the bias = 163 584 B of the 163 840.
+// ---------------------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int SK_KC = 6, SK_KH = 3, SK_C = 32, SK_RC = SK_C + 2;
+constexpr int SK_UNITS = SK_KC * SK_RC * 4;                 // 16-byte units of a ring row
+constexpr int SK_ROWB = SK_UNITS * 16;
+constexpr int SK_NP = (SK_UNITS + 63) / 64;                 // DMA pieces per ring row; the last one has SK_UNITS % 64 lanes
+constexpr int SK_HAND = SW_SLOTS * SK_ROWB, SK_BIAS = SK_HAND + 4 * 8 * 1024;
+constexpr int sk_lds_bytes() { return SK_BIAS + 256; }
+static_assert(sk_lds_bytes() <= 160 * 1024 && SK_ROWB % 256 == 0, "g_conv3_sk LDS budget / bank alignment of the rows");
+
+template <int RES, int RES2>
+__global__ __launch_bounds__(256, 1) void g_conv3_sk(GSwArgs a)
+{
+    constexpr int KC = SK_KC, KH = SK_KH, RC = SK_RC, ROWB = SK_ROWB, NP = SK_NP;
+    constexpr int NIR = SW_R + 2, NPW = (NP + 3) / 4;
+    constexpr int NT = 2 * 4;                  // pieces a wave FINISHES per block: 2 rows x 4 quads of channels (8 bytes per lane)
+    constexpr int NLD = NT * ((RES != 0) + (RES2 != 0));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ring = smem;
+    char* const hand = smem + SK_HAND;
+    float* const lbias = (float*)(smem + SK_BIAS);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int mh = wave & 1, khw = wave >> 1;
+    const int g5 = lane >> 5, p = lane & 31;   // MFMA 32x32x16: B column / D column = pixel p; k octet (B) and row quad (D) by g5
+
+    unsigned voff[NPW];
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) {
+        const int idx = min((wave + 4 * k) * 64 + lane, SK_UNITS - 1);
+        const int ch = idx / (RC * 4), rem = idx - ch * (RC * 4), rc = rem >> 2, sl = rem & 3;
+        const int u = sl ^ ((rc >> 2) & 3);
+        voff[k] = (unsigned)(rc * a.in_stride * 2 + ch * 64 + u * 16);
+    }
+    if (threadIdx.x < 64) lbias[threadIdx.x] = a.bias ? a.bias[threadIdx.x] : 0.f;
+    // per-lane LDS read offsets: tap column dx, channel half h of a chunk (unit 2h + g5 of ring column p + dx)
+    unsigned offr[3][2];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int rc = p + dx;
+            offr[dx][h] = (unsigned)(rc * 64 + (((2 * h + g5) ^ ((rc >> 2) & 3)) * 16) + khw * KH * (RC * 64));
+        }
+    const unsigned ring_lds = lds_offset(ring);
+    _Float16* const sink = a.sink + lane * 4;
+    const _Float16* pin = nullptr;
+    _Float16* pout = nullptr;
+    const _Float16* pres = nullptr;
+    const _Float16* pres2 = nullptr;
+    int ph = 0, pw = 0;
+    size_t in_pitch = 0;
+    auto set_plane = [&](int pl) {
+        pin = a.in[pl]; pout = a.out[pl]; pres = a.res[pl]; pres2 = a.res2[pl];
+        ph = a.ph[pl]; pw = a.pw[pl];
+        in_pitch = (size_t)(pw + 2) * a.in_stride;
+    };
+    auto dma_row = [&](int c0, int y0, int rr) {
+        const int ay = min(y0 + rr, ph + 1);
+        const unsigned long long sa = (unsigned long long)(pin + (size_t)ay * in_pitch + (size_t)c0 * a.in_stride);
+        // (made uniform by hand: the last piece sits under a lane mask, and an address the compiler has sunk into that
+        // divergent region does not reach the instruction's scalar operand)
+        const char* const src = (const char*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(sa >> 32)) << 32) |
+                                              (unsigned)__builtin_amdgcn_readfirstlane((unsigned)sa));       // (the builtin returns int)
+        const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)(rr % SW_SLOTS) * ROWB + wave * 1024);
+#pragma unroll
+        for (int k = 0; k < NPW; ++k) {
+            if (4 * k + 3 < NP - 1) glds16_s(src, voff[k], dst + k * 4096);           // (a piece every wave has, all 64 lanes)
+            else if (wave + 4 * k < NP - 1) glds16_s(src, voff[k], dst + k * 4096);
+            else if (wave + 4 * k == NP - 1 && lane < SK_UNITS - (NP - 1) * 64) glds16_s(src, voff[k], dst + k * 4096);
+        }
+    };
+
+    const int sb = a.seg_begin[blockIdx.x], se = a.seg_begin[blockIdx.x + 1];
+    if (sb < se) {
+        const GSwSeg seg = a.segs[sb];
+        set_plane(__builtin_amdgcn_readfirstlane(seg.plane));
+        for (int rr = 0; rr < NIR; ++rr) dma_row(seg.c0, seg.y0, rr);
+    }
+    // everything below once per k-half: a wave's accumulator rows are rotated so that acc[0], acc[1] are the rows it
+    // finishes (2kh, 2kh + 1) -- static register indices on both paths, no selects
+    auto run = [&](auto KHc) {
+    constexpr int kh = decltype(KHc)::value;
+    // A fragments out of pack_generic's 16x16x32 image: row p of the 32-row block is row p & 15 of 16-row block (p >> 4),
+    // k octet 2h + g5 of the chunk
+    half8 wgt[9][KH][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < KH; ++c)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                wgt[t][c][h] = a.wpk[((size_t)(t * KC + kh * KH + c) * 4 + 2 * mh + (p >> 4)) * 64 + ((2 * h + g5) * 16 + (p & 15))];
+
+    constexpr int NSTEP = KH * 3 * NIR;
+    constexpr int E0 = NSTEP / 4, ES = (NSTEP - 2 - E0) / NT > 0 ? (NSTEP - 2 - E0) / NT : 1;
+    static_assert(E0 + (NT - 1) * ES < NSTEP, "epilogue pieces fit the k-loop");
+    half4 rsv[RES ? NT : 1], rsw[RES2 ? NT : 1];
+
+    // finished piece j = (rr, q) of block b: row 4b + 2kh + rr, this lane's pixel, channels 32mh + 8q + 4g5 .. + 3
+    // (accumulator registers 4q .. 4q + 3 of the row's 32 x 32 tile)
+    auto piece_pos = [&](int j, int c0, int y0, int y1, int b, bool* inside) -> size_t {
+        const int rr = j >> 2;
+        const int y = y0 + SW_R * b + 2 * kh + rr, x = c0 + p;
+        *inside = (y < y1) & (x < pw);
+        return ((size_t)(min(y, ph - 1) + 1) * (pw + 2) + 1 + min(x, pw - 1));
+    };
+    const int chq = 32 * mh + 4 * g5;
+    auto load_res = [&](int j, int c0, int y0, int y1, int b) {
+        if constexpr (RES != 0 || RES2 != 0) {
+            bool in;
+            const size_t pos = piece_pos(j, c0, y0, y1, b, &in);
+            const int ch = chq + 8 * (j & 3);
+            // (asm: the compiler cannot count the LDS-DMA pieces and the stores, both asm, that sit between a load and its
+            // use -- its own s_waitcnt vmcnt(7) in front of every use waited for the DMA issued at the top of the block,
+            // 1.5 us per block; the waits are epi_piece's)
+            if constexpr (RES != 0) {
+                const _Float16* const q1 = pres + pos * a.res_stride + ch;
+                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rsv[j]) : "v"(q1));
+            }
+            if constexpr (RES2 != 0) {
+                const _Float16* const q2 = pres2 + pos * a.res2_stride + ch;
+                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rsw[j]) : "v"(q2));
+            }
+        }
+    };
+    // vector-memory operations a wave issues between the load of piece j's operands and their use one block later, if
+    // nothing else intervenes: the rest of that k-loop's pieces (one store + NRL loads each), the next block's DMA pieces
+    // (12; wave 0 has 16 and waits for four of them), the pieces before j of the current k-loop
+    constexpr int NRL = (RES != 0) + (RES2 != 0);
+    constexpr int KW_LOOP = (NT - 1) * (1 + NRL) + 4 * (NPW - 1);
+    auto epi_piece = [&](auto Jc, auto KWc, const f32x16 (&fin)[2], int c0, int y0, int y1, int b) {
+        constexpr int j = decltype(Jc)::value, q = j & 3, rr = j >> 2;
+        if constexpr (RES != 0 && RES2 != 0) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(rsv[j]), "+v"(rsw[j]) : "n"(decltype(KWc)::value));
+        else if constexpr (RES != 0) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rsv[j]) : "n"(decltype(KWc)::value));
+        else if constexpr (RES2 != 0) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rsw[j]) : "n"(decltype(KWc)::value));
+        half4 cv = {(_Float16)fin[rr][4 * q], (_Float16)fin[rr][4 * q + 1], (_Float16)fin[rr][4 * q + 2], (_Float16)fin[rr][4 * q + 3]};
+        if constexpr (RES != 0) {
+            const half4 rv = rsv[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                cv[e] = RES == 1 ? g_axpby1((float)rv[e], a.ca, (float)cv[e], a.cb) : g_axpby1((float)cv[e], a.ca, (float)rv[e], a.cb);
+        }
+        if constexpr (RES2 != 0) {
+            const half4 rv = rsw[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                cv[e] = RES2 == 1 ? g_axpby1((float)rv[e], a.ca2, (float)cv[e], a.cb2) : g_axpby1((float)cv[e], a.ca2, (float)rv[e], a.cb2);
+        }
+        bool in;
+        const size_t pos = piece_pos(j, c0, y0, y1, b, &in);
+        _Float16* const dst = in ? pout + pos * a.out_stride + a.out_coff + chq + 8 * q : sink;
+        asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(cv) : "memory");
+    };
+    auto kloop = [&](f32x16 (&acc)[SW_R], const int b, auto&& side) {
+        unsigned rowb[NIR];
+#pragma unroll
+        for (int ir = 0; ir < NIR; ++ir) rowb[ir] = (unsigned)((SW_R * b + ir) % SW_SLOTS) * ROWB;
+        {
+            const float bsel = kh ? 0.f : 1.f;      // the bias belongs to one half of the sum
+            f32x16 bs;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b4 = *(const f32x4*)(lbias + chq + 8 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bs[4 * q + e] = b4[e] * bsel;
+            }
+#pragma unroll
+            for (int r = 0; r < SW_R; ++r) acc[r] = bs;
+        }
+        constexpr int D = UVA_SW_D;
+        half8 bq[D + 1][2];
+        auto rd = [&](int idx, half8 (&dst)[2]) {      // idx = (c * 3 + dx) * NIR + ir
+            const int cd = idx / NIR, ir = idx - cd * NIR, c = cd / 3, dx = cd - 3 * c;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) dst[h] = *(const half8*)(ring + rowb[ir] + offr[dx][h] + c * (RC * 64));
+        };
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < D; ++i) rd(i, bq[i]);
+        __builtin_amdgcn_sched_group_barrier(0x100, D * 2, 0);
+        static_for<NSTEP>([&](auto I) {
+            constexpr int idx = decltype(I)::value;
+            constexpr int cd = idx / NIR, ir = idx - cd * NIR, c = cd / 3, dx = cd - 3 * c;
+            if constexpr (idx + D < NSTEP) rd(idx + D, bq[(idx + D) % (D + 1)]);
+            constexpr int ndy = (ir < 3 ? ir + 1 : 3) - (ir >= SW_R ? ir - SW_R + 1 : 0);
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int r = ir - dy;
+                if (r < 0 || r >= SW_R) continue;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    acc[(r + 2 * kh) % SW_R] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wgt[dy * 3 + dx][c][h], bq[idx % (D + 1)][h], acc[(r + 2 * kh) % SW_R], 0, 0, 0);
+            }
+            if constexpr (idx + D < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, ndy * 2, 0);
+            if constexpr (idx >= E0 && (idx - E0) % ES == 0 && (idx - E0) / ES < NT) side(std::integral_constant<int, (idx - E0) / ES>{});
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // the pair's reduction: this wave's partials of the partner's rows -> LDS; after the barrier the partner's partials of
+    // this wave's rows come back and are added.  A second barrier keeps the next block's hand-over off buffers that are
+    // still being read.
+    char* const my_hand = hand + wave * 8192 + lane * 16;
+    const char* const partner_hand = hand + (wave ^ 2) * 8192 + lane * 16;
+    auto hand_over = [&](const f32x16 (&acc)[SW_R]) {           // acc[2], acc[3]: the partner's rows
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *(f32x4*)(my_hand + (rr * 4 + q) * 1024) = f32x4{acc[2 + rr][4 * q], acc[2 + rr][4 * q + 1], acc[2 + rr][4 * q + 2], acc[2 + rr][4 * q + 3]};
+    };
+    auto take_over = [&](const f32x16 (&acc)[SW_R], f32x16 (&fin)[2]) {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {        // (bias + first half) + second half: fp32 addition commutes
+                const f32x4 got = *(const f32x4*)(partner_hand + (rr * 4 + q) * 1024);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) fin[rr][4 * q + e] = acc[rr][4 * q + e] + got[e];
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+
+    for (int si = sb; si < se; ++si) {
+        const GSwSeg seg = a.segs[si];
+        const int c0 = __builtin_amdgcn_readfirstlane(seg.c0), y0 = __builtin_amdgcn_readfirstlane(seg.y0),
+                  y1 = __builtin_amdgcn_readfirstlane(seg.y1);
+        if (si > sb) {
+            sw_barrier();
+            set_plane(__builtin_amdgcn_readfirstlane(seg.plane));
+            for (int rr = 0; rr < NIR; ++rr) dma_row(c0, y0, rr);
+        }
+        sw_barrier();
+        const int nblk = (y1 - y0 + SW_R - 1) / SW_R;
+        f32x16 acc[SW_R], fin[2];
+        // block 0: nothing to finish yet; its sums' operands are fetched up front
+        for (int rr = 0; rr < SW_R; ++rr) dma_row(c0, y0, SW_R + 2 + rr);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {         // (with a store to the sink in front of each: a regular block's sequence)
+            if constexpr (NRL != 0) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(sink), "v"(half4{0, 0, 0, 0}) : "memory");
+            load_res(j, c0, y0, y1, 0);
+        }
+        kloop(acc, 0, [](auto) {});
+        hand_over(acc);
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NLD ? NT + NLD : 0) : "memory");
+        take_over(acc, fin);
+        for (int b = 1; b < nblk; ++b) {
+            // the DMA of block b+1's rows, the k-loop of block b, the epilogue of block b-1 (its pieces' other operands
+            // replaced by block b's as they are used): exactly NT stores and NLD loads follow the DMA pieces, so "all but
+            // the newest NT + NLD memory operations have completed" proves the DMA and leaves them in flight
+            if (!(UVA_SK_DBG & 4))
+                for (int rr = 0; rr < SW_R; ++rr) dma_row(c0, y0, SW_R * (b + 1) + 2 + rr);
+            kloop(acc, b, [&](auto J) {
+                if (UVA_SK_DBG & 1) return;
+                epi_piece(J, std::integral_constant<int, KW_LOOP>{}, fin, c0, y0, y1, b - 1);
+                load_res(decltype(J)::value, c0, y0, y1, b);
+            });
+            if (!(UVA_SK_DBG & 2)) hand_over(acc);
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(UVA_SK_DBG ? 0 : NT + NLD) : "memory");
+            if (!(UVA_SK_DBG & 2)) take_over(acc, fin);
+            else {
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) fin[rr] = acc[rr] + acc[2 + rr];
+            }
+        }
+        // the last block's pieces: behind the load of piece j's operands came the later pieces of that k-loop and now the
+        // stores of the pieces before j
+        static_for<NT>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            epi_piece(J, std::integral_constant<int, (NT - 1 - j) * (1 + NRL) + j>{}, fin, c0, y0, y1, nblk - 1);
+        });
+    }
+    };
+    if (khw) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 0>{});
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -434,7 +745,7 @@ __global__ __launch_bounds__(256, 1) void rdb4_kernel(RdbArgs a)
     };
     // k-steps [K0, K1) of a convolution whose k-step k = chunk * 9 + tap reads chunk 0, 1 = x, 2.. = x1.. ; row q
     auto kpart = [&](auto K0c, auto K1c, const auto& wg, f32x4 (&acc)[RA_NF][2], const int q, auto&& side) {
-        constexpr int K0 = decltype(K0c)::value, K1 = decltype(K1c)::value, N = K1 - K0, D = 2;
+        constexpr int K0 = decltype(K0c)::value, K1 = decltype(K1c)::value, N = K1 - K0, D = UVA_RA_D;
         constexpr int G0 = (K0 / 9 < 2) ? 0 : K0 / 9 - 1, G1 = ((K1 - 1) / 9 < 2) ? 0 : (K1 - 1) / 9 - 1;
         unsigned ra[4][3];
 #pragma unroll
