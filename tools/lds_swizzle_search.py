@@ -65,3 +65,18 @@ for H in itertools.product(range(4), repeat=4):
 res.sort()
 print("read-conflict-free tables by worst ds_write_b64 multiplicity:", res[:4], "...", res[-1])
 # -> (2, (0, 1, 2, 3), 1) = u ^ ((col >> 1) & 3) is 2-way (rdb4_kernel's ra_swz); g_conv3_sw's (0, 2, 0, 2) at shift 2 is 4-way
+
+# ---- g_conv3_sk: B fragments of v_mfma_f32_32x32x16_f16 -- lane l reads unit 2h + (l >> 5) of ring column (l & 31) + dx
+def ok32(f):
+    for c0 in range(64):
+        for h in range(2):
+            for g in groups:
+                banks = set()
+                for l in g:
+                    rc = c0 + (l & 31)
+                    banks.add((rc * 4 + ((2 * h + (l >> 5)) ^ f(rc))) % 16)
+                if len(banks) != 16:
+                    return False
+    return True
+print("32-pixel fragments: u ^ ((rc >> 2) & 3):", ok32(lambda rc: (rc >> 2) & 3), " g_conv3_sw's u ^ (((rc >> 2) & 1) << 1):",
+      ok32(lambda rc: ((rc >> 2) & 1) << 1))

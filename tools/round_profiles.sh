@@ -23,6 +23,10 @@ python tools/rawvideo_bench.py 600 > "$OUT/${TAG}_rawvideo_bench.txt" 2>&1
 python tools/denoise_bench.py > "$OUT/${TAG}_denoise_bench_now.txt" 2>&1
 python tools/valar_bench.py 3 > "$OUT/${TAG}_bench_valar.txt" 2>&1
 UVA_GENERIC_RDB=0 UVA_GENERIC_SW=0 python tools/valar_bench.py 3 2>&1 | sed 's/^/layer by layer (UVA_GENERIC_RDB=0 UVA_GENERIC_SW=0): /' >> "$OUT/${TAG}_bench_valar.txt"
+for kv in UVA_GENERIC_BATCH=0 UVA_GENERIC_FUSE_INTERP=0 UVA_GENERIC_SK=1; do
+  env $kv python tools/valar_bench.py 3 2>&1 | grep -v amdgpu.ids | sed "s/^/$kv: /" >> "$OUT/${TAG}_bench_valar.txt"
+done
+hipcc --offload-arch=gfx950 -O3 tools/mfma_read_ratio_bench.hip -o /tmp/mrr_$TAG 2> /dev/null && /tmp/mrr_$TAG > "$OUT/${TAG}_mfma_read_ratio_bench.txt" 2>&1
 bash tools/pmc_valar.sh > "$OUT/${TAG}_valar_pmc.txt" 2>&1
 (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d /tmp/profval_$TAG -o p --output-format csv -- python $REPO/tools/valar_bench.py 3 > /dev/null 2>&1; cp $(find /tmp/profval_$TAG -name "*kernel_stats.csv" | head -1) "$OUT/${TAG}_kernel_stats_valar_rocprofv3.csv")
 UVA_RDB_STAMPS=1 UVA_LIB_PATH=$REPO/upscale_video_amd/libuva_instr.so python tools/rdb4_anatomy.py > "$OUT/${TAG}_rdb4_anatomy.txt" 2>&1

@@ -332,14 +332,15 @@ __global__ __launch_bounds__(256, 1) void g_conv3_sw(GSwArgs a)
 
 // ---------------------------------------------------------------------------------------------------------------
 // g_conv3_sk: the 192 -> 64 convolution (a dense block's last one, with its fused sums) on v_mfma_f32_32x32x16_f16,
-// the k-loop SPLIT between wave pairs.
+// the k-loop SPLIT between wave pairs.  UVA_GENERIC_SK=1 selects it instead of g_conv3_sw<6, 1>.
 //
-// What a one-wave-per-SIMD kernel pays for is ISSUE SLOTS.  A wave alone on its SIMD hides next to nothing behind a
-// 16-cycle v_mfma_f32_16x16x32_f16: every other instruction -- fragment read, address add, epilogue VALU -- costs its
-// 4-6 cycles on top (tools/mfma_read_ratio_bench.hip: one ds_read_b128 per MFMA -> 80 cycles per 64 of MFMA work, on
-// the 32-cycle v_mfma_f32_32x32x16_f16 the same bytes per flop -> 66; g_conv3_sw<6, 1>'s block = 432 MFMAs + ~1 100
-// other instructions takes 14.5k cycles for 6.9k of matrix work; profiles/r03_ab_results.txt, blocks 9-11).  So: the
-// 32-cycle shape (half the MFMA instructions, twice the shadow behind each) and fewer instructions beside them.
+// Built to find out what bounds g_conv3_sw<6, 1> (matrix pipes half busy): half the MFMA instructions for the same
+// flops, half the fragment reads per flop of the 16x16x32 version of this kernel, the sums' operands waited for with
+// exact counts.  Result, same box: 438 - 448 us against g_conv3_sw<6, 1>'s 440 - 449 -- three structures, one time;
+// the launch sits at the package's power limit (1 335 - 1 360 W, 2.07 - 2.10 GHz) and what is removed in cycles comes
+// back as clock only where it also removes energy (profiles/r03_ab_results.txt, blocks 9 - 11).  The default stays the
+// simpler kernel; this one is kept correct (tests/test_generic_graph.py runs it) as the starting point for work that
+// removes energy: fewer wasted columns, the block's last convolution fed from LDS instead of HBM.
 //
 // Wave (mh, kh) owns 32 output channels (one 32-row MFMA block) and HALF the input channels (chunks 3kh .. 3kh + 2: 216
 // weight registers): a k-step is (chunk, tap column, input row) = two B fragments of 16 channels x 32 pixels (the whole
