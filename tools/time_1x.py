@@ -13,7 +13,7 @@ out = torch.empty_like(img)
 for _ in range(20): net.process_u8_device(img.data_ptr(), 1080, 1920, out.data_ptr())
 net.synchronize()
 torch.cuda.synchronize(); t0 = time.time()
-N = 300
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 for _ in range(N): net.process_u8_device(img.data_ptr(), 1080, 1920, out.data_ptr())
 net.synchronize(); dt = time.time() - t0
 print("%.4f ms/frame  %.0f fps" % (dt / N * 1e3, N / dt))
