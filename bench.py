@@ -51,7 +51,11 @@ WORKLOADS = {
     "2x_compact_2160p": ("2x", "2x_Compact_Pretrain", 2160, 3840),
     # BASELINE.json configs[2]: 1x HurrDeblur -> u8 -> 2x Compact, both on the device
     "chain_1x_2x_1080p": ("2x", "2x_Compact_Pretrain", 1080, 1920),
+    # BASELINE.json configs[3] as named: 4x_Valar_v1 (`-m r`) through the generic graph executor.  Its .bin is a missing
+    # blob upstream (/root/reference/.MISSING_LARGE_BLOBS:1): random-init weights of that architecture unless the file is there
+    "4x_valar_1080p": ("valar", "4x_Valar_v1", 1080, 1920),
 }
+VALAR_FLOP_PER_INPUT_PIXEL = 36_136_320      # SURVEY.md 8d (un-tiled frame)
 
 
 def conv_flops_per_px(nf, nconv, scale):
@@ -189,7 +193,7 @@ def main():
     from upscale_video_amd import build
     build.build_lib()
     from upscale_video_amd import ncnn
-    from upscale_video_amd.synth import synthetic_frame
+    from upscale_video_amd.synth import synthetic_frame, synthetic_weights
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -222,7 +226,15 @@ def main():
     net = ncnn.Net()
     net.set_vulkan_device(local_rank)
     base = os.path.join(ROOT, "models", stem)
-    assert net.load_param(base + ".param") == 0 and net.load_model(base + ".bin") == 0, getattr(net, "last_error", "")
+    generic = key == "valar"
+    weights, weights_note = base + ".bin", "the repository's .bin"
+    if generic and not os.path.exists(weights):
+        import tempfile
+        tmpdir = tempfile.TemporaryDirectory()
+        weights = os.path.join(tmpdir.name, stem + ".bin")
+        synthetic_weights(base + ".param", weights, seed=1, gain=0.5)
+        weights_note = "random-init (the .bin is a missing blob upstream): throughput only"
+    assert net.load_param(base + ".param") == 0 and net.load_model(weights) == 0, getattr(net, "last_error", "")
     s = net.scale
 
     # synthetic frames, resident in HBM before the timed region
@@ -259,19 +271,21 @@ def main():
     for i in range(args.warmup):
         step(i)
     sync()
-    net.set_profiling(True)
+    if not generic:
+        net.set_profiling(True)
     elapsed = timed_region(lambda: [step(i) for i in range(args.steps)], sync, barrier, max_over_ranks)
-    n_launch, trunk_ms = net.kernel_stats(1)
-    _, head_ms = net.kernel_stats(0)
-    _, tail_ms = net.kernel_stats(2)
-    net.set_profiling(False)
+    if not generic:
+        n_launch, trunk_ms = net.kernel_stats(1)
+        _, head_ms = net.kernel_stats(0)
+        _, tail_ms = net.kernel_stats(2)
+        net.set_profiling(False)
 
     total_frames = args.steps * world
     fps = whole_job_rate(args.steps, world, elapsed)
 
     # (E) pipelined host route, PCIe inclusive, on every rank at once: frames in page-locked host memory,
     # submit/collect with 3 frames in flight (SURVEY.md 8d "host-to-host with stream overlap")
-    depth, n_host = 3, max(30, min(args.steps, 120))
+    depth, n_host = 3, (max(6, min(args.steps, 12)) if generic else max(30, min(args.steps, 120)))
     host_in = frames[0].cpu().numpy()
     pin_in = [ncnn.pinned_empty((h, w, 3)) for _ in range(depth)]
     pin_out = [ncnn.pinned_empty((h * s, w * s, 3)) for _ in range(depth)]
@@ -293,7 +307,37 @@ def main():
         host_elapsed = timed_region(lambda: host_pipeline(n_host), sync, barrier, max_over_ranks)
         host_fps = whole_job_rate(n_host, world, host_elapsed)
 
-    if rank == 0:
+    if rank == 0 and generic:
+        # the generic executor has no per-kernel event hooks: the roofline object is the WHOLE graph's (69 dense blocks =
+        # 68 x (rdb4_kernel + g_conv3_sw<6,1>) + the first block layer by layer + 7 other convolutions), per-kernel times
+        # are in profiles/*_kernel_stats_valar_rocprofv3.csv
+        frame_flops = VALAR_FLOP_PER_INPUT_PIXEL * h * w
+        achieved = frame_flops * fps / world / 1e12
+        result = {
+            "metric": "frames/sec " + args.workload, "value": round(fps, 3), "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16 operands / f32 accumulate",
+            "data": "synthetic frames; weights: " + weights_note,
+            "config": {
+                "workload": f"{w}x{h} synthetic u8 BGR frames, {stem} (1 206 layers) through the generic graph executor, "
+                            f"upscale_image arithmetic ({'reference 960-px tiles, 10-px border' if args.tile > 0 else 'whole frame'}), "
+                            f"frames and results resident in HBM",
+                "route": "K (device-resident frames and results; host_route_* fields are PCIe inclusive and never `value`)",
+                "frames_per_rank": args.steps, "tile_size": args.tile, "parallelism": f"frame-sharded x{world}, no collective",
+                "frame_tflop": round(frame_flops / 1e12, 4), "whole_path_tflops": round(achieved, 1),
+                "numa_cpus_rank0": (len(numa_cpus) if numa_cpus else None),
+            },
+            "roofline": {"kernel": "whole graph (dominant: rdb4_kernel 53 %, g_conv3_sw<6,1> 36 % of a frame's kernel time)",
+                         "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                         "flops_per_frame": frame_flops},
+            "cpu_baseline": None,
+        }
+        if host_fps is not None:
+            result["config"]["host_route_fps_pcie_inclusive"] = round(host_fps, 2)
+            result["config"]["host_route_frames_per_rank"] = n_host
+        print(json.dumps(result), flush=True)
+    elif rank == 0:
         nf, nconv = net.num_features, net.num_convs
         layers_per_launch = (nconv - 2) * args.steps / max(1, n_launch)       # 2 with trunk2_kernel (fused pairs)
         fused = layers_per_launch > 1.5

@@ -201,6 +201,25 @@ def test_bench_under_torch_distributed_run_one_rank(tmp_path):
     assert abs(d["value"] - d2["value"]) <= 0.10 * d2["value"], (d["value"], d2["value"])
 
 
+@pytest.mark.gpu
+def test_bench_valar_workload(tmp_path):
+    """BASELINE config 4 as named under bench.py's contract: `--workload 4x_valar_1080p` (random-init weights: the .bin is
+    a missing blob upstream) prints one JSON line with the whole-graph roofline object and both routes."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "4x_valar_1080p", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["metric"] == "frames/sec 4x_valar_1080p" and d["n_gpus"] == 1 and d["steps"] == 3
+    assert 5.0 < d["value"] < 30.0 and d["config"]["frame_tflop"] == pytest.approx(74.93, abs=0.01)
+    assert d["roofline"]["bound"] == "mfma" and 0.1 < d["roofline"]["frac"] < 1.0
+    assert d["config"]["host_route_fps_pcie_inclusive"] > 0 and "random-init" in d["data"]
+
+
 def _window_check(got, img, om_apply, rad, s, wins, win=24, max_lsb=2, min_psnr=50):
     """locality: an output window equals the oracle run on the window plus `rad` pixels of context"""
     h, w = img.shape[:2]

@@ -11,6 +11,7 @@ cd "$REPO"
 for wl in 4x_compact_1080p 1x_hurrdeblur_1080p chain_1x_2x_1080p 2x_compact_2160p; do
   python bench.py --workload $wl --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_${wl}.json" 2>> "$OUT/bench.err"
 done
+python bench.py --workload 4x_valar_1080p --steps 30 --warmup 3 > "$OUT/${TAG}_bench_4x_valar_1080p.json" 2>> "$OUT/bench.err"
 python bench.py --tile 0 --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_2x_whole_frame.json" 2>> "$OUT/bench.err"
 UVA_TRUNK_FUSION=0 python bench.py --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_unfused_trunk_kernel.json" 2>> "$OUT/bench.err"
 UVA_SUB10=0 python bench.py --workload 1x_hurrdeblur_1080p --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_1x_per_pair_kernels.json" 2>> "$OUT/bench.err"
