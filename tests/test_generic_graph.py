@@ -363,6 +363,17 @@ def test_conv3_sw_work_list_covers_every_pixel_once(kind, cols, h, w):
     assert blocks.max() - blocks.min() <= 1
 
 
+def test_product_side_weight_writer_matches_the_restatements(tmp_path):
+    """bench.py / tools write random-init weights for 4x_Valar_v1 (a missing blob upstream) with
+    upscale_video_amd.synth.synthetic_weights; the tests use the numpy restatement's writer.  Same bytes."""
+    from oracle import generic_oracle as go
+    from upscale_video_amd.synth import synthetic_weights
+    a, b = str(tmp_path / "a.bin"), str(tmp_path / "b.bin")
+    synthetic_weights(VALAR, a, seed=3, gain=0.5)
+    go.write_synthetic_bin(VALAR, b, seed=3, gain=0.5)
+    assert open(a, "rb").read() == open(b, "rb").read()
+
+
 def _segments_planes(kind, dims, grid=256):
     L = _lib.load()
     flat = (ctypes.c_int * (2 * len(dims)))(*[v for d in dims for v in d])

@@ -6,12 +6,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("UVA_RDB_STAMPS", "1")
-from oracle import generic_oracle as go  # noqa: E402  (synthetic weight file only)
+from upscale_video_amd.synth import synthetic_weights  # noqa: E402
 from upscale_video_amd import _lib, ncnn  # noqa: E402
 param = os.path.join(ROOT, "models", "4x_Valar_v1.param")
 with tempfile.TemporaryDirectory() as d:
     b = os.path.join(d, "v.bin")
-    go.write_synthetic_bin(param, b, seed=1, gain=0.5)
+    synthetic_weights(param, b, seed=1, gain=0.5)
     net = ncnn.Net()
     net.set_vulkan_device(0)
     assert net.load_param(param) == 0 and net.load_model(b) == 0

@@ -28,12 +28,12 @@ np.savez(sys.argv[4], *outs)
 """
 
 if __name__ == "__main__":
-    from oracle import generic_oracle as go
+    from upscale_video_amd.synth import synthetic_weights  # noqa: E402
     param = os.path.join(ROOT, "models", "4x_Valar_v1.param")
     settings = sys.argv[1:] or ["UVA_GENERIC_SW=0", "UVA_GENERIC_SW=1"]
     with tempfile.TemporaryDirectory() as d:
         b = os.path.join(d, "v.bin")
-        go.write_synthetic_bin(param, b, seed=7, gain=0.5)
+        synthetic_weights(param, b, seed=7, gain=0.5)
         res = []
         for i, s in enumerate(settings):
             env = dict(os.environ)

@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from oracle import generic_oracle as go  # noqa: E402  (only to write the synthetic weight file)
+from upscale_video_amd.synth import synthetic_weights  # noqa: E402
 from upscale_video_amd import ncnn  # noqa: E402
 from upscale_video_amd.synth import synthetic_frame  # noqa: E402
 
@@ -21,7 +21,7 @@ w = int(sys.argv[3]) if len(sys.argv) > 3 else 1920
 param = os.path.join(ROOT, "models", "4x_Valar_v1.param")
 with tempfile.TemporaryDirectory() as d:
     b = os.path.join(d, "4x_Valar_v1.bin")
-    go.write_synthetic_bin(param, b, seed=1, gain=0.5)
+    synthetic_weights(param, b, seed=1, gain=0.5)
     net = ncnn.Net()
     net.set_vulkan_device(0)
     assert net.load_param(param) == 0 and net.load_model(b) == 0, getattr(net, "last_error", "")
