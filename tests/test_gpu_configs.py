@@ -283,6 +283,7 @@ def test_config4_valar_at_1080p(uva, tmp_path):
     img = synthetic_frame(h, w, seed=4)
     out = net.process_u8(img, tile_size=960, border=10)
     assert out.shape == (4 * h, 4 * w, 3) and out.std() > 1
+    assert np.array_equal(out, net.process_u8(img, tile_size=960, border=10)), "the same frame twice: different bytes"
     (y0, y1, x0, x1), (top, bottom, left, right) = up.tile_window(960, 1, 1, h, w)          # the 130 x 970 plane
     tile = net.process_u8(np.ascontiguousarray(img[y0 - top:y1 + bottom, x0 - left:x1 + right]), tile_size=0)
     assert np.array_equal(out[4 * y0:4 * y1, 4 * x0:4 * x1], tile[4 * top:4 * (top + y1 - y0), 4 * left:4 * (left + x1 - x0)])
