@@ -855,7 +855,7 @@ __global__ __launch_bounds__(256, 1) void rdb4_kernel(RdbArgs a)
         RowOut r;
         r.rbase = conv == 1 ? rowaddr(1, q) : conv == 2 ? rowaddr(2, q) : rowaddr(3, q);
         r.goff = (size_t)(row + 1) * pitch + 32 * (conv - 1);
-        r.keep = ((row >= 0) & (row < ph) ? 0x0fu : 0u) | ((row >= sg.yb) & (row < sg.ye) ? 0xf0u : 0u);
+        r.keep = (((row >= 0) & (row < ph)) ? 0x0fu : 0u) | (((row >= sg.yb) & (row < sg.ye)) ? 0xf0u : 0u);
         return r;
     };
     // one tile (fragment f, channel block m) of a result row: zero outside the plane -> the ring (conv < 4) and, for the
