@@ -110,7 +110,6 @@ __global__ __launch_bounds__(256, 1) void g_conv3_sw(GSwArgs a)
     constexpr int NF = 2;                      // 16-pixel fragments per wave and row
     constexpr int NIR = SW_R + 2;              // input rows of a block
     constexpr int NPW = (NP + 3) / 4;          // DMA pieces per wave and ring row
-    constexpr int NST = SW_R * NF * MBW;       // stores per wave and block: always all of them (lanes outside -> the sink)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const ring = smem;
     float* const lbias = (float*)(smem + SW_SLOTS * ROWB);
@@ -194,7 +193,7 @@ __global__ __launch_bounds__(256, 1) void g_conv3_sw(GSwArgs a)
 
     // tile j = (r, f, m) of block b of the segment (c0, y0, y1): is this lane's pixel a real one, where it sits in the arrays
     auto tile_pos = [&](int j, int c0, int y0, int y1, int b, bool* inside) -> size_t {
-        const int m = j % MBW, f = (j / MBW) % NF, r = j / (MBW * NF);
+        const int f = (j / MBW) % NF, r = j / (MBW * NF);
         const int y = y0 + SW_R * b + r, x = c0 + cw + 16 * f + p;
         *inside = y < y1 && x < pw;
         return ((size_t)(min(y, ph - 1) + 1) * (pw + 2) + 1 + min(x, pw - 1));      // (clamped: lanes outside read a real pixel)
