@@ -5,16 +5,24 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from upscale_video_amd import ncnn
-from upscale_video_amd.synth import synthetic_frame
+from upscale_video_amd.synth import synthetic_frame, synthetic_weights
 
 ITERS = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+VALAR_ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else max(1, ITERS // 20)     # 85 ms per frame: the persistent dense-block kernels
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 bad = 0
+import tempfile
+tmp = tempfile.TemporaryDirectory()
 for stem, tile in (("2x_Compact_Pretrain", 960), ("4x_Compact_Pretrain", 960), ("1x_HurrDeblur_SubCompact_nf24-nc8_244k_net_g", 0),
-                   ("2x_Compact_Pretrain", 0)):
+                   ("2x_Compact_Pretrain", 0), ("4x_Valar_v1", 960)):
     net = ncnn.Net(); net.set_vulkan_device(0)
     base = os.path.join(ROOT, "models", stem)
-    assert net.load_param(base + ".param") == 0 and net.load_model(base + ".bin") == 0
+    weights = base + ".bin"
+    if stem == "4x_Valar_v1" and not os.path.exists(weights):       # a missing blob upstream: random-init weights
+        weights = os.path.join(tmp.name, "v.bin")
+        synthetic_weights(base + ".param", weights, seed=1, gain=0.5)
+        ITERS = VALAR_ITERS
+    assert net.load_param(base + ".param") == 0 and net.load_model(weights) == 0
     s = net.scale
     h, w = 1080, 1920
     frames = [torch.from_numpy(synthetic_frame(h, w, seed=7 + i, kind="random" if i & 1 else "smooth")).cuda() for i in range(3)]
