@@ -271,14 +271,12 @@ def main():
     for i in range(args.warmup):
         step(i)
     sync()
-    if not generic:
-        net.set_profiling(True)
+    net.set_profiling(True)
     elapsed = timed_region(lambda: [step(i) for i in range(args.steps)], sync, barrier, max_over_ranks)
-    if not generic:
-        n_launch, trunk_ms = net.kernel_stats(1)
-        _, head_ms = net.kernel_stats(0)
-        _, tail_ms = net.kernel_stats(2)
-        net.set_profiling(False)
+    n_launch, trunk_ms = net.kernel_stats(1)       # generic graphs: rdb4_kernel
+    _, head_ms = net.kernel_stats(0)
+    n_tail, tail_ms = net.kernel_stats(2)          # generic graphs: the dense blocks' 192 -> 64 convolution
+    net.set_profiling(False)
 
     total_frames = args.steps * world
     fps = whole_job_rate(args.steps, world, elapsed)
@@ -308,11 +306,12 @@ def main():
         host_fps = whole_job_rate(n_host, world, host_elapsed)
 
     if rank == 0 and generic:
-        # the generic executor has no per-kernel event hooks: the roofline object is the WHOLE graph's (69 dense blocks =
-        # 68 x (rdb4_kernel + g_conv3_sw<6,1>) + the first block layer by layer + 7 other convolutions), per-kernel times
-        # are in profiles/*_kernel_stats_valar_rocprofv3.csv
+        # dominant kernel: rdb4_kernel, the first four convolutions (+ the 1x1) of a residual dense block for all planes of
+        # the frame in one launch, timed by HIP events around every launch; 262 144 FLOP per input pixel
         frame_flops = VALAR_FLOP_PER_INPUT_PIXEL * h * w
-        achieved = frame_flops * fps / world / 1e12
+        rdb_flops = 2 * (9 * 32 * (64 + 96 + 128 + 160) + 64 * 32) * h * w
+        avg_ms = trunk_ms / max(1, n_launch)
+        achieved = rdb_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         result = {
             "metric": "frames/sec " + args.workload, "value": round(fps, 3), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -324,13 +323,14 @@ def main():
                             f"frames and results resident in HBM",
                 "route": "K (device-resident frames and results; host_route_* fields are PCIe inclusive and never `value`)",
                 "frames_per_rank": args.steps, "tile_size": args.tile, "parallelism": f"frame-sharded x{world}, no collective",
-                "frame_tflop": round(frame_flops / 1e12, 4), "whole_path_tflops": round(achieved, 1),
+                "frame_tflop": round(frame_flops / 1e12, 4), "whole_path_tflops": round(frame_flops * fps / world / 1e12, 1),
+                "kernel_ms_per_frame": {"rdb4_kernel": round(trunk_ms / args.steps, 3), "conv5 (g_conv3_sw<6,1>)": round(tail_ms / args.steps, 3)},
                 "numa_cpus_rank0": (len(numa_cpus) if numa_cpus else None),
             },
-            "roofline": {"kernel": "whole graph (dominant: rdb4_kernel 53 %, g_conv3_sw<6,1> 36 % of a frame's kernel time)",
+            "roofline": {"kernel": "rdb4_kernel (conv1..conv4 + the 1x1 of a residual dense block, every plane of the frame, one launch)",
                          "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
-                         "flops_per_frame": frame_flops},
+                         "flops_per_launch": rdb_flops, "avg_launch_ms": round(avg_ms, 4), "launches": n_launch},
             "cpu_baseline": None,
         }
         if host_fps is not None:

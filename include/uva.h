@@ -178,7 +178,8 @@ int uva_debug_denoise_stage(int device, int stage, const uint8_t* in, int h, int
 int uva_net_debug_read_activation(uva_net* net, int conv_idx, float* out_chw, int h, int w);
 
 /* Per-kernel-kind timing with HIP events recorded on the net's stream around each launch.
- * kind: 0 head conv, 1 trunk conv (the dominant kernel), 2 tail conv.
+ * kind: 0 head conv, 1 trunk conv (the dominant kernel), 2 tail conv.  Generic graphs (4x_Valar_v1): 1 = rdb4_kernel
+ * (a residual dense block's first four convolutions, all planes of the frame), 2 = the block's 192 -> 64 convolution; 0 unused.
  * enable != 0 starts (and resets) collection; stats are valid after uva_net_synchronize. */
 int uva_net_set_profiling(uva_net* net, int enable);
 int uva_net_kernel_stats(uva_net* net, int kind, long long* launches, double* total_ms);

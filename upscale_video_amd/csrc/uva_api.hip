@@ -172,6 +172,8 @@ struct uva_net {
     std::vector<hipEvent_t> ev_free;
     struct EvSet { hipEvent_t e[4]; int ntrunk; };
     std::vector<EvSet> ev_pending;
+    struct EvPair { hipEvent_t a, b; int kind; };       // generic graphs: one launch of rdb4_kernel (kind 1) / the 192 -> 64 convolution (2)
+    std::vector<EvPair> ev_pairs;
     long long launches[3] = {0, 0, 0};
     double total_ms[3] = {0, 0, 0};
 
@@ -221,6 +223,8 @@ struct uva_net {
         for (auto& s : ev_pending)
             for (auto e : s.e) (void)hipEventDestroy(e);
         ev_pending.clear();
+        for (auto& q : ev_pairs) { (void)hipEventDestroy(q.a); (void)hipEventDestroy(q.b); }
+        ev_pairs.clear();
         for (auto e : ev_free) (void)hipEventDestroy(e);
         ev_free.clear();
         if (stream) (void)hipStreamDestroy(stream);
@@ -875,6 +879,15 @@ void resolve_events(uva_net* n)
         for (auto e : s.e) n->ev_free.push_back(e);
     }
     n->ev_pending.swap(keep);
+    std::vector<uva_net::EvPair> keep2;
+    for (auto& q : n->ev_pairs) {
+        if (hipEventQuery(q.b) == hipErrorNotReady) { keep2.push_back(q); continue; }
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, q.a, q.b) == hipSuccess) { n->launches[q.kind] += 1; n->total_ms[q.kind] += ms; }
+        n->ev_free.push_back(q.a);
+        n->ev_free.push_back(q.b);
+    }
+    n->ev_pairs.swap(keep2);
 }
 
 // The whole graph for one frame.  stop_after >= 0: run only convolutions 0..stop_after (debug).
@@ -1318,8 +1331,11 @@ int generic_run_planes(uva_net* n, bool f32, const std::vector<PlaneJob>& jobs)
                 HIP_TRY(hipFuncSetAttribute((const void*)rdb4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 n->attr_set[28] = true;
             }
+            uva_net::EvPair evp{nullptr, nullptr, 1};
+            if (n->prof && (evp.a = take_event(n)) && (evp.b = take_event(n))) HIP_TRY(hipEventRecord(evp.a, n->stream));
             hipLaunchKernelGGL(rdb4_kernel, dim3(plan.grid), dim3(256), rdb4_lds_bytes(), n->stream, ra);
             HIP_TRY(hipGetLastError());
+            if (evp.b) { HIP_TRY(hipEventRecord(evp.b, n->stream)); n->ev_pairs.push_back(evp); }
             for (PlaneState& ps : P) finish_layer(ps);
             continue;
         }
@@ -1368,7 +1384,10 @@ int generic_run_planes(uva_net* n, bool f32, const std::vector<PlaneJob>& jobs)
                         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                         n->attr_set[slot] = true;
                     }
+                    uva_net::EvPair evp{nullptr, nullptr, 2};
+                    if (n->prof && cd.cin_pad == 192 && (evp.a = take_event(n)) && (evp.b = take_event(n))) HIP_TRY(hipEventRecord(evp.a, n->stream));
                     hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(256), lds, n->stream, sa);
+                    if (evp.b) { HIP_TRY(hipEventRecord(evp.b, n->stream)); n->ev_pairs.push_back(evp); }
                     return 0;
                 };
                 // 192 inputs: UVA_GENERIC_SK=1 takes g_conv3_sk (32x32x16 MFMAs, the k-loop split between wave pairs) instead of
