@@ -1097,7 +1097,9 @@ inline int generic_grid(const uva_net* n)
     static const int forced = [] { const char* e = std::getenv("UVA_GENERIC_GRID"); return e ? std::atoi(e) : 0; }();
     return forced > 0 ? forced : std::max(8, (n->ncu / 8) * 8);
 }
-inline int generic_plane_class(int w) { return (w >= 16) + (w >= 32) + (w >= 64); }
+// (the strip kernels want 32 / 64 output columns at 1x, 2x or 4x the plane's width; a batch is planned with its narrowest
+// plane, so mixing classes would only cost speed, never change a result)
+inline int generic_plane_class(int w) { return (w >= 8) + (w >= 16) + (w >= 32) + (w >= 64); }
 
 int generic_run_planes(uva_net* n, bool f32, const std::vector<PlaneJob>& jobs)
 {
