@@ -64,9 +64,8 @@ def test_numpy_restatement_agrees_with_the_c_oracle_on_the_real_compact_weights(
 def test_executor_plan_for_valar_and_the_mini_graph(uva, mini):
     """The plan the executor derives from the graph alone (csrc/uva_generic.h plan_concat_groups): Valar's 23 RRDBs x 3
     dense blocks become 69 chains of four Concats each in arrays of 64 + 4 x 32 channels -- all free, the block's input x
-    being written into the array by the sum (or the convolution with the sum in its epilogue) that produces it; only the
-    very first block's x, which comes from the 3-channel head convolution, is copied -- and all but the 1x1 convolutions
-    take the LDS-tiled kernel."""
+    being written into the array by the sum (or the convolution with the sum in its epilogue) that produces it, the
+    very first block's by the 3-channel head convolution -- and all but the 1x1 convolutions take the LDS-tiled kernel."""
     import ctypes
     from upscale_video_amd import _lib
     L = _lib.load()
@@ -75,7 +74,7 @@ def test_executor_plan_for_valar_and_the_mini_graph(uva, mini):
     info = (ctypes.c_int * 8)()
     assert L.uva_net_debug_generic_plan(net._h, info) == 0, L.uva_last_error()
     groups, concats, free, first, lds_convs, widest = list(info)[:6]
-    assert (groups, concats, free, first, widest) == (69, 276, 275, 1, 192)
+    assert (groups, concats, free, first, widest) == (69, 276, 276, 0, 192)
     assert lds_convs == 420 - 69                         # the one 1x1 convolution of every dense block stays on the plain kernel
     p, b, _ = mini
     net2 = uva.Net()
@@ -422,11 +421,11 @@ def test_conv3_sw_work_list_of_a_plane_batch(kind, cols, dims):
 
 
 def test_valar_dense_blocks_are_recognised(uva):
-    """find_rdbs: 68 of 4x_Valar_v1's 69 residual dense blocks run their first four convolutions as one launch (the very
-    first block's x comes from the 3-channel head convolution and is copied into the chain's array after conv1)."""
+    """find_rdbs: all 69 residual dense blocks of 4x_Valar_v1 run their first four convolutions as one launch (the first
+    block's x is written into the chain's array by the 3-channel head convolution), and none of the 276 Concats copies."""
     L = _lib.load()
     net = uva.Net()
     assert net.load_param(VALAR) == 0, getattr(net, "last_error", "")
     info = (ctypes.c_int * 8)()
     assert L.uva_net_debug_generic_plan(net._h, info) == 0, L.uva_last_error()
-    assert info[6] == 68
+    assert info[6] == 69 and info[1] == 276 and info[2] == 276 and info[3] == 0

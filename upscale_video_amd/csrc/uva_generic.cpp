@@ -272,7 +272,10 @@ void plan_concat_groups(GenericGraph& g)
             x_joins = pl >= 0 && g.blobs[x].alias_of < 0 && g.blobs[x].group < 0 && x != g.out_blob;
             if (x_joins) {
                 const GLayer& pr = g.layers[pl];
-                x_joins = pr.kind == GLayer::ADD || pr.kind == GLayer::ELTWISE_SUM || conv_any(pl, g.blobs[root(pr.in[0])].channels);
+                // (a producing convolution only has to be one that can WRITE a channel range: what it reads is its own
+                // business -- the 3-channel head convolution in front of 4x_Valar_v1's first dense block, padded to 32)
+                x_joins = pr.kind == GLayer::ADD || pr.kind == GLayer::ELTWISE_SUM ||
+                          conv_any(pl, (g.blobs[root(pr.in[0])].channels + 31) / 32 * 32);
             }
             int in_chain = 0;
             for (int r : readers[x]) {
