@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UVA_ABI_VERSION 10  /* 2: + uva_net_submit_u8 / uva_net_collect_u8 / uva_host_alloc / uva_host_free;
+#define UVA_ABI_VERSION 11  /* 2: + uva_net_submit_u8 / uva_net_collect_u8 / uva_host_alloc / uva_host_free;
                                3: + uva_get_gpu_pci_bus_id, uva_debug_trunk2_schedule;
                                4: + uva_denoise_u8, uva_debug_denoise_stage; generic graphs (4x_Valar_v1) load;
                                5: + uva_debug_sub10_rows;
@@ -34,7 +34,8 @@ extern "C" {
                                7: + uva_png_decode_bgr, uva_debug_zlib_decompress;
                                8: + uva_net_debug_generic_plan;
                                9: + uva_debug_generic_segments (generic graphs: the fused residual-dense-block kernels);
-                               10: + uva_debug_generic_segments_planes (a frame's reference tiles through those kernels in one launch) */
+                               10: + uva_debug_generic_segments_planes (a frame's reference tiles through those kernels in one launch);
+                               11: + uva_debug_generic_batches */
 
 typedef struct uva_net uva_net;
 
@@ -230,6 +231,12 @@ int uva_debug_generic_segments(int kind, int h, int w, int grid, int32_t* segs_w
  * dims = {h0, w0, h1, w1, ...}, nplanes <= 16; word 5 of a segment is the index of its plane. */
 int uva_debug_generic_segments_planes(int kind, const int* dims, int nplanes, int grid, int32_t* segs_words, size_t capacity_words,
                                       size_t* needed_words, int* seg_begin);
+
+/* Test hook (host only): how the generic executor groups the planes (reference tiles) of an h x w frame into the batches
+ * that go through the graph together.  Four words per plane {h, w, batch, class}; planes of a batch have one class, at
+ * most 16 members and -- unless a single plane exceeds it -- at most batch_pixels input pixels (<= 0: the default). */
+int uva_debug_generic_batches(int h, int w, int tile_size, int border, long long batch_pixels, int32_t* words, size_t capacity_words,
+                              size_t* needed_words);
 
 /* Test hook (host only): the row lists sub10_kernel (the whole 24-feature 1x net, one launch) walks for an h x w
  * frame on `grid` workgroups.  Every workgroup has `*stride` 16-byte entries of 4 words {y, x0, emit, 0}

@@ -362,6 +362,37 @@ def test_conv3_sw_work_list_covers_every_pixel_once(kind, cols, h, w):
     assert blocks.max() - blocks.min() <= 1
 
 
+@pytest.mark.parametrize("h,w,tile,bound", [(1080, 1920, 960, 0), (2160, 3840, 960, 0), (2160, 3840, 960, 4200000), (70, 75, 32, 0),
+                                              (40, 150, 64, 0), (100, 500, 32, 0), (1080, 1920, 0, 0), (4320, 7680, 960, 0)])
+def test_plane_batches(h, w, tile, bound):
+    """generic_plan_batches: every plane (reference tile) of the frame in exactly one batch; a batch's planes of one width
+    class, at most 16 of them and at most `bound` input pixels (default 2.2 M: the planes of a 1080p frame are ONE batch);
+    batches numbered in running order."""
+    L = _lib.load()
+    need = ctypes.c_size_t(0)
+    L.uva_debug_generic_batches(h, w, tile, 10, bound, None, 0, ctypes.byref(need))
+    words = (ctypes.c_int32 * need.value)()
+    assert L.uva_debug_generic_batches(h, w, tile, 10, bound, words, need.value, ctypes.byref(need)) == 0, L.uva_last_error()
+    pl = np.frombuffer(words, np.int32).reshape(-1, 4)
+    if tile > 0:
+        assert len(pl) == -(-h // tile) * -(-w // tile)
+        assert sum(int(p[0]) * int(p[1]) for p in pl) >= h * w           # (borders overlap)
+    else:
+        assert len(pl) == 1 and tuple(pl[0][:2]) == (h, w)
+    limit = bound or 2200000
+    seen = []
+    for k in sorted(set(int(b) for b in pl[:, 2])):
+        members = pl[pl[:, 2] == k]
+        assert len(set(int(c) for c in members[:, 3])) == 1 and len(members) <= 16
+        assert len(members) == 1 or sum(int(p[0]) * int(p[1]) for p in members) <= limit
+        seen.append(k)
+    assert seen == list(range(len(seen)))
+    first = [int(np.argmax(pl[:, 2] == k)) for k in seen]
+    assert first == sorted(first)
+    if (h, w, tile, bound) == (1080, 1920, 960, 0):
+        assert len(seen) == 1 and len(pl) == 4
+
+
 def test_product_side_weight_writer_matches_the_restatements(tmp_path):
     """bench.py / tools write random-init weights for 4x_Valar_v1 (a missing blob upstream) with
     upscale_video_amd.synth.synthetic_weights; the tests use the numpy restatement's writer.  Same bytes."""

@@ -1553,33 +1553,50 @@ int generic_run_plane(uva_net* n, bool f32, const void* src, size_t src_stride, 
     return generic_run_planes(n, f32, std::vector<PlaneJob>{PlaneJob{src, src_stride, sy0, sx0, h, w, dst, dst_stride, cy0, cy1, cx0, cx1}});
 }
 
+// which planes of a frame go through the graph together: batch_of[i] = the batch of plane i, batches numbered in the order
+// they run.  Planes of a batch are of one class (generic_plane_class), at most GEN_MAX_PLANES and `batch_pixels` input
+// pixels (a single plane may exceed the bound: it is then a batch of its own).
+void generic_plan_batches(const std::vector<PlaneDesc>& planes, bool batch_on, long long batch_pixels, std::vector<int>& batch_of)
+{
+    std::vector<int> cls, count;
+    std::vector<long long> px;
+    batch_of.clear();
+    for (const PlaneDesc& p : planes) {
+        const int c = generic_plane_class(p.w);
+        const long long ppx = (long long)p.h * p.w;
+        size_t k = 0;
+        for (; batch_on && k < cls.size(); ++k)
+            if (cls[k] == c && count[k] < GEN_MAX_PLANES && px[k] + ppx <= batch_pixels) break;
+        if (!batch_on || k == cls.size()) { cls.push_back(c); count.push_back(0); px.push_back(0); k = cls.size() - 1; }
+        ++count[k];
+        px[k] += ppx;
+        batch_of.push_back((int)k);
+    }
+}
+// UVA_GENERIC_BATCH=0: one plane after the other (the A/B switch).  UVA_GENERIC_BATCH_PIXELS: a batch holds every array of
+// its planes at once (at 4x, 16x the plane's pixels x 64 channels), so it is bounded to the planes of one 1080p frame
+// (2.13 Mpixel) -- measured with 4x_Valar_v1 at 3840x2160 (12 planes), same bytes every way: this bound 0.343 s per frame
+// and 33 GB in use, 4.2 Mpixel 0.345 s and 61 GB, all planes in one batch 0.338 s and 64 GB, one plane after the other
+// 0.361 s and 33 GB
+bool generic_batch_on() { static const bool on = [] { const char* e = std::getenv("UVA_GENERIC_BATCH"); return !e || std::atoi(e) != 0; }(); return on; }
+long long generic_batch_pixels() { static const long long v = [] { const char* e = std::getenv("UVA_GENERIC_BATCH_PIXELS"); return e ? std::atoll(e) : 2200000ll; }(); return v; }
+
 // the u8 frame call for a generic graph: every reference tile (upscale_processing.py:499-516) is one plane; planes that
-// take the same kernels go through the graph together (UVA_GENERIC_BATCH=0: one after the other, the A/B switch)
+// take the same kernels go through the graph together
 int generic_process_u8_device(uva_net* n, const void* d_in, int h, int w, size_t in_stride, void* d_out, size_t out_stride,
                               int tile_size, int border)
 {
     std::vector<PlaneDesc> planes;
     if (tile_size <= 0) { tile_size = 0; border = 0; }
     if (build_planes(h, w, tile_size, border, planes)) return 1;
-    static const bool batch_on = [] { const char* e = std::getenv("UVA_GENERIC_BATCH"); return !e || std::atoi(e) != 0; }();
-    // a batch holds every array of its planes at once (at 4x, 16x the plane's pixels x 64 channels): bounded to the planes
-    // of one 1080p frame (2.13 Mpixel) -- measured with 4x_Valar_v1 at 3840x2160 (12 planes), same bytes every way:
-    // this bound 0.343 s per frame and 33 GB in use, 4.2 Mpixel 0.345 s and 61 GB, all planes in one batch 0.338 s and
-    // 64 GB, one plane after the other 0.361 s and 33 GB
-    static const long long batch_pixels = [] { const char* e = std::getenv("UVA_GENERIC_BATCH_PIXELS"); return e ? std::atoll(e) : 2200000ll; }();
+    std::vector<int> batch_of;
+    generic_plan_batches(planes, generic_batch_on(), generic_batch_pixels(), batch_of);
     std::vector<std::vector<PlaneJob>> batches;
-    std::vector<int> batch_class;
-    std::vector<long long> batch_px;
-    for (const PlaneDesc& p : planes) {
-        const PlaneJob j{d_in, in_stride, p.src_y0, p.src_x0, p.h, p.w, d_out, out_stride, p.core_y0, std::min(p.core_y1, p.h), p.core_x0,
-                         std::min(p.core_x1, p.w)};
-        const int cls = generic_plane_class(p.w);
-        size_t k = 0;
-        for (; batch_on && k < batches.size(); ++k)
-            if (batch_class[k] == cls && (int)batches[k].size() < GEN_MAX_PLANES && batch_px[k] + (long long)p.h * p.w <= batch_pixels) break;
-        if (!batch_on || k == batches.size()) { batches.emplace_back(); batch_class.push_back(cls); batch_px.push_back(0); k = batches.size() - 1; }
-        batches[k].push_back(j);
-        batch_px[k] += (long long)p.h * p.w;
+    for (size_t i = 0; i < planes.size(); ++i) {
+        const PlaneDesc& p = planes[i];
+        if ((size_t)batch_of[i] >= batches.size()) batches.resize(batch_of[i] + 1);
+        batches[batch_of[i]].push_back(PlaneJob{d_in, in_stride, p.src_y0, p.src_x0, p.h, p.w, d_out, out_stride, p.core_y0,
+                                                std::min(p.core_y1, p.h), p.core_x0, std::min(p.core_x1, p.w)});
     }
     for (const auto& b : batches)
         if (generic_run_planes(n, false, b)) return 1;
@@ -2660,6 +2677,23 @@ int uva_debug_generic_segments_planes(int kind, const int* dims, int nplanes, in
     if (!out || capacity_words < words.size()) return fail("segment buffer too small");
     std::memcpy(out, words.data(), words.size() * sizeof(int32_t));
     if (seg_begin) std::copy(sbeg.begin(), sbeg.end(), seg_begin);
+    return 0;
+}
+
+int uva_debug_generic_batches(int h, int w, int tile_size, int border, long long batch_pixels, int32_t* out, size_t capacity_words,
+                              size_t* needed_words)
+{
+    if (h <= 0 || w <= 0) return fail("bad argument");
+    std::vector<PlaneDesc> planes;
+    if (tile_size <= 0) { tile_size = 0; border = 0; }
+    if (build_planes(h, w, tile_size, border, planes)) return 1;
+    std::vector<int> batch_of;
+    generic_plan_batches(planes, true, batch_pixels > 0 ? batch_pixels : generic_batch_pixels(), batch_of);
+    if (needed_words) *needed_words = planes.size() * 4;
+    if (!out || capacity_words < planes.size() * 4) return fail("batch buffer too small");
+    for (size_t i = 0; i < planes.size(); ++i) {
+        out[4 * i] = planes[i].h; out[4 * i + 1] = planes[i].w; out[4 * i + 2] = batch_of[i]; out[4 * i + 3] = generic_plane_class(planes[i].w);
+    }
     return 0;
 }
 
