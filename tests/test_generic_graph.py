@@ -277,7 +277,7 @@ def test_long_segments_against_the_restatement(sk):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("switch", ["UVA_GENERIC_BATCH", "UVA_GENERIC_FUSE_INTERP"])
+@pytest.mark.parametrize("switch", ["UVA_GENERIC_BATCH", "UVA_GENERIC_FUSE_INTERP", "UVA_GENERIC_FUSE_OUT"])
 def test_plane_batches_and_the_folded_interp_change_nothing(tmp_path, switch):
     """A frame's reference tiles go through the graph together (one rdb4 / g_conv3_sw launch per layer for all planes,
     UVA_GENERIC_BATCH=0: one plane after the other) and the nearest 2x Interp is folded into the next convolution's row

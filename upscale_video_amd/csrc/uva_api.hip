@@ -1244,6 +1244,20 @@ int generic_run_planes(uva_net* n, bool f32, const std::vector<PlaneJob>& jobs)
             skip[pi] = 1;
         }
     }
+    // On the u8 route the graph's last convolution (3 output channels, no activation, no sum, g_conv3_lds) writes the frame's
+    // bytes itself (GConvArgs::u8dst): no fp16 result array, no g_output_u8 launch.  UVA_GENERIC_FUSE_OUT=0: the A/B switch.
+    static const bool out_on = [] { const char* e = std::getenv("UVA_GENERIC_FUSE_OUT"); return !e || std::atoi(e) != 0; }();
+    int out_conv = -1;
+    if (out_on && !f32 && n->generic_lds_conv) {
+        for (size_t li = 0; li < g.layers.size(); ++li) {
+            const GLayer& l = g.layers[li];
+            if (l.kind != GLayer::CONV || l.out.empty() || root(l.out[0]) != root(g.out_blob)) continue;
+            const GenericDevice::ConvDev& cd = n->gd.convs[l.conv];
+            const GBlob& ob = g.blobs[l.out[0]];
+            if (cd.wpk_lds && l.ksize == 3 && !l.has_act && fuse_add[li] < 0 && ob.channels == 3 && group_of(l.out[0]) < 0 && ob.scale == g.scale)
+                out_conv = (int)li;
+        }
+    }
     // residual dense blocks whose first four convolutions run as one rdb4_kernel launch at the first one (UVA_GENERIC_RDB=0:
     // layer by layer, the A/B switch): the other six layers are bookkeeping only, and none of their sums is fused elsewhere
     static const bool rdb_on = [] { const char* e = std::getenv("UVA_GENERIC_RDB"); return !e || std::atoi(e) != 0; }();
@@ -1441,6 +1455,12 @@ int generic_run_planes(uva_net* n, bool f32, const std::vector<PlaneJob>& jobs)
                     ga.res = other.p; ga.res_stride = other.cpad; ga.res_first = fuse_pos[layer_i] == 1;
                     ga.ca = sum->coeffs[0]; ga.cb = sum->coeffs[1];
                 }
+                if ((int)layer_i == out_conv) {       // the frame's bytes leave from this convolution's epilogue (no g_output_u8)
+                    const int s = g.scale;
+                    ga.u8dst = (uint8_t*)ps.j.dst; ga.u8stride = ps.j.dst_stride;
+                    ga.dy0 = ps.j.sy0 * s; ga.dx0 = ps.j.sx0 * s;
+                    ga.cy0 = ps.j.cy0 * s; ga.cy1 = ps.j.cy1 * s; ga.cx0 = ps.j.cx0 * s; ga.cx1 = ps.j.cx1 * s;
+                }
                 const int mbn = cd.cout_pad / 16;
                 // (UVA_GENERIC_WG=0: the 3x3 convolutions stage their weights through LDS again -- the A/B switch)
                 static const int wg_max = [] { const char* e = std::getenv("UVA_GENERIC_WG"); return e ? std::atoi(e) : 4; }();
@@ -1538,6 +1558,7 @@ int generic_run_planes(uva_net* n, bool f32, const std::vector<PlaneJob>& jobs)
         const GBuf& res = ps.buf[root(g.out_blob)];
         const int s = g.scale;
         if (f32) hipLaunchKernelGGL(g_output_f32, dim3((j.w * s + T2 - 1) / T2, j.h * s), dim3(T2), 0, n->stream, res.p, j.h * s, j.w * s, res.cpad, (float*)j.dst);
+        else if (out_conv >= 0) { /* written by the last convolution */ }
         else if (j.cx1 > j.cx0 && j.cy1 > j.cy0)
             hipLaunchKernelGGL(g_output_u8, dim3(((j.cx1 - j.cx0) * s + T2 - 1) / T2, (j.cy1 - j.cy0) * s), dim3(T2), 0, n->stream, res.p, j.h * s, j.w * s, res.cpad,
                                (uint8_t*)j.dst, j.dst_stride, j.sy0 * s, j.sx0 * s, j.cy0 * s, j.cy1 * s, j.cx0 * s, j.cx1 * s);

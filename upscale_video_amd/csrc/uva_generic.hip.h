@@ -134,6 +134,12 @@ struct GConvArgs {
     const _Float16* res;          // nullptr: no sum
     int res_stride, res_first;
     float ca, cb;
+    // the graph's LAST convolution on the u8 route (cout not a multiple of 8: 3 channels): g_output_u8's arithmetic on the
+    // value rounded to fp16 -- rint(v * 255), clamped -- straight into the frame, the tile's core [cy0, cy1) x [cx0, cx1)
+    // only, at (dy0 + y, dx0 + x); the fp16 array is then not written at all
+    uint8_t* u8dst;               // nullptr: the fp16 array as usual
+    size_t u8stride;
+    int dy0, dx0, cy0, cy1, cx0, cx1;
 };
 constexpr int GC_TH = 8, GC_TW = 32;
 constexpr int GC_CH = 1;          // input channels go through LDS 32 at a time (one k-step): 33 KB and 80-100 registers per
@@ -361,7 +367,13 @@ __global__ __launch_bounds__(64 * NW) void g_conv3_lds(GConvArgs a)
         for (int i = tid; i < TH * GC_TW * a.cout; i += NT) {
             const int px = i / a.cout, c = i - px * a.cout;
             const int y = y0 + px / GC_TW, x = x0 + px % GC_TW;
-            if (y < a.h && x < a.w)
+            if (a.u8dst) {
+                if (y >= a.cy0 && y < a.cy1 && x >= a.cx0 && x < a.cx1) {
+                    float q = __builtin_rintf((float)*(const _Float16*)(stage + px * OUTB + 2 * c) * 255.0f);
+                    q = fminf(fmaxf(q, 0.f), 255.f);
+                    a.u8dst[(size_t)(a.dy0 + y) * a.u8stride + (size_t)(a.dx0 + x) * a.cout + c] = (uint8_t)q;
+                }
+            } else if (y < a.h && x < a.w)
                 a.out[((size_t)(y + 1) * (a.w + 2) + (x + 1)) * a.out_stride + a.out_coff + c] = *(const _Float16*)(stage + px * OUTB + 2 * c);
         }
     }
