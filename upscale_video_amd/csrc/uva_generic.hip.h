@@ -493,6 +493,39 @@ inline void sw_segments(const std::vector<int>& dims, int cols, int grid, std::v
     }
     segs.clear();
     seg_begin.assign(1, 0);
+    // Several planes: like rdb_segments, a segment's start (two barriers and the wait for its first six rows) is counted as
+    // SW_FILL blocks and the budget of blocks + starts is what the workgroups share evenly (UVA_RDB_DEAL=0: blocks alone).
+    constexpr int SW_FILL = 1;
+    static const bool by_steps = [] { const char* e = std::getenv("UVA_RDB_DEAL"); return !e || std::atoi(e) != 0; }();
+    if (by_steps && dims.size() > 2) {
+        auto deal = [&](long long T, bool emit) -> int {
+            size_t si = 0;
+            int y = 0, g = 0;
+            if (emit) { segs.clear(); seg_begin.assign(1, 0); }
+            while (si < strips.size()) {
+                long long cap = T;
+                while (si < strips.size() && cap > SW_FILL) {
+                    const Strip& st = strips[si];
+                    const int take = (int)std::min<long long>(st.nb - y, cap - SW_FILL);
+                    if (emit) segs.push_back(GSwSeg{st.c0, y * SW_R, std::min(st.h, (y + take) * SW_R), st.plane});
+                    cap -= take + SW_FILL;
+                    y += take;
+                    if (y == st.nb) { ++si; y = 0; }
+                }
+                ++g;
+                if (emit) seg_begin.push_back((int)segs.size());
+            }
+            return g;
+        };
+        long long lo = total / grid + SW_FILL + 1, hi = total + SW_FILL * (long long)strips.size() + 1;
+        while (lo < hi) {
+            const long long mid = (lo + hi) / 2;
+            if (deal(mid, false) <= grid) hi = mid; else lo = mid + 1;
+        }
+        deal(lo, true);
+        while ((int)seg_begin.size() < grid + 1) seg_begin.push_back((int)segs.size());
+        return;
+    }
     size_t si = 0;
     long long sbase = 0;                       // blocks before strip si
     for (int g = 0; g < grid; ++g) {
@@ -577,6 +610,40 @@ inline void rdb_segments(const std::vector<int>& dims, int grid, std::vector<Rdb
         const size_t n0 = strips.size();
         rdb_strips(dims[2 * pl], dims[2 * pl + 1], (int)pl, strips);
         total += (long long)(strips.size() - n0) * dims[2 * pl];
+    }
+    // What is dealt out evenly is STEPS, not rows: a segment costs its rows plus RDB_FILL steps of pipeline fill, and a
+    // workgroup whose run crosses a strip's end has two segments (dealing rows alone left those 9 steps -- 4 % -- longer than
+    // the others: the launch's tail).  A workgroup takes strip rows, in order, until its budget T is used up; T is the
+    // smallest budget with which `grid` workgroups are enough.  UVA_RDB_DEAL=0: rows dealt evenly, the A/B switch.
+    constexpr int RDB_FILL = 9;                // rdb4_kernel's RA_LAG
+    static const bool by_steps = [] { const char* e = std::getenv("UVA_RDB_DEAL"); return !e || std::atoi(e) != 0; }();
+    auto deal = [&](long long T, bool emit) -> int {
+        size_t si = 0;
+        int y = 0, g = 0;
+        if (emit) { segs.clear(); seg_begin.assign(1, 0); }
+        while (si < strips.size()) {
+            long long cap = T;
+            while (si < strips.size() && cap > RDB_FILL) {
+                const int take = (int)std::min<long long>(strips[si].ye - y, cap - RDB_FILL);
+                if (emit) { RdbSeg sg = strips[si]; sg.yb = y; sg.ye = y + take; segs.push_back(sg); }
+                cap -= take + RDB_FILL;
+                y += take;
+                if (y == strips[si].ye) { ++si; y = 0; }
+            }
+            ++g;
+            if (emit) seg_begin.push_back((int)segs.size());
+        }
+        return g;
+    };
+    if (by_steps) {
+        long long lo = total / grid + RDB_FILL + 1, hi = total + RDB_FILL * (long long)strips.size() + 1;     // (a budget <= RDB_FILL buys no row)
+        while (lo < hi) {
+            const long long mid = (lo + hi) / 2;
+            if (deal(mid, false) <= grid) hi = mid; else lo = mid + 1;
+        }
+        deal(lo, true);
+        while ((int)seg_begin.size() < grid + 1) seg_begin.push_back((int)segs.size());
+        return;
     }
     segs.clear();
     seg_begin.assign(1, 0);
