@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UVA_ABI_VERSION 11  /* 2: + uva_net_submit_u8 / uva_net_collect_u8 / uva_host_alloc / uva_host_free;
+#define UVA_ABI_VERSION 12  /* 2: + uva_net_submit_u8 / uva_net_collect_u8 / uva_host_alloc / uva_host_free;
                                3: + uva_get_gpu_pci_bus_id, uva_debug_trunk2_schedule;
                                4: + uva_denoise_u8, uva_debug_denoise_stage; generic graphs (4x_Valar_v1) load;
                                5: + uva_debug_sub10_rows;
@@ -35,7 +35,8 @@ extern "C" {
                                8: + uva_net_debug_generic_plan;
                                9: + uva_debug_generic_segments (generic graphs: the fused residual-dense-block kernels);
                                10: + uva_debug_generic_segments_planes (a frame's reference tiles through those kernels in one launch);
-                               11: + uva_debug_generic_batches */
+                               11: + uva_debug_generic_batches;
+                               12: + uva_debug_trunkw_schedule (trunkw_kernel: fused trunk pairs as Winograd F(2,3)) */
 
 typedef struct uva_net uva_net;
 
@@ -211,6 +212,12 @@ int uva_net_debug_packed_weights(uva_net* net, int conv_idx, uint16_t* out, size
  * real.  plane_hw receives h, w, activation pitch and array offset (pixels) of up to max_planes planes.
  * Returns non-zero if steps_words (capacity in 32-bit words) is too small; *needed_words says how many. */
 int uva_debug_trunk2_schedule(int h, int w, int tile_size, int border, int grid, uint32_t* steps_words,
+                              size_t capacity_words, size_t* needed_words, int* nsteps, int* stride,
+                              long long* plane_info, int max_planes, int* nplanes, long long* guard_bytes);
+
+/* Test hook (host only): the same for trunkw_kernel (csrc/uva_wino.hip.h: the fused pair as 1-D Winograd F(2,3)), whose
+ * segments start without the two input rows shared with the step above: entry layout in that file (TrunkwArgs). */
+int uva_debug_trunkw_schedule(int h, int w, int tile_size, int border, int grid, uint32_t* steps_words,
                               size_t capacity_words, size_t* needed_words, int* nsteps, int* stride,
                               long long* plane_info, int max_planes, int* nplanes, long long* guard_bytes);
 

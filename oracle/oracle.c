@@ -48,6 +48,13 @@
 enum {
     UVO_F16_STORAGE = 1, /* emulate the HIP path's storage precision: fp16 weights,
                             fp16 activations after every PReLU (fp32 accumulate) */
+    UVO_F16_INPUT = 4,   /* with UVO_F16_STORAGE: the input blob itself is rounded to fp16 -- what the HIP path's float
+                            (Extractor) route does with the caller's normalised ncnn::Mat (head_kernel<NF, 1>); the u8
+                            route feeds the integer pixel values, which are exact */
+    UVO_WINOGRAD_F23 = 2, /* with UVO_F16_STORAGE: the 64 -> 64 trunk convolutions that the HIP path runs
+                            as fused pairs are evaluated as 1-D Winograd F(2,3) along x with the kernel's
+                            rounding points (trunkw_kernel, csrc/uva_wino.hip.h): transformed inputs and
+                            transformed weights rounded to fp16, products and sums in fp32 */
 };
 
 typedef enum {
@@ -441,6 +448,81 @@ static void conv2d(const layer* L, const float* wt, const blob* in, blob* out, i
     free(pin);
 }
 
+/* The same convolution (3x3, pad 1, stride 1) as 1-D Winograd F(2,3) along x, the way trunkw_kernel evaluates
+ * it.  Output columns come in pairs (xa, xa+1), xa = align + 2q (align = -1 for the first layer of a fused
+ * pair, 0 for the second: csrc/uva_wino.hip.h); with d(x) the fp16 input activation (0 outside the plane):
+ *   V0 = f16(d(xa-1) - d(xa+1))  V1 = f16(d(xa) + d(xa+1))  V2 = f16(d(xa+1) - d(xa))  V3 = f16(d(xa) - d(xa+2))
+ *   U0 = f16(g0)  U1 = f16((g0+g1+g2)/2)  U2 = f16((g0-g1+g2)/2)  U3 = f16(g2)     (g = the row's three taps)
+ *   Mj = sum over ci, ky of Uj * Vj (fp32), M1's sum starting at the bias;  out(xa) = (M0 + M1) + M2,  out(xa+1) = (M1 - M2) - M3.
+ * In exact arithmetic this IS conv2d (Lavin & Gray 2015, F(2,3)); what differs is where fp16 rounds. */
+static void conv2d_wino_f23(const layer* L, const blob* in, blob* out, int align, int nthreads)
+{
+    const int C = L->cin, O = L->num_output, H = in->h, W = in->w;
+    const int NP = (W - 1 - align) / 2 + 1;           /* pairs covering columns align .. W-1 */
+    const int PH = H + 2;
+    out->c = O; out->h = H; out->w = W;
+    out->d = (float*)malloc(sizeof(float) * (size_t)O * H * W);
+    float* V = (float*)calloc((size_t)4 * C * PH * NP, sizeof(float));      /* [j][ci][y+1][q], rows -1 and H zero */
+    float* U = (float*)malloc(sizeof(float) * (size_t)4 * O * C * 3);       /* [j][co][ci][ky] */
+    for (int co = 0; co < O; ++co)
+        for (int ci = 0; ci < C; ++ci)
+            for (int ky = 0; ky < 3; ++ky) {
+                const float* g = L->w + (((size_t)co * C + ci) * 3 + ky) * 3;
+                const double g0 = g[0], g1 = g[1], g2 = g[2];
+                const size_t k = ((size_t)co * C + ci) * 3 + ky, js = (size_t)O * C * 3;
+                U[0 * js + k] = uvo_round_f16(g[0]);
+                U[1 * js + k] = uvo_round_f16((float)(0.5 * (g0 + g1 + g2)));
+                U[2 * js + k] = uvo_round_f16((float)(0.5 * (g0 - g1 + g2)));
+                U[3 * js + k] = uvo_round_f16(g[2]);
+            }
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for collapse(2) schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (int ci = 0; ci < C; ++ci)
+        for (int y = 0; y < H; ++y) {
+            const float* row = in->d + ((size_t)ci * H + y) * W;
+#define D_(x) (((x) >= 0 && (x) < W) ? row[(x)] : 0.f)
+            for (int q = 0; q < NP; ++q) {
+                const int xa = align + 2 * q;
+                const float d0 = D_(xa - 1), d1 = D_(xa), d2 = D_(xa + 1), d3 = D_(xa + 2);
+                const size_t k = ((size_t)ci * PH + y + 1) * NP + q, js = (size_t)C * PH * NP;
+                V[0 * js + k] = uvo_round_f16(d0 - d2);
+                V[1 * js + k] = uvo_round_f16(d1 + d2);
+                V[2 * js + k] = uvo_round_f16(d2 - d1);
+                V[3 * js + k] = uvo_round_f16(d1 - d3);
+            }
+#undef D_
+        }
+#ifdef _OPENMP
+#pragma omp parallel for collapse(2) schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (int co = 0; co < O; ++co)
+        for (int y = 0; y < H; ++y) {
+            float* M = (float*)calloc((size_t)4 * NP, sizeof(float));
+            const float b = L->bias[co];
+            for (int q = 0; q < NP; ++q) M[NP + q] = b;     /* M1 enters both results with +: its sum starts at the bias */
+            for (int j = 0; j < 4; ++j) {
+                float* restrict mj = M + (size_t)j * NP;
+                for (int ci = 0; ci < C; ++ci)
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const float u = U[(size_t)j * O * C * 3 + ((size_t)co * C + ci) * 3 + ky];
+                        const float* restrict v = V + (size_t)j * C * PH * NP + ((size_t)ci * PH + y + ky) * NP;
+                        for (int q = 0; q < NP; ++q) mj[q] += u * v[q];
+                    }
+            }
+            float* o = out->d + ((size_t)co * H + y) * W;
+            for (int q = 0; q < NP; ++q) {
+                const int xa = align + 2 * q;
+                const float m0 = M[q], m1 = M[NP + q], m2 = M[2 * NP + q], m3 = M[3 * (size_t)NP + q];
+                if (xa >= 0) o[xa] = (m0 + m1) + m2;
+                if (xa + 1 < W) o[xa + 1] = (m1 - m2) - m3;
+            }
+            free(M);
+        }
+    free(V); free(U);
+}
+
 /* ncnn prelu.cpp: x < 0 ? x * slope[c] : x (num_slope == channels here) */
 static void prelu(const layer* L, blob* b, int f16)
 {
@@ -519,6 +601,8 @@ static int run_graph(const uvo_model* m, const float* in_chw, int h, int w, int 
             o->c = 3; o->h = h; o->w = w;
             o->d = (float*)malloc(sizeof(float) * 3 * (size_t)h * w);
             memcpy(o->d, in_chw, sizeof(float) * 3 * (size_t)h * w);
+            if (f16 && (flags & UVO_F16_INPUT))
+                for (size_t k = 0; k < 3 * (size_t)h * w; ++k) o->d[k] = uvo_round_f16(o->d[k]);
             break;
         }
         case L_SPLIT:
@@ -534,6 +618,13 @@ static int run_graph(const uvo_model* m, const float* in_chw, int h, int w, int 
             blob* o = &bl[nb++];
             snprintf(o->name, UVO_NAME, "%s", L->out[0]);
             if (a->c != L->cin) goto done;
+            /* the HIP path fuses trunk convolutions (2k-1, 2k) into one launch; a debug tap on 2k-1 runs it alone,
+             * through the direct kernel (uva_api.hip run_graph) */
+            const int second = convs + (convs & 1);
+            if (f16 && (flags & UVO_WINOGRAD_F23) && m->nf == 64 && L->kernel == 3 && L->cin == 64 && L->num_output == 64 &&
+                convs >= 1 && second <= m->nconv - 2 && (tap_conv < 0 || second <= tap_conv))
+                conv2d_wino_f23(L, a, o, (convs & 1) ? -1 : 0, nthreads);
+            else
             conv2d(L, f16 ? L->w16 : L->w, a, o, nthreads);
             free(a->d); a->d = NULL;
             if (convs == tap_conv && !(i + 1 < m->nlayers && m->L[i + 1].type == L_PRELU)) {

@@ -16,6 +16,16 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "liboracle.so")
 
 F16_STORAGE = 1
+F16_INPUT = 4        # with F16_STORAGE: the float route rounds the caller's normalised input to fp16
+WINOGRAD_F23 = 2     # with F16_STORAGE: fused trunk pairs as 1-D Winograd F(2,3) with the HIP kernel's rounding points
+
+
+def product_flags(route="u8"):
+    """The storage mode that restates the HIP path's rounding points: fp16 storage, and -- unless the product is run with
+    UVA_TRUNK_WINO=0 (direct convolution, trunk2_kernel) or UVA_TRUNK_FUSION=0 -- the fused 64 -> 64 trunk pairs as
+    Winograd F(2,3) (trunkw_kernel).  No effect on the 24-feature net."""
+    wino = os.environ.get("UVA_TRUNK_WINO", "1") != "0" and os.environ.get("UVA_TRUNK_FUSION", "1") != "0"
+    return F16_STORAGE | (WINOGRAD_F23 if wino else 0) | (F16_INPUT if route == "f32" else 0)
 
 
 def build(force=False):

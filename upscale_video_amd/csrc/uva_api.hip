@@ -11,6 +11,7 @@
 #include "uva_kernels.hip.h"
 #include "uva_model.h"
 #include "uva_png.hip.h"
+#include "uva_wino.h"
 
 namespace uva {   // uva_pngread.cpp
 int png_read_bgr(const uint8_t* file, size_t len, uint8_t* out, size_t cap, int* h_out, int* w_out, std::string& err);
@@ -75,12 +76,20 @@ struct Workspace {
     Trunk2Step* d_steps2 = nullptr;
     int* d_nsteps2 = nullptr;
     int max_steps2 = 0, grid2 = 0;
+    // trunkw_kernel (fused layer pair, Winograd F(2,3)): its own step lists (segments start without the shared rows)
+    Trunk2Step* d_stepsw = nullptr;
+    int* d_nstepsw = nullptr;
+    int max_stepsw = 0;
     void release()
     {
         if (d_planes) (void)hipFree(d_planes);
         if (d_sched4) (void)hipFree(d_sched4);
         if (d_steps2) (void)hipFree(d_steps2);
         if (d_nsteps2) (void)hipFree(d_nsteps2);
+        if (d_stepsw) (void)hipFree(d_stepsw);
+        if (d_nstepsw) (void)hipFree(d_nstepsw);
+        d_stepsw = nullptr;
+        d_nstepsw = nullptr;
         if (d_rows10) (void)hipFree(d_rows10);
         if (d_nrows10) (void)hipFree(d_nrows10);
         d_rows10 = nullptr;
@@ -98,6 +107,7 @@ struct Workspace {
 
 struct DeviceLayer {
     half8* wpk = nullptr;
+    half8* wpk_w = nullptr;   // 64 -> 64 trunk layers: pack_trunk64_wino image for trunkw_kernel
     half8* wpk16 = nullptr;   // tail layer of the 64-feature 2x / 4x nets: pack_tail64 image for tail_kernel / tail4_kernel
     half8* wpk_s10 = nullptr; // 24-feature 1x net: pack_sub16 image for sub10_kernel, with its own (sign-folded) bias
     float* bias_s10 = nullptr;
@@ -143,6 +153,7 @@ struct uva_net {
     bool generic_lds_conv = true; // generic graphs: 3x3 convolutions through g_conv3_lds (UVA_GENERIC_LDS=0: the plain g_conv<3>)
     bool fuse_all = true;         // 24-feature 1x net: all ten convolutions in one launch (sub10_kernel); UVA_SUB10=0 turns it off
     bool fuse_pairs = true;       // 64-feature nets: trunk layers run two per launch (trunk2_kernel); UVA_TRUNK_FUSION=0 turns it off
+    bool wino = true;             // ... as 1-D Winograd F(2,3) (trunkw_kernel); UVA_TRUNK_WINO=0: trunk2_kernel (direct convolution)
     LastCall last;
     // pipelined host route (uva_net_submit_u8 / uva_net_collect_u8): H2D, kernels and D2H of
     // consecutive frames overlap on three streams; PIPE_SLOTS frames may be in flight
@@ -186,6 +197,7 @@ struct uva_net {
         if (stream) (void)hipStreamSynchronize(stream);
         for (auto& l : layers) {
             if (l.wpk) (void)hipFree(l.wpk);
+            if (l.wpk_w) (void)hipFree(l.wpk_w);
             if (l.wpk16) (void)hipFree(l.wpk16);
             if (l.wpk_s10) (void)hipFree(l.wpk_s10);
             if (l.bias_s10) (void)hipFree(l.bias_s10);
@@ -479,6 +491,104 @@ int launch_trunk2(uva_net* n, const Workspace* ws, const Trunk2Args& a)
     return 0;
 }
 
+// Step lists of trunkw_kernel: the same 30-column strips and 4-row steps as trunk2_kernel's, but a segment starts
+// WITHOUT the two input rows a step shares with the one above it: its first producer step yields two valid
+// intermediate rows and its first consumer step nothing, so k steps yield 4 (k - 1) output rows and a segment of
+// `rows` output rows beginning at row r0 has its first intermediate block at row r0 - 3.  Step g of a segment:
+//   producer: intermediate rows yA .. yA+3, yA = r0 - 3 + 4g, from the new input rows yA+1 .. yA+4 (+ the two above);
+//   consumer: output rows yA-1 .. yA+2 = r0 + 4(g-1) .. (g >= 1), from the last two rows of block g-1 and block g.
+int build_trunkw_schedule(const std::vector<PlaneDesc>& planes, int grid, size_t guard_bytes, std::vector<Trunk2Step>& steps,
+                          std::vector<int>& nsteps, int* max_steps)
+{
+    constexpr int PIXB = 128;
+    struct Seg { int plane, x0, r0, rows, k; };
+    long long total = 0;
+    for (const auto& p : planes) total += (long long)((p.w + TW_SW - 1) / TW_SW) * ((p.h + 3) / 4 + 1);
+    std::vector<std::vector<Seg>> per_wg;
+    int L = (int)std::max<long long>(4, (total + grid - 1) / grid);
+    for (;; ++L) {
+        per_wg.assign(1, {});
+        int cap = L;
+        auto next_wg = [&]() { per_wg.emplace_back(); cap = L; };
+        for (size_t pi = 0; pi < planes.size(); ++pi) {
+            const PlaneDesc& p = planes[pi];
+            for (int x0 = 0; x0 < p.w; x0 += TW_SW) {
+                int y = 0;
+                while (y < p.h) {
+                    const int need = (p.h - y + 3) / 4 + 1;
+                    if (need <= cap) {
+                        per_wg.back().push_back({(int)pi, x0, y, p.h - y, need});
+                        cap -= need;
+                        y = p.h;
+                    } else if (cap < 3) {             // a segment of fewer than 3 steps is mostly pipeline fill
+                        next_wg();
+                        continue;
+                    } else {
+                        per_wg.back().push_back({(int)pi, x0, y, 4 * (cap - 1), cap});
+                        y += 4 * (cap - 1);
+                        cap = 0;
+                    }
+                    if (cap < 1) next_wg();
+                }
+            }
+        }
+        while (!per_wg.empty() && per_wg.back().empty()) per_wg.pop_back();
+        if ((int)per_wg.size() <= grid) break;
+    }
+    int most = 0;
+    for (const auto& v : per_wg) {
+        int k = 0;
+        for (const Seg& sg : v) k += sg.k;
+        most = std::max(most, k);
+    }
+    *max_steps = most;
+    const int stride = most + TW_PAD_STEPS;
+    steps.assign((size_t)grid * stride, Trunk2Step{make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)});
+    nsteps.assign(grid, 0);
+    const int per_xcd = grid / 8;
+    for (size_t c = 0; c < per_wg.size(); ++c) {
+        const int b = (int)(c % per_xcd) * 8 + (int)(c / per_xcd);
+        Trunk2Step* out = steps.data() + (size_t)b * stride;
+        int g = 0;
+        for (const Seg& sg : per_wg[c]) {
+            const PlaneDesc& p = planes[sg.plane];
+            for (int j = 0; j < sg.k; ++j, ++g) {
+                const int yA = sg.r0 - 3 + 4 * j;                        // first intermediate row of the block
+                // first new input row = pixel (yA + 1, x0 - 2) = array position (yA + 2, x0 - 1)
+                const long long ao = (long long)guard_bytes +
+                                     ((long long)p.act_off + (long long)(yA + 2) * p.pitch + (sg.x0 - 1)) * PIXB;
+                if (ao < 0 || (ao >> 40)) return fail("activation buffer too large for the step encoding");
+                unsigned rmask = 0;
+                for (int r = 0; r < 4; ++r)
+                    if (yA + r >= 0 && yA + r < p.h) rmask |= 1u << r;
+                const unsigned c_lo = sg.x0 == 0 ? 1 : 0, c_hi = (unsigned)std::min(32, p.w - sg.x0 + 1);
+                out[g].a = make_uint4((unsigned)ao, (unsigned)(ao >> 32) | (rmask << 8) | (c_lo << 12) | (c_hi << 18) | (1u << 24),
+                                      (unsigned)(p.pitch * PIXB), (unsigned)sg.plane);
+                if (j >= 1) {
+                    const int yo = sg.r0 + 4 * (j - 1);
+                    const long long bo = (long long)guard_bytes +
+                                         ((long long)p.act_off + (long long)(yo + 1) * p.pitch + (sg.x0 + 1)) * PIXB;
+                    const unsigned vy = (unsigned)std::min(4, sg.r0 + sg.rows - yo), vx = (unsigned)std::min(TW_SW, p.w - sg.x0);
+                    out[g].b = make_uint4((unsigned)bo, (unsigned)(bo >> 32) | (vy << 8) | (vx << 11) | (1u << 24),
+                                          (unsigned)(p.pitch * PIXB), (unsigned)sg.plane);
+                }
+            }
+        }
+        nsteps[b] = g;
+        for (int k = 0; k < TW_PAD_STEPS && g > 0; ++k) {     // harmless re-fetches of the last rows, nothing active
+            out[g + k].a = out[g - 1].a;
+            out[g + k].a.y &= 0xffu;
+        }
+    }
+    return 0;
+}
+
+int launch_trunkw(uva_net* n, const Workspace* ws, const TrunkwArgs& a)
+{
+    HIP_TRY(launch_trunkw_kernel(n->stream, ws->grid2, a));
+    return 0;
+}
+
 // Row descriptors of sub10_kernel for an h x w frame: 60-column strips, the sequence (strip, row) dealt out to the
 // workgroups in contiguous ranges; every range (segment) starts 10 rows early and ends 9 rows late (the rows the
 // layers in between need), only its own rows are written out.
@@ -618,6 +728,7 @@ int ensure_device(uva_net* n)
     } undo{n};
     HIP_TRY(hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking));
     if (const char* e = std::getenv("UVA_TRUNK_FUSION")) n->fuse_pairs = std::atoi(e) != 0;
+    if (const char* e = std::getenv("UVA_TRUNK_WINO")) n->wino = std::atoi(e) != 0;
     if (const char* e = std::getenv("UVA_SUB10")) n->fuse_all = std::atoi(e) != 0;
     if (const char* e = std::getenv("UVA_GENERIC_LDS")) n->generic_lds_conv = std::atoi(e) != 0;
     if (const char* e = std::getenv("UVA_GENERIC_FUSE_ADD")) n->generic_fuse_add = std::atoi(e) != 0;
@@ -666,6 +777,11 @@ int ensure_device(uva_net* n)
         else pack_conv3x3(g.convs[i], g.nf, pk, nullptr, &mf);
         DeviceLayer& dl = n->layers[i];
         if (upload(&dl.wpk, pk.data(), pk.size() * 2, n->stream)) return 1;
+        std::vector<uint16_t> pkw;
+        if (g.nf == 64 && i > 0 && i + 1 < g.convs.size()) {
+            pack_trunk64_wino(g.convs[i], pkw);
+            if (upload(&dl.wpk_w, pkw.data(), pkw.size() * 2, n->stream)) return 1;
+        }
         std::vector<uint16_t> pk16;
         if (g.nf == 64 && (g.scale == 2 || g.scale == 4) && i + 1 == g.convs.size()) {
             pack_tail64(g.convs[i], pk16);
@@ -771,8 +887,8 @@ int get_workspace(uva_net* n, int h, int w, int tile_size, int border, Workspace
     ws.act_pixels = pix;
     // everything that can be refused is checked BEFORE anything is allocated
     std::vector<uint4> sched4;
-    std::vector<Trunk2Step> steps2;
-    std::vector<int> nsteps2;
+    std::vector<Trunk2Step> steps2, stepsw;
+    std::vector<int> nsteps2, nstepsw;
     int max_pitch = 0;
     for (auto& p : ws.planes) max_pitch = std::max(max_pitch, p.pitch);
     ws.guard_bytes = (size_t)8 * max_pitch * n->g.nf * 2;
@@ -795,6 +911,7 @@ int get_workspace(uva_net* n, int h, int w, int tile_size, int border, Workspace
         ws.grid2 = std::max(8, (n->ncu / 8) * 8);
         const char* const nv = std::getenv("UVA_T2_NARROW");      // (A/B switch: 0 = every strip computes both fragment columns)
         if (build_trunk2_schedule(ws.planes, ws.grid2, ws.guard_bytes, steps2, nsteps2, &ws.max_steps2, !(nv && std::atoi(nv) == 0))) return 1;
+        if (build_trunkw_schedule(ws.planes, ws.grid2, ws.guard_bytes, stepsw, nstepsw, &ws.max_stepsw)) return 1;
     }
     const size_t bytes = pix * (size_t)n->g.nf * 2 + 2 * ws.guard_bytes;
     // LRU over the cached geometries, by bytes (the fused route keeps one workspace per frame size, the
@@ -833,6 +950,10 @@ int get_workspace(uva_net* n, int h, int w, int tile_size, int border, Workspace
         HIP_TRY(hipMalloc((void**)&ws.d_nsteps2, nsteps2.size() * sizeof(int)));
         HIP_TRY(hipMemcpyAsync(ws.d_steps2, steps2.data(), steps2.size() * sizeof(Trunk2Step), hipMemcpyHostToDevice, n->stream));
         HIP_TRY(hipMemcpyAsync(ws.d_nsteps2, nsteps2.data(), nsteps2.size() * sizeof(int), hipMemcpyHostToDevice, n->stream));
+        HIP_TRY(hipMalloc((void**)&ws.d_stepsw, stepsw.size() * sizeof(Trunk2Step)));
+        HIP_TRY(hipMalloc((void**)&ws.d_nstepsw, nstepsw.size() * sizeof(int)));
+        HIP_TRY(hipMemcpyAsync(ws.d_stepsw, stepsw.data(), stepsw.size() * sizeof(Trunk2Step), hipMemcpyHostToDevice, n->stream));
+        HIP_TRY(hipMemcpyAsync(ws.d_nstepsw, nstepsw.data(), nstepsw.size() * sizeof(int), hipMemcpyHostToDevice, n->stream));
     }
     HIP_TRY(hipStreamSynchronize(n->stream));
     guard.w = nullptr;
@@ -965,6 +1086,27 @@ int run_graph(uva_net* n, Workspace* ws, bool f32, const void* src, size_t src_s
     for (int i = 1; i < nconv - 1; ++i) {
         if (stop_after >= 0 && i > stop_after) return 0;
         // two trunk layers per launch where a pair is wanted in full (a debug tap on layer i itself runs it alone)
+        if (n->fuse_pairs && n->wino && ws->d_stepsw && n->layers[i].wpk_w && i + 1 < nconv - 1 && (stop_after < 0 || i + 1 <= stop_after)) {
+            TrunkwArgs wa;
+            std::memset(&wa, 0, sizeof wa);
+            wa.in_act = ws->act_base[cur];
+            wa.out_act = ws->act_base[cur ^ 1];
+            for (int k = 0; k < 2; ++k) {
+                wa.wpk[k] = n->layers[i + k].wpk_w;
+                wa.bias[k] = n->layers[i + k].bias;
+                wa.slope[k] = n->layers[i + k].slope;
+            }
+            wa.steps = ws->d_stepsw;
+            wa.nsteps = ws->d_nstepsw;
+            wa.max_steps = ws->max_stepsw;
+            wa.sink = n->d_sink;
+            if (launch_trunkw(n, ws, wa)) return 1;
+            ++ev.ntrunk;
+            ++i;
+            cur ^= 1;
+            n->last_act_buf = cur;
+            continue;
+        }
         if (n->fuse_pairs && ws->d_steps2 && i + 1 < nconv - 1 && (stop_after < 0 || i + 1 <= stop_after)) {
             Trunk2Args ta;
             std::memset(&ta, 0, sizeof ta);
@@ -2539,6 +2681,38 @@ int uva_net_debug_trunk_stamps(uva_net* n, unsigned long long* out, int max_tile
         if (tiles) *tiles = (ca.tiles_per_xcd + grid6 / 8 - 1) / (grid6 / 8);
         return rc6;
     }
+    if (ablate == 8) {
+        // trunkw_kernel (the fused pair as Winograd F(2,3)): stamps of workgroup 0, both groups (out[16*it + 8*group + k], entry
+        // at out[16*niter]); only an instrumented build (-DUVA_INSTRUMENT) writes them
+        if (!ws->d_stepsw || !n->layers[1].wpk_w) { (void)hipFree(d); return fail("no Winograd fused-pair schedule for this net"); }
+        TrunkwArgs wa;
+        std::memset(&wa, 0, sizeof wa);
+        wa.in_act = ws->act_base[0];
+        wa.out_act = ws->act_base[1];
+        for (int k = 0; k < 2; ++k) { wa.wpk[k] = n->layers[1 + k].wpk_w; wa.bias[k] = n->layers[1 + k].bias; wa.slope[k] = n->layers[1 + k].slope; }
+        wa.steps = ws->d_stepsw; wa.nsteps = ws->d_nstepsw; wa.max_steps = ws->max_stepsw; wa.sink = n->d_sink;
+        if (2 * (ws->max_stepsw + 3) + 1 > max_tiles) { (void)hipFree(d); return fail("max_tiles too small"); }
+        int rc8 = launch_trunkw(n, ws, wa);
+        HIP_TRY(hipEventRecord(e0, n->stream));
+        for (int r = 0; r < 50 && !rc8; ++r) rc8 = launch_trunkw(n, ws, wa);
+        HIP_TRY(hipEventRecord(e1, n->stream));
+        wa.dbg = d;
+        if (!rc8) rc8 = launch_trunkw(n, ws, wa);
+        if (!rc8) {
+            HIP_TRY(hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, n->stream));
+            HIP_TRY(hipStreamSynchronize(n->stream));
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+            if (kernel_ms) *kernel_ms = ms / 50;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        (void)hipFree(d);
+        int ns0 = 0;
+        if (!rc8) HIP_TRY(hipMemcpy(&ns0, ws->d_nstepsw, sizeof(int), hipMemcpyDeviceToHost));
+        if (tiles) *tiles = ns0 + 2;
+        return rc8;
+    }
     if (ablate == 5) {
         // the fused pair kernel: stamps of workgroup 0, both groups (out[16*it + 8*group + k], entry at out[16*niter])
         if (!ws->d_steps2) { (void)hipFree(d); return fail("no fused-pair schedule for this net"); }
@@ -2642,6 +2816,38 @@ int uva_debug_trunk2_schedule(int h, int w, int tile_size, int border, int grid,
     if (build_trunk2_schedule(planes, grid, guard, steps, ns, &max_steps)) return 1;
     if (needed_words) *needed_words = steps.size() * 8;
     if (stride) *stride = max_steps + T2_PAD_STEPS;
+    if (nplanes) *nplanes = (int)planes.size();
+    if (guard_bytes) *guard_bytes = (long long)guard;
+    if (plane_info)
+        for (int i = 0; i < (int)planes.size() && i < max_planes; ++i) {
+            plane_info[4 * i + 0] = planes[i].h; plane_info[4 * i + 1] = planes[i].w;
+            plane_info[4 * i + 2] = planes[i].pitch; plane_info[4 * i + 3] = planes[i].act_off;
+        }
+    if (!steps_words || capacity_words < steps.size() * 8) return fail("steps buffer too small");
+    std::memcpy(steps_words, steps.data(), steps.size() * sizeof(Trunk2Step));
+    if (nsteps) std::copy(ns.begin(), ns.end(), nsteps);
+    return 0;
+}
+
+int uva_debug_trunkw_schedule(int h, int w, int tile_size, int border, int grid, uint32_t* steps_words,
+                              size_t capacity_words, size_t* needed_words, int* nsteps, int* stride,
+                              long long* plane_info, int max_planes, int* nplanes, long long* guard_bytes)
+{
+    if (h <= 0 || w <= 0 || grid < 8 || grid % 8) return fail("bad argument");
+    std::vector<PlaneDesc> planes;
+    if (tile_size <= 0) { tile_size = 0; border = 0; }
+    if (build_planes(h, w, tile_size, border, planes)) return 1;
+    size_t pix = 0;
+    int max_pitch = 0;
+    layout_planes(planes, &pix, nullptr, nullptr);
+    for (auto& p : planes) max_pitch = std::max(max_pitch, p.pitch);
+    const size_t guard = (size_t)8 * max_pitch * 128;
+    std::vector<Trunk2Step> steps;
+    std::vector<int> ns;
+    int max_steps = 0;
+    if (build_trunkw_schedule(planes, grid, guard, steps, ns, &max_steps)) return 1;
+    if (needed_words) *needed_words = steps.size() * 8;
+    if (stride) *stride = max_steps + TW_PAD_STEPS;
     if (nplanes) *nplanes = (int)planes.size();
     if (guard_bytes) *guard_bytes = (long long)guard;
     if (plane_info)

@@ -48,12 +48,9 @@
 #define UVA_MEMTIME() 0ull
 #endif
 
-namespace uva {
+#include "uva_devutil.hip.h"
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+namespace uva {
 
 // compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{}).
 // Used where a loop body must see its index as a constant expression (if constexpr, builtin
@@ -109,7 +106,6 @@ struct Geo {
     static constexpr int BUFB = NCHUNK * 1024;
 };
 
-constexpr int PARAM_LDS = 768;   // bias[64] + slope[64] + PReLU med3 selector[64] floats
 
 struct ConvArgs {
     const PlaneDesc* planes;
@@ -155,61 +151,6 @@ struct HeadArgs {
     const float* slope;
     float in_scale;               // 1/255 for u8 sources (applied to the fp32 accumulator), else 1
 };
-
-__device__ __forceinline__ unsigned lds_offset(const void* p)
-{
-    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
-}
-
-// A wave-uniform pointer that lives in VGPRs (e.g. computed from LDS reads), moved to SGPRs.
-__device__ __forceinline__ const char* uniform_ptr(const char* p)
-{
-    const unsigned long long v = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
-    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return (const char*)(((unsigned long long)hi << 32) | lo);
-}
-
-// An opaque copy of a lane-constant value: stops hipcc from hoisting everything derived from it out
-// of the persistent tile loop (where it would be spilled to scratch and reloaded behind a vmcnt wait).
-__device__ __forceinline__ int opaque(int v)
-{
-    asm volatile("" : "+v"(v));
-    return v;
-}
-
-// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to lds_dst + lane*16.
-// Invisible to hipcc's s_waitcnt bookkeeping by design (it would otherwise drain the DMA before
-// every LDS read); completion is waited for explicitly with vmcnt(0) in tile_barrier().  No
-// "memory" clobber: the pieces are issued between the MFMAs of the previous tile and must not
-// fence its LDS reads; ordering against the buffers comes from tile_barrier() alone.
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst)
-{
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_dst));
-}
-
-// Same, with the tile's base address in SGPRs and a 32-bit per-lane byte offset (the "saddr" form):
-// no 64-bit vector address arithmetic per piece.
-__device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_dst)
-{
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(sbase), "s"(lds_dst));
-}
 
 // End of a tile's k-loop: wait until all but the newest KEEP vector-memory operations of this
 // wave have completed (loads, LDS-DMA included, return in issue order), drain LDS, then barrier.
@@ -287,9 +228,6 @@ __device__ __forceinline__ const char* halo_tile_base(const _Float16* act, const
     return (const char*)act +
            ((size_t)pl.act_off + (size_t)(ty * THT) * pl.pitch + (size_t)tx * TW) * Geo<NF, THT>::PIXB;
 }
-
-typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Trunk epilogue shared by the head and trunk kernels: per-channel PReLU (ncnn prelu.cpp:
 // x < 0 ? x*slope[c] : x), fp32 -> fp16 RNE, store into the zero-bordered NHWC plane.
@@ -1473,21 +1411,6 @@ __device__ __forceinline__ int trunk_pieces_issued(int n, int wave)
     return (n == TrunkGeo<NF>::CPW && 4 * (n - 1) + wave >= TrunkGeo<NF>::PIECES) ? n - 1 : n;
 }
 
-// 16 bytes through the scalar cache: the address must be wave-uniform.  The constant address space
-// makes hipcc emit s_load_dwordx4 (its own counter, lgkmcnt) instead of a vector load + readfirstlane.
-__device__ __forceinline__ uint4 scalar_load16(const uint4* p)
-{
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    typedef const u32x4 __attribute__((address_space(4))) * const_ptr;
-    const u32x4 v = *(const_ptr)(unsigned long long)p;
-    return make_uint4(v[0], v[1], v[2], v[3]);
-}
-
-__device__ __forceinline__ void group_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 // ABL (debug ablations, never used by the product path): 0 = the real kernel; 1 = no MFMAs and no
 // LDS reads (memory traffic only); 2 = every tile re-fetches tile 0 and stores to the sink (compute
 // only, memory traffic stays in L2); 4 = memory traffic and LDS fragment reads, no MFMAs
@@ -1834,16 +1757,6 @@ constexpr int T2_SLOTS = 4;                     // input halo-tile ring (A only:
 constexpr int T2_RING_ROWS = 12;                // intermediate ring: 3 blocks of 4 rows
 constexpr int T2_PAD_STEPS = T2_SLOTS;          // dummy entries behind a workgroup's last step (DMA look-ahead)
 
-struct Trunk2Step {                             // 32 bytes
-    // A half: x = input halo origin byte offset (low 32), y = offset bits 32..39 | row mask << 8 (bit r:
-    // intermediate row r of the block is inside the plane) | c_lo << 12 | c_hi << 18 (intermediate columns
-    // [c_lo, c_hi) of the block are inside the plane) | active << 24, z = row pitch in bytes
-    uint4 a;
-    // B half: x = output origin byte offset (low 32), y = offset bits 32..39 | valid rows << 8 |
-    // valid columns << 11 | active << 24, z = row pitch in bytes
-    uint4 b;
-};
-static_assert(sizeof(Trunk2Step) == 32, "Trunk2Step layout");
 
 struct Trunk2Args {
     const char* in_act;           // activation buffer INCLUDING its leading guard (offsets are from here)
@@ -1889,12 +1802,6 @@ __device__ __forceinline__ unsigned t2_piece_const(int i, int wave, int lane)
     if (pix >= (TH4 + 2) * PW) pix = (TH4 + 2) * PW - 1;      // tail of the last piece: any valid address
     const int r = pix / PW, cc = pix - r * PW;
     return (unsigned)((r << 13) | (cc * T2_PIXB + ((s ^ (cc & 7)) << 4)));
-}
-
-template <int KEEP>
-__device__ __forceinline__ void dma_barrier()
-{
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(KEEP) : "memory");
 }
 
 template <int NF>
@@ -2070,10 +1977,23 @@ __global__ __launch_bounds__(512, 2) void trunk2_kernel(Trunk2Args a)
                     for (int c = 0; c < (NARROW ? 1 : 2); ++c)
                         if (2 * st + c + PFF < NFRAG) bq[(2 * st + c + PFF) % RQ] = read_b(2 * st + c + PFF);
                     const int R = st & 3, ch = (st >> 2) & 1, dx = st >> 3;
+#if !defined(UVA_EXP_WINO) || UVA_EXP_WINO != 2
                     const half8 b0 = bq[(2 * st) % RQ], b1 = bq[(2 * st + 1) % RQ];
-#pragma unroll
+#endif
+#ifdef UVA_EXP_WINO
+                    // EXPERIMENT (wrong results): the k-loop of a Winograd F(2,3) kernel would issue 96 MFMAs for the same
+                    // 48 fragment reads -- drop the dy == 1 taps (every fragment stays in use); UVA_EXP_WINO == 2: plus four
+                    // packed fp16 adds per fragment (the input transform done at read time)
+#if UVA_EXP_WINO == 2
+                    const half8 b0x = bq[(2 * st) % RQ], b1x = bq[(2 * st + 1) % RQ];
+                    const half8 b0 = pk_sub(b0x, b1x), b1 = b1x + b0x;
+#endif
+#endif
                     for (int n = 0; n < 2; ++n) {
                         if (n == 0 ? R > 2 : R < 1) continue;       // output row n, tap (dy = R - n, dx)
+#ifdef UVA_EXP_WINO
+                        if (R - n == 1) continue;
+#endif
                         const bool first = st == n;
 #pragma unroll
                         for (int m = 0; m < 2; ++m) {
@@ -2088,7 +2008,14 @@ __global__ __launch_bounds__(512, 2) void trunk2_kernel(Trunk2Args a)
 #pragma unroll
                 for (int st = 0; st < NSTEP; ++st) {
                     const int R = st & 3;
+#ifdef UVA_EXP_WINO
+                    const bool light = true;
+#if UVA_EXP_WINO == 2
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+#endif
+#else
                     const bool light = R == 0 || R == 3;
+#endif
                     const bool rd = 2 * st + PFF < NFRAG;
                     constexpr int D = NARROW ? 2 : 1;
                     if (light) __builtin_amdgcn_sched_group_barrier(0x008, 2 / D, 0); else __builtin_amdgcn_sched_group_barrier(0x008, 4 / D, 0);

@@ -270,6 +270,25 @@ void pack_trunk64(const ConvWeights& c, std::vector<uint16_t>& out)
             }
 }
 
+void pack_trunk64_wino(const ConvWeights& c, std::vector<uint16_t>& out)
+{
+    out.assign((size_t)4 * 3 * 2 * 4 * 64 * 8, 0);
+    for (int j = 0; j < 4; ++j)
+        for (int dy = 0; dy < 3; ++dy)
+            for (int ch = 0; ch < 2; ++ch)
+                for (int mb = 0; mb < 4; ++mb)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int co = 16 * mb + (lane & 15);
+                        for (int e = 0; e < 8; ++e) {
+                            const int ci = 32 * ch + 8 * (lane >> 4) + e;
+                            const float* g = &c.w[((size_t)co * 64 + ci) * 9 + 3 * dy];
+                            const double g0 = g[0], g1 = g[1], g2 = g[2];
+                            const float u = j == 0 ? g[0] : j == 1 ? (float)(0.5 * (g0 + g1 + g2)) : j == 2 ? (float)(0.5 * (g0 - g1 + g2)) : g[2];
+                            out[((((((size_t)j * 3 + dy) * 2 + ch) * 4 + mb) * 64) + lane) * 8 + e] = f32_to_f16_bits(u);
+                        }
+                    }
+}
+
 void pack_tail64(const ConvWeights& c, std::vector<uint16_t>& out)
 {
     const int mb_n = (c.cout + 15) / 16;

@@ -43,6 +43,12 @@ void pack_conv3x3(const ConvWeights& c, int nf, std::vector<uint16_t>& out, int*
 // lanes][8] fp16, k-step = 2*tap + ch; lane = (octet << 4) | i supplies output channel 16*mb + i and
 // input channels 32*ch + 8*octet .. +7 of that tap.
 void pack_trunk64(const ConvWeights& c, std::vector<uint16_t>& out);
+// trunkw_kernel (csrc/uva_wino.hip.h): the same 64 -> 64 convolution as 1-D Winograd F(2,3) along x.  Image
+// [j 0..3][dy 0..2][ch 0..1][4 channel blocks][64 lanes][8] fp16 of the TRANSFORMED taps of row dy
+// (g0, g1, g2 = that row's three taps, taken at full precision; one rounding to fp16 at the end):
+//   U0 = g0   U1 = (g0 + g1 + g2) / 2   U2 = (g0 - g1 + g2) / 2   U3 = g2
+// lanes as in pack_trunk64.  The CPU checker (conv2d_wino_f23, test side) spells the same expressions.
+void pack_trunk64_wino(const ConvWeights& c, std::vector<uint16_t>& out);
 // tail_kernel<64, R> (v_mfma_f32_16x16x32_f16, cin = 64, cout = 3*R*R padded to a multiple of 16):
 // image [18 k-steps][MB = ceil(cout/16) blocks][64 lanes][8] fp16, lanes and k-steps as pack_trunk64.
 void pack_tail64(const ConvWeights& c, std::vector<uint16_t>& out);

@@ -1,0 +1,32 @@
+// uva_wino.h -- what the host side (uva_api.hip) needs of trunkw_kernel (csrc/uva_wino.hip.h; its own translation
+// unit, uva_wino.hip): the step-list constants, the argument block and the launcher.  No device code here.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace uva {
+
+struct Trunk2Step;                                // uva_devutil.hip.h (32 bytes; trunkw's meaning of the fields: uva_wino.hip.h)
+
+constexpr int TW_SW = 30;                         // output columns per strip
+constexpr int TW_PAD_STEPS = 2;                   // dummy entries behind a workgroup's last step (DMA look-ahead)
+
+struct TrunkwArgs {
+    const char* in_act;           // activation buffer INCLUDING its leading guard
+    char* out_act;
+    const void* wpk[2];           // pack_trunk64_wino images of layer i and i+1
+    const float* bias[2];
+    const float* slope[2];
+    const Trunk2Step* steps;      // [grid][max_steps + TW_PAD_STEPS]
+    const int* nsteps;            // [grid]
+    int max_steps;
+    _Float16* sink;
+    unsigned long long* dbg;      // instrumented builds (-DUVA_INSTRUMENT): s_memtime stamps of workgroup 0, wave 0 of each group:
+                                  // [16 * it + 8 * group + {0: iteration start, 1: phase X work done, 2: barrier 1 passed,
+                                  // 3: phase Y work done, 4: (A) the epilogue's ring writes done}], entry time at [16 * niter]
+};
+
+// One launch of trunkw_kernel<64> on `grid` workgroups.  Returns hipSuccess or the failing call's error.
+hipError_t launch_trunkw_kernel(hipStream_t stream, int grid, const TrunkwArgs& a);
+
+}  // namespace uva

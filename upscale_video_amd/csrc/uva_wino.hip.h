@@ -1,0 +1,451 @@
+// uva_wino.hip.h -- trunkw_kernel<64>: TWO consecutive 64 -> 64 trunk layers (each + bias + PReLU) per launch,
+// like trunk2_kernel, but every 3x3 convolution is evaluated as 1-D WINOGRAD F(2,3) ALONG x: four multiplications
+// for two output columns instead of six, i.e. 96 instead of 144 v_mfma_f32_16x16x32_f16 per wave and k-loop.
+// (reference graph: models/2x_Compact_Pretrain.param:7-37, models/4x_Compact_Pretrain.param:7-37 -- the sixteen
+// Convolution 64->64 3x3 pad 1 + PReLU layers; ncnn itself runs 3x3 stride-1 convolutions through Winograd
+// transforms, src/layer/vulkan/convolution_vulkan.cpp.)
+//
+// Why: trunk2_kernel runs at the package power limit, and the matrix pipes are most of that energy
+// (profiles/r04_ab_results.txt block 1: dropping a third of its MFMAs, same fragment reads, takes the launch from
+// 268 to 220 us on the same box; doing the input transform redundantly at fragment-read time gives half of that
+// back -- a v_pk_add_f16 costs about a tenth of an MFMA).  So the transform is done ONCE per value and the
+// transformed values live in LDS:
+//
+//   output columns come in PAIRS (xa, xa+1); with d0..d3 the input at columns xa-1..xa+2 and g0,g1,g2 a filter row:
+//     V0 = d0 - d2   V1 = d1 + d2   V2 = d2 - d1   V3 = d1 - d3                (fp16, one rounding each)
+//     U0 = g0   U1 = (g0+g1+g2)/2   U2 = (g0-g1+g2)/2   U3 = g2               (fp16, host: pack_trunk64_wino)
+//     Mj = sum over input channels and filter rows of Uj * Vj                   (MFMA, fp32 accumulate)
+//     out(xa) = M0 + M1 + M2,   out(xa+1) = M1 - M2 - M3                        (fp32, then bias, PReLU, fp16)
+//   The CPU checker restates exactly this, rounding points included (conv2d_wino_f23, mode UVO_WINOGRAD_F23; test side).
+//
+// Organisation (one persistent 8-wave workgroup per CU, walking DOWN a 30-column strip of a plane in 4-row steps):
+//   group A (waves 0-3) = layer i, group B (waves 4-7) = layer i+1, ping-pong as in trunk2_kernel: A's k-loop runs
+//   beside B's epilogue (HBM stores) in phase X, B's k-loop beside A's epilogue in phase Y.  A wave owns 16 OUTPUT
+//   CHANNELS (96 weight registers: 4 transformed taps x 3 rows x 64 input channels) and all 4 rows x 16 pairs of a
+//   step: 16 accumulators [row][j], 48 fragment reads and 96 MFMAs per k-loop, every fragment used by up to three
+//   filter rows.  Both k-loops read TRANSFORMED rows:
+//     A-ring (6 rows):  filled in phase Y from the 4 new RAW input rows of the next step (LDS-DMA by A's waves into a
+//                       2-slot staging area one and a half periods ahead; B's wave w transforms row w once its k-loop
+//                       is done -- A's epilogue is the longer half of that phase); the two rows a step shares with
+//                       the previous one stay where they are;
+//     B-ring (10 rows): A's epilogue turns its result pairs into V0..V3 with the neighbouring lane's pair
+//                       (v_mov_dpp row_shl:1) and writes them here; B is 1.5 steps behind.
+//   Pair p of a step's block: A computes intermediate columns x0-1+2p, x0+2p (16 pairs = 32 columns from the 34
+//   input columns x0-2 .. x0+31), B output columns x0+2p, x0+2p+1 (15 pairs from A's 32 columns).
+//   A segment (a run of steps down one strip) starts WITHOUT the two shared rows: the first block's first two
+//   intermediate rows are garbage and its consumer step is idle -- k steps yield 4(k-1) output rows (host:
+//   build_trunkw_schedule; the CPU test walks the lists and checks that every pixel is produced exactly once from
+//   valid rows).
+//
+// LDS (162 304 of 163 840 bytes):
+//   transformed rows: [j 0..3][channel half][pair][4 x 16 B], unit o of pair p in slot o ^ ((p >> 1) & 3):
+//     fragment reads (lane (o, p)) and the 16-byte writes (8 consecutive pairs) are bank-conflict free;
+//   raw rows: 34 pixel records of 128 B, column cc = 2h + par in record h + 17 par, octet in slot octet ^ (h & 7):
+//     the transform's reads of columns 2p + k are conflict free (tools/wino_swizzle_check.py).
+#pragma once
+#include <type_traits>
+
+#include "uva_devutil.hip.h"
+#include "uva_wino.h"
+
+namespace uva {
+
+constexpr int TW_AROWB = 4 * 2 * 16 * 64;         // 8192: one transformed row of the A-ring (16 pairs)
+constexpr int TW_BROWB = 4 * 2 * 15 * 64;         // 7680: one transformed row of the B-ring (15 pairs)
+constexpr int TW_AROWS = 6, TW_BROWS = 10;
+constexpr int TW_RAWROWB = 34 * 128;              // 4352
+constexpr int TW_RAWSLOTB = 4 * TW_RAWROWB;       // 17 408 = 17 LDS-DMA pieces
+constexpr int TW_RAW_PIECES = TW_RAWSLOTB / 1024;
+constexpr int TW_ARING = 0;
+constexpr int TW_BRING = TW_ARING + TW_AROWS * TW_AROWB;
+constexpr int TW_RAW = TW_BRING + TW_BROWS * TW_BROWB;
+constexpr int TW_PRM = TW_RAW + 2 * TW_RAWSLOTB;
+constexpr int TW_LDS_BYTES = TW_PRM + 2 * PARAM_LDS;
+static_assert(TW_RAW_PIECES == 17 && TW_RAWSLOTB % 1024 == 0, "raw slot = whole LDS-DMA pieces");
+static_assert(TW_LDS_BYTES <= 160 * 1024, "trunkw kernel LDS budget");
+static_assert(TW_RAW % 128 == 0 && TW_RAWROWB % 128 == 0, "raw pixel records are 128-byte aligned (the octet XOR flips address bits 4..6)");
+
+// Step g of a workgroup (host: build_trunkw_schedule).  Trunk2Step's 32 bytes, other meaning:
+//   a: x = byte offset (low 32) of input pixel (yA + 1, x0 - 2) -- the first of the step's four NEW input rows --
+//      from the activation buffer's base (guard included), y = offset bits 32..39 | row mask << 8 (bit n:
+//      intermediate row yA + n is inside the plane) | c_lo << 12 | c_hi << 18 (intermediate columns [c_lo, c_hi) of
+//      the 32 are inside the plane) | active << 24, z = row pitch in bytes
+//   b: x = byte offset (low 32) of output pixel (yA - 1, x0), y = offset bits 32..39 | valid rows << 8 (rows
+//      yA-1 .. yA-1+vy-1 are stored) | valid columns << 11 | active << 24, z = row pitch in bytes
+
+// LDS-DMA piece i of wave `wave`: piece c = 4i + wave covers units [64c, 64c + 64) of a raw slot; unit q is row
+// q / 272, record (q % 272) / 8, slot q % 8 -> (row << 13) | byte offset of that octet inside the source row
+__device__ __forceinline__ unsigned tw_piece_const(int i, int wave, int lane)
+{
+    const int q = (4 * i + wave) * 64 + lane;
+    const int r = q / 272, u = q - r * 272;
+    const int rec = u >> 3, sl = u & 7;
+    const int par = rec >= 17 ? 1 : 0, h = rec - 17 * par;
+    return (unsigned)((r << 13) | ((2 * h + par) * 128 + ((sl ^ (h & 7)) << 4)));
+}
+
+__device__ __forceinline__ unsigned dpp_row_shl1(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x101, 0xf, 0xf, true);    // lane p <- lane p + 1 of its row of 16 (lane 15: 0)
+}
+__device__ __forceinline__ unsigned pk_add_f16(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, (half2v)(__builtin_bit_cast(half2v, a) + __builtin_bit_cast(half2v, b)));
+}
+
+// wave priorities inside the k-loops / everywhere else (A/B builds override them)
+#ifndef TW_PRIO_K
+#define TW_PRIO_K 2
+#endif
+#ifndef TW_PRIO_E
+#define TW_PRIO_E 0
+#endif
+
+#ifdef UVA_INSTRUMENT
+#define TW_STAMP(k) do { if (stamp) a.dbg[16 * it + 8 * grp + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TW_STAMP(k) do { } while (0)
+#endif
+
+template <int NF>
+__global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
+{
+    static_assert(NF == 64, "written for 64 features");
+    constexpr int PIXB = 128;
+#ifndef TW_PFF
+#define TW_PFF 10
+#endif
+    constexpr int PFF = TW_PFF;                   // fragments read ahead of their MFMAs: an LDS read takes ~280 cycles to come back
+                                                  // while four waves stream fragments, and an MFMA 16 (profiles/r04_ab_results.txt)
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = lds_offset(smem);
+    float* const prm_all = (float*)(smem + TW_PRM);       // per layer: bias[64], slope[64], med3 selector[64]
+
+    const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave8 >> 2;   // 0: producer (layer i), 1: consumer (layer i+1)
+    const int wave = wave8 & 3;   // = the 16-channel block this wave computes
+    const int lane = threadIdx.x & 63;
+
+#ifdef UVA_INSTRUMENT
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
+    const int nsteps = __builtin_amdgcn_readfirstlane(a.nsteps[blockIdx.x]);
+    if (nsteps <= 0) return;
+#ifdef UVA_INSTRUMENT
+    const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && (threadIdx.x & 255) == 0;
+    if (stamp && grp == 0) a.dbg[16 * (nsteps + 2)] = t_entry;
+#endif
+    const Trunk2Step* const steps = a.steps + (size_t)blockIdx.x * (a.max_steps + TW_PAD_STEPS);
+    auto load_a = [&](int g) __attribute__((always_inline)) { return scalar_load16(&steps[g].a); };
+    auto load_b = [&](int g) __attribute__((always_inline)) { return scalar_load16(&steps[g].b); };
+
+    float prm_b = 0.f, prm_s = 0.f;
+    if (wave == 0) {
+        prm_b = (grp ? a.bias[1] : a.bias[0])[lane];
+        prm_s = (grp ? a.slope[1] : a.slope[0])[lane];
+    }
+    // this wave's 16 output channels of its layer's transformed weights, resident for the whole kernel
+    half8 w[24];                                  // [(j * 3 + dy) * 2 + ch]
+    {
+        const half8* wp = (const half8*)(grp ? a.wpk[1] : a.wpk[0]);
+#pragma unroll
+        for (int i = 0; i < 24; ++i) w[i] = wp[(i * 4 + wave) * 64 + lane];
+    }
+    // LDS-DMA source position of this lane in piece i (wave 0: five pieces, the others four), two per register
+    unsigned dma_pc2[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        dma_pc2[i] = tw_piece_const(2 * i, wave, lane) | (2 * i + 1 < 5 ? tw_piece_const(2 * i + 1, wave, lane) << 16 : 0u);
+    auto issue_rows = [&](const uint4 e, int slot) __attribute__((always_inline)) {
+        const unsigned lo = __builtin_amdgcn_readfirstlane(e.x), hi = __builtin_amdgcn_readfirstlane(e.y) & 0xffu;
+        const char* base = a.in_act + (((unsigned long long)hi << 32) | lo);
+        const int pitch = __builtin_amdgcn_readfirstlane(e.z);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            if (4 * i + wave >= TW_RAW_PIECES) continue;
+            const unsigned pc = (dma_pc2[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+            glds16_s(base, (pc >> 13) * (unsigned)pitch + (pc & 0x1fffu), lds0 + TW_RAW + slot * TW_RAWSLOTB + (4 * i + wave) * 1024);
+        }
+    };
+    if (wave == 0) {
+        float* prm = prm_all + grp * (PARAM_LDS / 4);
+        prm[lane] = prm_b;
+        prm[64 + lane] = prm_s;
+        prm[128 + lane] = prm_s <= 1.f ? __builtin_inff() : -__builtin_inff();
+    }
+
+    // lane part of a transformed-row address, fragment / transform view (pair pq = lane & 15, K octet oq = lane >> 4): pair
+    // record (64 B) + swizzled unit.  Recomputed from an opaque copy of the lane id where it is used: everything derived
+    // from the lane id is loop invariant, and hipcc would keep it all in registers across the k-loops (or spill it)
+    auto vlane_of = [](int l) __attribute__((always_inline)) { const int p_ = l & 15, o_ = l >> 4; return (unsigned)(p_ * 64 + ((o_ ^ ((p_ >> 1) & 3)) << 4)); };
+
+    // Raw rows -> transformed rows of the A-ring: wave w transforms the step's new row w.  Lane (oq, pq) handles octets
+    // oq and 4 + oq of pair pq: d0..d3 = columns 2pq .. 2pq+3 (records pq / pq+1, parity planes 17 records apart).
+    auto transform_rows = [&](int slot, int pos0) __attribute__((always_inline)) {
+        const int lane_o = opaque(lane);
+        const int pq = lane_o & 15, oq = lane_o >> 4;
+        const unsigned vlane = vlane_of(lane_o);
+        int pos = pos0 + wave;
+        pos = pos >= TW_AROWS ? pos - TW_AROWS : pos;
+        const char* const rrow = smem + TW_RAW + slot * TW_RAWSLOTB + wave * TW_RAWROWB;
+        const unsigned a_lo = (unsigned)(pq * PIXB + ((oq ^ (pq & 7)) << 4));
+        const unsigned a_hi = (unsigned)((pq + 1) * PIXB + ((oq ^ ((pq + 1) & 7)) << 4));
+        char* const vrow = smem + TW_ARING + pos * TW_AROWB + vlane;
+        half8 d[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {              // all eight reads first: one LDS round trip, not two
+            d[t][0] = *(const half8*)(rrow + (a_lo ^ (t ? 64u : 0u)));
+            d[t][1] = *(const half8*)(rrow + (a_lo ^ (t ? 64u : 0u)) + 17 * PIXB);
+            d[t][2] = *(const half8*)(rrow + (a_hi ^ (t ? 64u : 0u)));
+            d[t][3] = *(const half8*)(rrow + (a_hi ^ (t ? 64u : 0u)) + 17 * PIXB);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            *(half8*)(vrow + 0 * 2048 + t * 1024) = pk_sub(d[t][0], d[t][2]);
+            *(half8*)(vrow + 1 * 2048 + t * 1024) = d[t][1] + d[t][2];
+            *(half8*)(vrow + 2 * 2048 + t * 1024) = pk_sub(d[t][2], d[t][1]);
+            *(half8*)(vrow + 3 * 2048 + t * 1024) = pk_sub(d[t][1], d[t][3]);
+        }
+    };
+
+    // ---- prologue: weights, parameters; A: raw rows of steps 0 and 1, rows of step 0 transformed -----------------
+    if (grp == 0) {
+        issue_rows(load_a(0), 0);
+        issue_rows(load_a(1), 1);
+#pragma unroll
+        for (int i = 0; i < 24; ++i) asm volatile("" : "+v"(w[i]));
+        if (wave == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+    group_barrier();                   // every A wave's pieces of step 0 have landed (each waited for its own)
+    if (grp == 1) transform_rows(0, 2);       // (the consumer group fills the A-ring: see its loop)
+    group_barrier();
+
+    const float* const bias_lds = prm_all + grp * (PARAM_LDS / 4);
+    const float* const prm_lds = bias_lds + 64;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // this lane's four output channels' bias: the start value of the M1 accumulators (resident, like the weights)
+    const f32x4 bias4 = *(const f32x4*)(bias_lds + 16 * wave + 4 * (lane >> 4));
+    // ... and their PReLU slopes and med3 selectors (an LDS read in front of every epilogue is a ~280-cycle stall)
+    const f32x4 s4 = *(const f32x4*)(prm_lds + 16 * wave + 4 * (lane >> 4));
+    const f32x4 i4 = *(const f32x4*)(prm_lds + 64 + 16 * wave + 4 * (lane >> 4));
+
+    // one k-loop: 48 fragments f = (R * 2 + ch) * 4 + j of 6 transformed rows; fragment (R, j, ch) feeds output rows
+    // n = R - dy (dy = 0..2) of accumulator [n][j]
+    f32x4 acc[4][4];
+    auto kloop = [&](auto ring_tag, int base_pos) __attribute__((always_inline)) {
+        constexpr bool BR = decltype(ring_tag)::value;
+        constexpr int ROWB = BR ? TW_BROWB : TW_AROWB, NROWS = BR ? TW_BROWS : TW_AROWS;
+        constexpr int JS = ROWB / 4, CS = ROWB / 8;
+        constexpr int NFRAG = 48, RQ = PFF + 2;
+        unsigned radr[6];
+        const unsigned vlane = vlane_of(opaque(lane));
+#pragma unroll
+        for (int R = 0; R < 6; ++R) {
+            int pos = base_pos + R;
+            pos = pos >= NROWS ? pos - NROWS : pos;
+            radr[R] = vlane + (unsigned)((BR ? TW_BRING : TW_ARING) + pos * ROWB);
+        }
+        auto read_f = [&](int f) __attribute__((always_inline)) -> half8 {
+            const int R = f >> 3, ch = (f >> 2) & 1, j = f & 3;
+            return *(const half8*)(smem + radr[R] + j * JS + ch * CS);
+        };
+        half8 bq[RQ];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < PFF; ++f) bq[f] = read_f(f);
+#pragma unroll
+        for (int f = 0; f < NFRAG; ++f) {
+#ifdef TW_EXP_NOREAD       // EXPERIMENT (wrong results): only the first RQ fragments are read, the others reuse them
+            if (f + PFF < RQ) bq[(f + PFF) % RQ] = read_f(f + PFF);
+#else
+            if (f + PFF < NFRAG) bq[(f + PFF) % RQ] = read_f(f + PFF);
+#endif
+            const int R = f >> 3, ch = (f >> 2) & 1, j = f & 3;
+            const half8 b = bq[f % RQ];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int dy = R - n;
+                if (dy < 0 || dy > 2) continue;
+                const bool first = dy == 0 && ch == 0;
+                // M1 enters both results with a plus sign: its accumulator starts at the bias
+                acc[n][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[(j * 3 + dy) * 2 + ch], b, first ? (j == 1 ? bias4 : zero4) : acc[n][j], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, PFF, 0);
+#pragma unroll
+        for (int f = 0; f < NFRAG; ++f) {
+            const int R = f >> 3;
+#ifdef TW_EXP_NOREAD
+            if (f + PFF < RQ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#else
+            if (f + PFF < NFRAG) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#endif
+            if (R == 0 || R == 5) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            else if (R == 1 || R == 4) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            else __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // output transform + PReLU of one block row (the bias is already in M1): -> the pair's two pixels as packed fp16, 4
+    // channels each.  Written on float pairs: v_pk_add_f32 / v_pk_mul_f32.
+    struct Pix { unsigned x0, x1, y0, y1; };      // x: column 2p (channels 4cg.., 4cg+2..), y: column 2p + 1
+    f32x2 neg1 = {-1.f, -1.f};
+    asm volatile("" : "+v"(neg1));
+    auto finish_row = [&](int n, const f32x4& s4, const f32x4& i4) __attribute__((always_inline)) -> Pix {
+        Pix r;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const f32x2 m0 = {acc[n][0][2 * hh], acc[n][0][2 * hh + 1]}, m1 = {acc[n][1][2 * hh], acc[n][1][2 * hh + 1]};
+            const f32x2 m2 = {acc[n][2][2 * hh], acc[n][2][2 * hh + 1]}, m3 = {acc[n][3][2 * hh], acc[n][3][2 * hh + 1]};
+            const f32x2 sl = {s4[2 * hh], s4[2 * hh + 1]};
+            // differences as fma(x, -1, y): one rounding like y - x, and it stays a packed instruction (y - x on float pairs is
+            // scalarised into two v_sub_f32, and so is an fma with a visible -1: neg1 is opaque)
+            const f32x2 u = (m0 + m1) + m2;
+            const f32x2 v = __builtin_elementwise_fma(m3, neg1, __builtin_elementwise_fma(m2, neg1, m1));
+            const f32x2 us = u * sl, vs = v * sl;
+            const f32x2 pu = {__builtin_amdgcn_fmed3f(u[0], us[0], i4[2 * hh]), __builtin_amdgcn_fmed3f(u[1], us[1], i4[2 * hh + 1])};
+            const f32x2 pv = {__builtin_amdgcn_fmed3f(v[0], vs[0], i4[2 * hh]), __builtin_amdgcn_fmed3f(v[1], vs[1], i4[2 * hh + 1])};
+            const unsigned xu = __builtin_bit_cast(unsigned, __builtin_convertvector(pu, half2v));
+            const unsigned xv = __builtin_bit_cast(unsigned, __builtin_convertvector(pv, half2v));
+            if (hh == 0) { r.x0 = xu; r.y0 = xv; } else { r.x1 = xu; r.y1 = xv; }
+        }
+        return r;
+    };
+
+    // The two groups run DISJOINT loops (same number of barriers per iteration): with both roles in one loop body hipcc
+    // allocates the two k-loops' accumulators and fragment queues apart and spills the weights.
+    const int niter = nsteps + 2;
+    // an s_waitcnt hipcc's own bookkeeping can see: without it every k-loop opens with a vmcnt wait for "the weights",
+    // i.e. for the LDS-DMA pieces issued in front of it
+    __builtin_amdgcn_s_waitcnt(0x0f70);            // vmcnt(0)
+    if (grp == 0) {
+        // ---- group A: k-loop(it) in phase X, epilogue(it) + the raw rows of step it + 1 in phase Y -------------------
+        // entries fetched one iteration ahead through the scalar cache: e_own = masks of step it, e_dma = rows of step it + 2
+        uint4 e_own = load_a(0);
+        uint4 e_dma = load_a(2 <= nsteps + TW_PAD_STEPS - 1 ? 2 : nsteps + TW_PAD_STEPS - 1);
+        int a6 = 0;                    // (4 * it) mod 6: A-ring position of the step's first input row
+        int b10 = 0;                   // (4 * it) mod 10: B-ring position of the block written in iteration it
+        for (int it = 0; it < niter; ++it) {
+            TW_STAMP(0);
+            issue_rows(e_dma, it & 1);             // raw rows of step it + 2 (slot it & 1: transformed one phase ago)
+            if (it < nsteps) {
+                __builtin_amdgcn_s_setprio(TW_PRIO_K);
+                kloop(std::false_type{}, a6);
+                __builtin_amdgcn_s_setprio(TW_PRIO_E);
+            }
+            e_dma = load_a(it + 3 <= nsteps + TW_PAD_STEPS - 1 ? it + 3 : nsteps + TW_PAD_STEPS - 1);
+            // the rows of step it + 1 (issued one iteration ago) are complete once only this phase's pieces are outstanding
+            TW_STAMP(1);
+            if (wave == 0) dma_barrier<5>(); else dma_barrier<4>();
+            TW_STAMP(2);
+            if (it < nsteps) {
+                const int lane_o = opaque(lane);
+                const int cg = lane_o >> 4, p = lane_o & 15;
+                const unsigned ey = __builtin_amdgcn_readfirstlane(e_own.y);
+                const int rmask = (ey >> 8) & 15, c_lo = (ey >> 12) & 63, c_hi = (ey >> 18) & 63;
+                const bool in0 = 2 * p >= c_lo && 2 * p < c_hi, in1 = 2 * p + 1 >= c_lo && 2 * p + 1 < c_hi;
+                const bool edge = rmask != 15 || c_lo != 0 || c_hi != 32;
+                // lane (p, cg) writes units of channel octet 2 wave + (cg >> 1): even cg V0 and V1, odd cg V2 and V3
+                const int oo = 2 * (wave & 1) + (cg >> 1);
+                char* const wlane = smem + TW_BRING + (2 * (cg & 1)) * (TW_BROWB / 4) + (wave >> 1) * (TW_BROWB / 8) + p * 64 +
+                                    ((oo ^ ((p >> 1) & 3)) << 4);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    Pix q = finish_row(n, s4, i4);
+                    if (edge) {                    // (uniform: most steps lie inside their plane)
+                        const bool rin = (rmask >> n) & 1;
+                        if (!(rin && in0)) { q.x0 = 0; q.x1 = 0; }    // layer i+1's zero padding
+                        if (!(rin && in1)) { q.y0 = 0; q.y1 = 0; }
+                    }
+                    const unsigned nx0 = dpp_row_shl1(q.x0), nx1 = dpp_row_shl1(q.x1);     // the next pair's first column (d2)
+                    const unsigned ny0 = dpp_row_shl1(q.y0), ny1 = dpp_row_shl1(q.y1);     // ... and second column (d3)
+                    const unsigned v0a = pk_sub_f16(q.x0, nx0), v0b = pk_sub_f16(q.x1, nx1);      // d0 - d2
+                    const unsigned v1a = pk_add_f16(q.y0, nx0), v1b = pk_add_f16(q.y1, nx1);      // d1 + d2
+                    const unsigned v2a = pk_sub_f16(nx0, q.y0), v2b = pk_sub_f16(nx1, q.y1);      // d2 - d1
+                    const unsigned v3a = pk_sub_f16(q.y0, ny0), v3b = pk_sub_f16(q.y1, ny1);      // d1 - d3
+                    const auto s02a = __builtin_amdgcn_permlane16_swap(v0a, v2a, false, false);
+                    const auto s02b = __builtin_amdgcn_permlane16_swap(v0b, v2b, false, false);
+                    const auto s13a = __builtin_amdgcn_permlane16_swap(v1a, v3a, false, false);
+                    const auto s13b = __builtin_amdgcn_permlane16_swap(v1b, v3b, false, false);
+                    int pos = b10 + n;
+                    pos = pos >= TW_BROWS ? pos - TW_BROWS : pos;
+                    if (p < 15) {                  // the B-ring holds 15 pairs per plane
+                        *(uint4*)(wlane + pos * TW_BROWB) = make_uint4(s02a[0], s02b[0], s02a[1], s02b[1]);
+                        *(uint4*)(wlane + pos * TW_BROWB + TW_BROWB / 4) = make_uint4(s13a[0], s13b[0], s13a[1], s13b[1]);
+                    }
+                }
+            }
+            e_own = load_a(it + 1 < nsteps ? it + 1 : nsteps - 1);
+            TW_STAMP(3);
+            group_barrier();
+            a6 = a6 + 4 >= TW_AROWS ? a6 + 4 - TW_AROWS : a6 + 4;
+            b10 = b10 + 4 >= TW_BROWS ? b10 + 4 - TW_BROWS : b10 + 4;
+        }
+    } else {
+        // ---- group B: epilogue(it - 2) in phase X, k-loop(it - 1) in phase Y ------------------------------------------
+        uint4 e_own = make_uint4(0, 0, 0, 0);      // output of step it - 2
+        int a6 = 0, b10 = 0;
+        for (int it = 0; it < niter; ++it) {
+            TW_STAMP(0);
+            const unsigned ey = __builtin_amdgcn_readfirstlane(e_own.y);
+#ifdef TW_EXP_NOBEPI
+            if (false) {
+#else
+            if (it >= 2 && ((ey >> 24) & 1u)) {
+#endif
+                const int lane_o = opaque(lane);
+                const int cg = lane_o >> 4, p = lane_o & 15;
+                const unsigned lo = __builtin_amdgcn_readfirstlane(e_own.x);
+                const size_t off = ((unsigned long long)(ey & 0xffu) << 32) | lo;
+                const int pitch = __builtin_amdgcn_readfirstlane(e_own.z);
+                const int vy = (ey >> 8) & 7, vx = (ey >> 11) & 63;
+                const int col = 2 * p + (cg & 1);
+                // after the lane exchange lane (p, cg) holds 8 consecutive channels 16 wave + 8 (cg >> 1) .. of column col
+                char* const obase = a.out_act + off + (size_t)col * PIXB + 32 * wave + 16 * (cg >> 1);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const Pix q = finish_row(n, s4, i4);
+                    const auto x = __builtin_amdgcn_permlane16_swap(q.x0, q.y0, false, false);
+                    const auto y = __builtin_amdgcn_permlane16_swap(q.x1, q.y1, false, false);
+                    const uint4 val = make_uint4(x[0], y[0], x[1], y[1]);
+                    const bool ok = n < vy && col < vx;
+                    char* dst = ok ? obase + (size_t)n * pitch : (char*)a.sink + lane_o * PIXB;
+                    *(uint4*)dst = val;
+#ifndef TW_EXP_NOSB
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+                }
+            }
+            e_own = load_b(it >= 1 ? it - 1 : 0);                  // step (it + 1) - 2
+            const unsigned kact = (it >= 1 && it <= nsteps) ? (__builtin_amdgcn_readfirstlane(e_own.y) >> 24) & 1u : 0u;
+            TW_STAMP(1);
+            group_barrier();
+            TW_STAMP(2);
+            if (kact) {
+                __builtin_amdgcn_s_setprio(TW_PRIO_K);
+                int bp = b10 - 4 - 2;              // block it - 1 begins at (4 (it - 1)) mod 10; the window starts two rows above
+                bp = bp < 0 ? bp + TW_BROWS : bp;
+                kloop(std::true_type{}, bp);
+                __builtin_amdgcn_s_setprio(TW_PRIO_E);
+            }
+            TW_STAMP(4);
+            // the raw rows of step it + 1 (landed: the producers waited for them in front of barrier 1) -> A-ring, while the
+            // producers are still busy with their epilogue: this phase is theirs to lose
+            if (it + 1 < nsteps) {
+                int pos0 = a6 + 4 + 2;             // step it + 1's new rows follow its two shared ones
+                pos0 = pos0 >= TW_AROWS ? pos0 - TW_AROWS : pos0;
+                transform_rows((it + 1) & 1, pos0);
+            }
+            TW_STAMP(3);
+            group_barrier();
+            a6 = a6 + 4 >= TW_AROWS ? a6 + 4 - TW_AROWS : a6 + 4;
+            b10 = b10 + 4 >= TW_BROWS ? b10 + 4 - TW_BROWS : b10 + 4;
+        }
+    }
+    // nothing of the dummy look-ahead rows may land after the workgroup's LDS is released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+}  // namespace uva
