@@ -5,7 +5,7 @@ import csv, glob, json, os, statistics, sys
 
 out_dir, tag = sys.argv[1], sys.argv[2]
 KERNEL = sys.argv[3] if len(sys.argv) > 3 else "trunk2_kernel<64>"
-LAYERS = 2 if KERNEL.startswith("trunk2") else 1
+LAYERS = 2 if KERNEL.startswith(("trunk2", "trunkw")) else 1
 
 
 def per_launch(sub):

@@ -5,7 +5,25 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+#include <utility>
+
 namespace uva {
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{}).
+// Used where a loop body must see its index as a constant expression (if constexpr, builtin
+// immediates) and where '#pragma unroll' would give up on the pre-unrolling size of the body.
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));

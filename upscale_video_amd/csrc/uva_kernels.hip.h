@@ -52,20 +52,6 @@
 
 namespace uva {
 
-// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{}).
-// Used where a loop body must see its index as a constant expression (if constexpr, builtin
-// immediates) and where '#pragma unroll' would give up on the pre-unrolling size of the body.
-template <typename F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>)
-{
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f)
-{
-    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
-}
-
 constexpr int TH = 8;           // work-tile rows
 constexpr int TW = 32;          // work-tile columns (= one MFMA N fragment)
 constexpr int PH = TH + 2;      // halo tile rows

@@ -60,7 +60,7 @@ constexpr int TW_ARING = 0;
 constexpr int TW_BRING = TW_ARING + TW_AROWS * TW_AROWB;
 constexpr int TW_RAW = TW_BRING + TW_BROWS * TW_BROWB;
 constexpr int TW_PRM = TW_RAW + 2 * TW_RAWSLOTB;
-constexpr int TW_LDS_BYTES = TW_PRM + 2 * PARAM_LDS;
+constexpr int TW_LDS_BYTES = TW_PRM + 2 * PARAM_LDS + 64;       // + a spare unit per lane group (pair 15's writes)
 static_assert(TW_RAW_PIECES == 17 && TW_RAWSLOTB % 1024 == 0, "raw slot = whole LDS-DMA pieces");
 static_assert(TW_LDS_BYTES <= 160 * 1024, "trunkw kernel LDS budget");
 static_assert(TW_RAW % 128 == 0 && TW_RAWROWB % 128 == 0, "raw pixel records are 128-byte aligned (the octet XOR flips address bits 4..6)");
@@ -113,7 +113,10 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
     static_assert(NF == 64, "written for 64 features");
     constexpr int PIXB = 128;
 #ifndef TW_PFF
-#define TW_PFF 10
+#define TW_PFF 6
+#endif
+#ifndef TW_INROWS
+#define TW_INROWS 0           // rows of a block whose epilogue slices run inside the k-loop (A/B builds: 0..3)
 #endif
     constexpr int PFF = TW_PFF;                   // fragments read ahead of their MFMAs: an LDS read takes ~280 cycles to come back
                                                   // while four waves stream fragments, and an MFMA 16 (profiles/r04_ab_results.txt)
@@ -182,16 +185,17 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
 
     // Raw rows -> transformed rows of the A-ring: wave w transforms the step's new row w.  Lane (oq, pq) handles octets
     // oq and 4 + oq of pair pq: d0..d3 = columns 2pq .. 2pq+3 (records pq / pq+1, parity planes 17 records apart).
+    // per-lane constants of the whole kernel (a dozen registers that stay put; recomputing them per step costs more
+    // instructions than the kernel can afford: every instruction outside the MFMA stream counts)
+    const unsigned vlane_c = vlane_of(lane);
+    const unsigned t_lo = (unsigned)((lane & 15) * PIXB + (((lane >> 4) ^ (lane & 7)) << 4));
+    const unsigned t_hi = (unsigned)(((lane & 15) + 1) * PIXB + (((lane >> 4) ^ (((lane & 15) + 1) & 7)) << 4));
     auto transform_rows = [&](int slot, int pos0) __attribute__((always_inline)) {
-        const int lane_o = opaque(lane);
-        const int pq = lane_o & 15, oq = lane_o >> 4;
-        const unsigned vlane = vlane_of(lane_o);
         int pos = pos0 + wave;
         pos = pos >= TW_AROWS ? pos - TW_AROWS : pos;
         const char* const rrow = smem + TW_RAW + slot * TW_RAWSLOTB + wave * TW_RAWROWB;
-        const unsigned a_lo = (unsigned)(pq * PIXB + ((oq ^ (pq & 7)) << 4));
-        const unsigned a_hi = (unsigned)((pq + 1) * PIXB + ((oq ^ ((pq + 1) & 7)) << 4));
-        char* const vrow = smem + TW_ARING + pos * TW_AROWB + vlane;
+        const unsigned a_lo = t_lo, a_hi = t_hi;
+        char* const vrow = smem + TW_ARING + pos * TW_AROWB + vlane_c;
         half8 d[2][4];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {              // all eight reads first: one LDS round trip, not two
@@ -230,16 +234,22 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
     const f32x4 s4 = *(const f32x4*)(prm_lds + 16 * wave + 4 * (lane >> 4));
     const f32x4 i4 = *(const f32x4*)(prm_lds + 64 + 16 * wave + 4 * (lane >> 4));
 
-    // one k-loop: 48 fragments f = (R * 2 + ch) * 4 + j of 6 transformed rows; fragment (R, j, ch) feeds output rows
-    // n = R - dy (dy = 0..2) of accumulator [n][j]
+    // One k-loop: 48 fragments f = (R * 2 + ch) * 4 + j of 6 transformed rows; fragment (R, j, ch) feeds output rows
+    // n = R - dy (dy = 0..2) of accumulator [n][j].  Output row n is complete behind the fragments of window row n + 2; its
+    // epilogue is cut into EIGHT SLICES that follow the eight fragments of window row n + 3, in the wave's own instruction
+    // stream: slice(n, k), n = 0..2.  There an epilogue instruction costs its wave a few issue cycles; left to the other
+    // group's k-loop phase it would get through at a rate of ONE per MFMA of the wave it shares the SIMD with, and the
+    // rest would run after that k-loop with nothing beside it (profiles/r04_ab_results.txt).  Row 3 completes with the
+    // last MFMA: its slices are the caller's, in the next phase.  The order is pinned fragment by fragment
+    // (sched_barrier): the read PFF fragments ahead, this fragment's MFMAs, one slice.
     f32x4 acc[4][4];
-    auto kloop = [&](auto ring_tag, int base_pos) __attribute__((always_inline)) {
+    auto kloop = [&](auto ring_tag, int base_pos, auto&& slice) __attribute__((always_inline)) {
         constexpr bool BR = decltype(ring_tag)::value;
         constexpr int ROWB = BR ? TW_BROWB : TW_AROWB, NROWS = BR ? TW_BROWS : TW_AROWS;
         constexpr int JS = ROWB / 4, CS = ROWB / 8;
-        constexpr int NFRAG = 48, RQ = PFF + 2;
+        constexpr int NFRAG = 48, RQ = PFF + 1;
         unsigned radr[6];
-        const unsigned vlane = vlane_of(opaque(lane));
+        const unsigned vlane = vlane_c;
 #pragma unroll
         for (int R = 0; R < 6; ++R) {
             int pos = base_pos + R;
@@ -254,64 +264,50 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int f = 0; f < PFF; ++f) bq[f] = read_f(f);
-#pragma unroll
-        for (int f = 0; f < NFRAG; ++f) {
-#ifdef TW_EXP_NOREAD       // EXPERIMENT (wrong results): only the first RQ fragments are read, the others reuse them
-            if (f + PFF < RQ) bq[(f + PFF) % RQ] = read_f(f + PFF);
-#else
-            if (f + PFF < NFRAG) bq[(f + PFF) % RQ] = read_f(f + PFF);
-#endif
-            const int R = f >> 3, ch = (f >> 2) & 1, j = f & 3;
-            const half8 b = bq[f % RQ];
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const int dy = R - n;
-                if (dy < 0 || dy > 2) continue;
-                const bool first = dy == 0 && ch == 0;
-                // M1 enters both results with a plus sign: its accumulator starts at the bias
-                acc[n][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[(j * 3 + dy) * 2 + ch], b, first ? (j == 1 ? bias4 : zero4) : acc[n][j], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, PFF, 0);
-#pragma unroll
-        for (int f = 0; f < NFRAG; ++f) {
-            const int R = f >> 3;
-#ifdef TW_EXP_NOREAD
-            if (f + PFF < RQ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-#else
-            if (f + PFF < NFRAG) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-#endif
-            if (R == 0 || R == 5) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            else if (R == 1 || R == 4) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            else __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-        }
         __builtin_amdgcn_sched_barrier(0);
+        static_for<NFRAG>([&](auto fc) __attribute__((always_inline)) {
+            constexpr int f = decltype(fc)::value;
+            if constexpr (f + PFF < NFRAG) bq[(f + PFF) % RQ] = read_f(f + PFF);
+            constexpr int R = f >> 3, ch = (f >> 2) & 1, j = f & 3;
+            const half8 b = bq[f % RQ];
+            static_for<4>([&](auto nc) __attribute__((always_inline)) {
+                constexpr int n = decltype(nc)::value, dy = R - n;
+                if constexpr (dy >= 0 && dy <= 2) {
+                    constexpr bool first = dy == 0 && ch == 0;
+                    // M1 enters both results with a plus sign: its accumulator starts at the bias
+                    acc[n][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[(j * 3 + dy) * 2 + ch], b, first ? (j == 1 ? bias4 : zero4) : acc[n][j], 0, 0, 0);
+                }
+            });
+            if constexpr (R >= 3 && R - 3 < TW_INROWS) slice(std::integral_constant<int, R - 3>{}, std::integral_constant<int, (f & 7)>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
     };
 
-    // output transform + PReLU of one block row (the bias is already in M1): -> the pair's two pixels as packed fp16, 4
-    // channels each.  Written on float pairs: v_pk_add_f32 / v_pk_mul_f32.
-    struct Pix { unsigned x0, x1, y0, y1; };      // x: column 2p (channels 4cg.., 4cg+2..), y: column 2p + 1
+    // The slices 0..3 of a row's epilogue, the same for both groups: output transform and PReLU of one block row (the bias
+    // is already in M1) -> the pair's two pixels as packed fp16, 4 channels each.  On float pairs: v_pk_add_f32 / v_pk_mul_f32;
+    // differences as fma(x, -1, y): one rounding like y - x, and it stays a packed instruction (y - x on float pairs is
+    // scalarised into two v_sub_f32, and so is an fma with a visible -1: neg1 is opaque).
+    struct RowSt {
+        f32x2 u, v;
+        unsigned x0, x1, y0, y1;       // x: column 2p (channels 4cg.., 4cg+2..), y: column 2p + 1
+        unsigned t[4], q[8];
+    };
     f32x2 neg1 = {-1.f, -1.f};
     asm volatile("" : "+v"(neg1));
-    auto finish_row = [&](int n, const f32x4& s4, const f32x4& i4) __attribute__((always_inline)) -> Pix {
-        Pix r;
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const f32x2 m0 = {acc[n][0][2 * hh], acc[n][0][2 * hh + 1]}, m1 = {acc[n][1][2 * hh], acc[n][1][2 * hh + 1]};
-            const f32x2 m2 = {acc[n][2][2 * hh], acc[n][2][2 * hh + 1]}, m3 = {acc[n][3][2 * hh], acc[n][3][2 * hh + 1]};
-            const f32x2 sl = {s4[2 * hh], s4[2 * hh + 1]};
-            // differences as fma(x, -1, y): one rounding like y - x, and it stays a packed instruction (y - x on float pairs is
-            // scalarised into two v_sub_f32, and so is an fma with a visible -1: neg1 is opaque)
-            const f32x2 u = (m0 + m1) + m2;
-            const f32x2 v = __builtin_elementwise_fma(m3, neg1, __builtin_elementwise_fma(m2, neg1, m1));
-            const f32x2 us = u * sl, vs = v * sl;
-            const f32x2 pu = {__builtin_amdgcn_fmed3f(u[0], us[0], i4[2 * hh]), __builtin_amdgcn_fmed3f(u[1], us[1], i4[2 * hh + 1])};
-            const f32x2 pv = {__builtin_amdgcn_fmed3f(v[0], vs[0], i4[2 * hh]), __builtin_amdgcn_fmed3f(v[1], vs[1], i4[2 * hh + 1])};
-            const unsigned xu = __builtin_bit_cast(unsigned, __builtin_convertvector(pu, half2v));
-            const unsigned xv = __builtin_bit_cast(unsigned, __builtin_convertvector(pv, half2v));
-            if (hh == 0) { r.x0 = xu; r.y0 = xv; } else { r.x1 = xu; r.y1 = xv; }
-        }
-        return r;
+    auto fin_sum = [&](RowSt& st, int n, int hh) __attribute__((always_inline)) {
+        const f32x2 m0 = {acc[n][0][2 * hh], acc[n][0][2 * hh + 1]}, m1 = {acc[n][1][2 * hh], acc[n][1][2 * hh + 1]};
+        const f32x2 m2 = {acc[n][2][2 * hh], acc[n][2][2 * hh + 1]}, m3 = {acc[n][3][2 * hh], acc[n][3][2 * hh + 1]};
+        st.u = (m0 + m1) + m2;
+        st.v = __builtin_elementwise_fma(m3, neg1, __builtin_elementwise_fma(m2, neg1, m1));
+    };
+    auto fin_act = [&](RowSt& st, int hh) __attribute__((always_inline)) {
+        const f32x2 sl = {s4[2 * hh], s4[2 * hh + 1]};
+        const f32x2 us = st.u * sl, vs = st.v * sl;
+        const f32x2 pu = {__builtin_amdgcn_fmed3f(st.u[0], us[0], i4[2 * hh]), __builtin_amdgcn_fmed3f(st.u[1], us[1], i4[2 * hh + 1])};
+        const f32x2 pv = {__builtin_amdgcn_fmed3f(st.v[0], vs[0], i4[2 * hh]), __builtin_amdgcn_fmed3f(st.v[1], vs[1], i4[2 * hh + 1])};
+        const unsigned xu = __builtin_bit_cast(unsigned, __builtin_convertvector(pu, half2v));
+        const unsigned xv = __builtin_bit_cast(unsigned, __builtin_convertvector(pv, half2v));
+        if (hh == 0) { st.x0 = xu; st.y0 = xv; } else { st.x1 = xu; st.y1 = xv; }
     };
 
     // The two groups run DISJOINT loops (same number of barriers per iteration): with both roles in one loop body hipcc
@@ -320,19 +316,74 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
     // an s_waitcnt hipcc's own bookkeeping can see: without it every k-loop opens with a vmcnt wait for "the weights",
     // i.e. for the LDS-DMA pieces issued in front of it
     __builtin_amdgcn_s_waitcnt(0x0f70);            // vmcnt(0)
+    RowSt st;
     if (grp == 0) {
-        // ---- group A: k-loop(it) in phase X, epilogue(it) + the raw rows of step it + 1 in phase Y -------------------
+        // ---- group A: k-loop(it) with the epilogue of its rows 0..2 in phase X, row 3 in phase Y ----------------------
         // entries fetched one iteration ahead through the scalar cache: e_own = masks of step it, e_dma = rows of step it + 2
         uint4 e_own = load_a(0);
         uint4 e_dma = load_a(2 <= nsteps + TW_PAD_STEPS - 1 ? 2 : nsteps + TW_PAD_STEPS - 1);
         int a6 = 0;                    // (4 * it) mod 6: A-ring position of the step's first input row
         int b10 = 0;                   // (4 * it) mod 10: B-ring position of the block written in iteration it
+        // lane (p, cg) writes units of channel octet 2 wave + (cg >> 1): even cg V0 and V1, odd cg V2 and V3; the lanes of
+        // pair 15 (the B-ring holds 15 pairs per plane) write to a spare unit behind the parameters instead: no exec mask
+        const int cg = lane >> 4, p = lane & 15;
+        const int oo = 2 * (wave & 1) + (cg >> 1);
+        const unsigned wlane = p < 15 ? (unsigned)(TW_BRING + (2 * (cg & 1)) * (TW_BROWB / 4) + (wave >> 1) * (TW_BROWB / 8) + p * 64 +
+                                                    ((oo ^ ((p >> 1) & 3)) << 4))
+                                      : (unsigned)(TW_LDS_BYTES - 64 + 16 * cg);
+        const unsigned wrow = p < 15 ? (unsigned)TW_BROWB : 0u;      // (pair 15: every row and both units to the same spare place)
+        const unsigned wj = p < 15 ? (unsigned)(TW_BROWB / 4) : 0u;
         for (int it = 0; it < niter; ++it) {
             TW_STAMP(0);
             issue_rows(e_dma, it & 1);             // raw rows of step it + 2 (slot it & 1: transformed one phase ago)
+            // what the epilogue of step it needs: the masks of a step at its plane's edge
+            const unsigned ey = __builtin_amdgcn_readfirstlane(e_own.y);
+            const int rmask = (ey >> 8) & 15, c_lo = (ey >> 12) & 63, c_hi = (ey >> 18) & 63;
+            const bool in0 = 2 * p >= c_lo && 2 * p < c_hi, in1 = 2 * p + 1 >= c_lo && 2 * p + 1 < c_hi;
+            const bool edge = rmask != 15 || c_lo != 0 || c_hi != 32;
+            auto slice = [&](auto edge_tag, auto nc, auto kc) __attribute__((always_inline)) {
+                constexpr int n = decltype(nc)::value, k = decltype(kc)::value;
+                if constexpr (k == 0) fin_sum(st, n, 0);
+                else if constexpr (k == 1) fin_act(st, 0);
+                else if constexpr (k == 2) fin_sum(st, n, 1);
+                else if constexpr (k == 3) fin_act(st, 1);
+                else if constexpr (k == 4) {
+                    if constexpr (decltype(edge_tag)::value) {            // layer i+1's zero padding
+                        const bool rin = (rmask >> n) & 1;
+                        const unsigned k0 = (rin && in0) ? 0xffffffffu : 0u, k1 = (rin && in1) ? 0xffffffffu : 0u;
+                        st.x0 &= k0; st.x1 &= k0;
+                        st.y0 &= k1; st.y1 &= k1;
+                    }
+                    st.t[0] = dpp_row_shl1(st.x0); st.t[1] = dpp_row_shl1(st.x1);       // the next pair's first column (d2)
+                    st.t[2] = dpp_row_shl1(st.y0); st.t[3] = dpp_row_shl1(st.y1);       // ... and second column (d3)
+                } else if constexpr (k == 5) {
+                    st.q[0] = pk_sub_f16(st.x0, st.t[0]); st.q[1] = pk_sub_f16(st.x1, st.t[1]);      // V0 = d0 - d2
+                    st.q[2] = pk_add_f16(st.y0, st.t[0]); st.q[3] = pk_add_f16(st.y1, st.t[1]);      // V1 = d1 + d2
+                    st.q[4] = pk_sub_f16(st.t[0], st.y0); st.q[5] = pk_sub_f16(st.t[1], st.y1);      // V2 = d2 - d1
+                    st.q[6] = pk_sub_f16(st.y0, st.t[2]); st.q[7] = pk_sub_f16(st.y1, st.t[3]);      // V3 = d1 - d3
+                } else if constexpr (k == 6) {
+                    const auto s02a = __builtin_amdgcn_permlane16_swap(st.q[0], st.q[4], false, false);
+                    const auto s02b = __builtin_amdgcn_permlane16_swap(st.q[1], st.q[5], false, false);
+                    const auto s13a = __builtin_amdgcn_permlane16_swap(st.q[2], st.q[6], false, false);
+                    const auto s13b = __builtin_amdgcn_permlane16_swap(st.q[3], st.q[7], false, false);
+                    st.q[0] = s02a[0]; st.q[1] = s02b[0]; st.q[2] = s02a[1]; st.q[3] = s02b[1];
+                    st.q[4] = s13a[0]; st.q[5] = s13b[0]; st.q[6] = s13a[1]; st.q[7] = s13b[1];
+                } else {
+                    int pos = b10 + n;
+                    pos = pos >= TW_BROWS ? pos - TW_BROWS : pos;
+                    char* const w0 = smem + wlane + (unsigned)pos * wrow;
+                    *(uint4*)w0 = make_uint4(st.q[0], st.q[1], st.q[2], st.q[3]);
+                    *(uint4*)(w0 + wj) = make_uint4(st.q[4], st.q[5], st.q[6], st.q[7]);
+                }
+            };
             if (it < nsteps) {
                 __builtin_amdgcn_s_setprio(TW_PRIO_K);
-                kloop(std::false_type{}, a6);
+                // steps that touch their plane's edge (uniform, few) mask what lies outside
+#if TW_INROWS > 0
+                if (edge) kloop(std::false_type{}, a6, [&](auto nc, auto kc) __attribute__((always_inline)) { slice(std::true_type{}, nc, kc); });
+                else
+#endif
+                kloop(std::false_type{}, a6, [&](auto nc, auto kc) __attribute__((always_inline)) { slice(std::false_type{}, nc, kc); });
                 __builtin_amdgcn_s_setprio(TW_PRIO_E);
             }
             e_dma = load_a(it + 3 <= nsteps + TW_PAD_STEPS - 1 ? it + 3 : nsteps + TW_PAD_STEPS - 1);
@@ -340,42 +391,13 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
             TW_STAMP(1);
             if (wave == 0) dma_barrier<5>(); else dma_barrier<4>();
             TW_STAMP(2);
-            if (it < nsteps) {
-                const int lane_o = opaque(lane);
-                const int cg = lane_o >> 4, p = lane_o & 15;
-                const unsigned ey = __builtin_amdgcn_readfirstlane(e_own.y);
-                const int rmask = (ey >> 8) & 15, c_lo = (ey >> 12) & 63, c_hi = (ey >> 18) & 63;
-                const bool in0 = 2 * p >= c_lo && 2 * p < c_hi, in1 = 2 * p + 1 >= c_lo && 2 * p + 1 < c_hi;
-                const bool edge = rmask != 15 || c_lo != 0 || c_hi != 32;
-                // lane (p, cg) writes units of channel octet 2 wave + (cg >> 1): even cg V0 and V1, odd cg V2 and V3
-                const int oo = 2 * (wave & 1) + (cg >> 1);
-                char* const wlane = smem + TW_BRING + (2 * (cg & 1)) * (TW_BROWB / 4) + (wave >> 1) * (TW_BROWB / 8) + p * 64 +
-                                    ((oo ^ ((p >> 1) & 3)) << 4);
-#pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    Pix q = finish_row(n, s4, i4);
-                    if (edge) {                    // (uniform: most steps lie inside their plane)
-                        const bool rin = (rmask >> n) & 1;
-                        if (!(rin && in0)) { q.x0 = 0; q.x1 = 0; }    // layer i+1's zero padding
-                        if (!(rin && in1)) { q.y0 = 0; q.y1 = 0; }
-                    }
-                    const unsigned nx0 = dpp_row_shl1(q.x0), nx1 = dpp_row_shl1(q.x1);     // the next pair's first column (d2)
-                    const unsigned ny0 = dpp_row_shl1(q.y0), ny1 = dpp_row_shl1(q.y1);     // ... and second column (d3)
-                    const unsigned v0a = pk_sub_f16(q.x0, nx0), v0b = pk_sub_f16(q.x1, nx1);      // d0 - d2
-                    const unsigned v1a = pk_add_f16(q.y0, nx0), v1b = pk_add_f16(q.y1, nx1);      // d1 + d2
-                    const unsigned v2a = pk_sub_f16(nx0, q.y0), v2b = pk_sub_f16(nx1, q.y1);      // d2 - d1
-                    const unsigned v3a = pk_sub_f16(q.y0, ny0), v3b = pk_sub_f16(q.y1, ny1);      // d1 - d3
-                    const auto s02a = __builtin_amdgcn_permlane16_swap(v0a, v2a, false, false);
-                    const auto s02b = __builtin_amdgcn_permlane16_swap(v0b, v2b, false, false);
-                    const auto s13a = __builtin_amdgcn_permlane16_swap(v1a, v3a, false, false);
-                    const auto s13b = __builtin_amdgcn_permlane16_swap(v1b, v3b, false, false);
-                    int pos = b10 + n;
-                    pos = pos >= TW_BROWS ? pos - TW_BROWS : pos;
-                    if (p < 15) {                  // the B-ring holds 15 pairs per plane
-                        *(uint4*)(wlane + pos * TW_BROWB) = make_uint4(s02a[0], s02b[0], s02a[1], s02b[1]);
-                        *(uint4*)(wlane + pos * TW_BROWB + TW_BROWB / 4) = make_uint4(s13a[0], s13b[0], s13a[1], s13b[1]);
-                    }
-                }
+            if (it < nsteps) {                     // the last row: beside the consumers' k-loop
+                auto rest = [&](auto edge_tag) __attribute__((always_inline)) {
+                    static_for<4 - TW_INROWS>([&](auto rc) __attribute__((always_inline)) {
+                        static_for<8>([&](auto kc) __attribute__((always_inline)) { slice(edge_tag, std::integral_constant<int, TW_INROWS + decltype(rc)::value>{}, kc); });
+                    });
+                };
+                if (edge) rest(std::true_type{}); else rest(std::false_type{});     // (uniform: most steps lie inside their plane)
             }
             e_own = load_a(it + 1 < nsteps ? it + 1 : nsteps - 1);
             TW_STAMP(3);
@@ -384,42 +406,48 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
             b10 = b10 + 4 >= TW_BROWS ? b10 + 4 - TW_BROWS : b10 + 4;
         }
     } else {
-        // ---- group B: epilogue(it - 2) in phase X, k-loop(it - 1) in phase Y ------------------------------------------
-        uint4 e_own = make_uint4(0, 0, 0, 0);      // output of step it - 2
+        // ---- group B: step s: k-loop in iteration s + 1 (phase Y), its rows 0..2 stored from inside that k-loop, row 3 in
+        // phase X of iteration s + 2.  e_k = the entry of the step whose k-loop runs in this iteration, e_3 = of the one before.
         int a6 = 0, b10 = 0;
+        uint4 e_k = make_uint4(0, 0, 0, 0), e_3 = make_uint4(0, 0, 0, 0);
+        const int cg = lane >> 4, p = lane & 15;
+        const int col = 2 * p + (cg & 1);
+        // after the lane exchange lane (p, cg) holds 8 consecutive channels 16 wave + 8 (cg >> 1) .. of column col
+        const unsigned olane = (unsigned)(col * PIXB + 32 * wave + 16 * (cg >> 1));
+        char* const sink = (char*)a.sink + lane * PIXB;
+        auto make_slice = [&](const uint4 e) __attribute__((always_inline)) {
+            const unsigned ey = __builtin_amdgcn_readfirstlane(e.y), lo = __builtin_amdgcn_readfirstlane(e.x);
+            const size_t off = ((unsigned long long)(ey & 0xffu) << 32) | lo;
+            const int pitch = __builtin_amdgcn_readfirstlane(e.z);
+            const int vy = (ey >> 8) & 7, vx = (ey >> 11) & 63;
+            char* const obase = a.out_act + off + olane;
+            const bool colok = col < vx;
+            return [&, obase, pitch, vy, colok](auto nc, auto kc) __attribute__((always_inline)) {
+                constexpr int n = decltype(nc)::value, k = decltype(kc)::value;
+                if constexpr (k == 0) fin_sum(st, n, 0);
+                else if constexpr (k == 1) fin_act(st, 0);
+                else if constexpr (k == 2) fin_sum(st, n, 1);
+                else if constexpr (k == 3) fin_act(st, 1);
+                else if constexpr (k == 4) {
+                    const auto x = __builtin_amdgcn_permlane16_swap(st.x0, st.y0, false, false);
+                    const auto y = __builtin_amdgcn_permlane16_swap(st.x1, st.y1, false, false);
+                    st.q[0] = x[0]; st.q[1] = y[0]; st.q[2] = x[1]; st.q[3] = y[1];
+                } else if constexpr (k == 5) {
+                    char* dst = (n < vy && colok) ? obase + (size_t)n * pitch : sink;
+                    *(uint4*)dst = make_uint4(st.q[0], st.q[1], st.q[2], st.q[3]);
+                }
+            };
+        };
         for (int it = 0; it < niter; ++it) {
             TW_STAMP(0);
-            const unsigned ey = __builtin_amdgcn_readfirstlane(e_own.y);
-#ifdef TW_EXP_NOBEPI
-            if (false) {
-#else
-            if (it >= 2 && ((ey >> 24) & 1u)) {
-#endif
-                const int lane_o = opaque(lane);
-                const int cg = lane_o >> 4, p = lane_o & 15;
-                const unsigned lo = __builtin_amdgcn_readfirstlane(e_own.x);
-                const size_t off = ((unsigned long long)(ey & 0xffu) << 32) | lo;
-                const int pitch = __builtin_amdgcn_readfirstlane(e_own.z);
-                const int vy = (ey >> 8) & 7, vx = (ey >> 11) & 63;
-                const int col = 2 * p + (cg & 1);
-                // after the lane exchange lane (p, cg) holds 8 consecutive channels 16 wave + 8 (cg >> 1) .. of column col
-                char* const obase = a.out_act + off + (size_t)col * PIXB + 32 * wave + 16 * (cg >> 1);
-#pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    const Pix q = finish_row(n, s4, i4);
-                    const auto x = __builtin_amdgcn_permlane16_swap(q.x0, q.y0, false, false);
-                    const auto y = __builtin_amdgcn_permlane16_swap(q.x1, q.y1, false, false);
-                    const uint4 val = make_uint4(x[0], y[0], x[1], y[1]);
-                    const bool ok = n < vy && col < vx;
-                    char* dst = ok ? obase + (size_t)n * pitch : (char*)a.sink + lane_o * PIXB;
-                    *(uint4*)dst = val;
-#ifndef TW_EXP_NOSB
-                    __builtin_amdgcn_sched_barrier(0);
-#endif
-                }
+            if (it >= 2 && ((__builtin_amdgcn_readfirstlane(e_3.y) >> 24) & 1u)) {      // row 3 of step it - 2
+                auto sl3 = make_slice(e_3);
+                static_for<4 - TW_INROWS>([&](auto rc) __attribute__((always_inline)) {
+                    static_for<6>([&](auto kc) __attribute__((always_inline)) { sl3(std::integral_constant<int, TW_INROWS + decltype(rc)::value>{}, kc); });
+                });
             }
-            e_own = load_b(it >= 1 ? it - 1 : 0);                  // step (it + 1) - 2
-            const unsigned kact = (it >= 1 && it <= nsteps) ? (__builtin_amdgcn_readfirstlane(e_own.y) >> 24) & 1u : 0u;
+            e_k = load_b(it >= 1 ? it - 1 : 0);
+            const unsigned kact = (it >= 1 && it <= nsteps) ? (__builtin_amdgcn_readfirstlane(e_k.y) >> 24) & 1u : 0u;
             TW_STAMP(1);
             group_barrier();
             TW_STAMP(2);
@@ -427,12 +455,12 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
                 __builtin_amdgcn_s_setprio(TW_PRIO_K);
                 int bp = b10 - 4 - 2;              // block it - 1 begins at (4 (it - 1)) mod 10; the window starts two rows above
                 bp = bp < 0 ? bp + TW_BROWS : bp;
-                kloop(std::true_type{}, bp);
+                kloop(std::true_type{}, bp, make_slice(e_k));
                 __builtin_amdgcn_s_setprio(TW_PRIO_E);
             }
+            e_3 = e_k;
             TW_STAMP(4);
-            // the raw rows of step it + 1 (landed: the producers waited for them in front of barrier 1) -> A-ring, while the
-            // producers are still busy with their epilogue: this phase is theirs to lose
+            // the raw rows of step it + 1 (landed: the producers waited for them in front of barrier 1) -> A-ring
             if (it + 1 < nsteps) {
                 int pos0 = a6 + 4 + 2;             // step it + 1's new rows follow its two shared ones
                 pos0 = pos0 >= TW_AROWS ? pos0 - TW_AROWS : pos0;
