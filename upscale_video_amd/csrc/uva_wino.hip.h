@@ -316,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
     // an s_waitcnt hipcc's own bookkeeping can see: without it every k-loop opens with a vmcnt wait for "the weights",
     // i.e. for the LDS-DMA pieces issued in front of it
     __builtin_amdgcn_s_waitcnt(0x0f70);            // vmcnt(0)
-    RowSt st;
+    RowSt st2[2];
     if (grp == 0) {
         // ---- group A: k-loop(it) with the epilogue of its rows 0..2 in phase X, row 3 in phase Y ----------------------
         // entries fetched one iteration ahead through the scalar cache: e_own = masks of step it, e_dma = rows of step it + 2
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
             const int rmask = (ey >> 8) & 15, c_lo = (ey >> 12) & 63, c_hi = (ey >> 18) & 63;
             const bool in0 = 2 * p >= c_lo && 2 * p < c_hi, in1 = 2 * p + 1 >= c_lo && 2 * p + 1 < c_hi;
             const bool edge = rmask != 15 || c_lo != 0 || c_hi != 32;
-            auto slice = [&](auto edge_tag, auto nc, auto kc) __attribute__((always_inline)) {
+            auto slice = [&](RowSt& st, auto edge_tag, auto nc, auto kc) __attribute__((always_inline)) {
                 constexpr int n = decltype(nc)::value, k = decltype(kc)::value;
                 if constexpr (k == 0) fin_sum(st, n, 0);
                 else if constexpr (k == 1) fin_act(st, 0);
@@ -380,10 +380,10 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
                 __builtin_amdgcn_s_setprio(TW_PRIO_K);
                 // steps that touch their plane's edge (uniform, few) mask what lies outside
 #if TW_INROWS > 0
-                if (edge) kloop(std::false_type{}, a6, [&](auto nc, auto kc) __attribute__((always_inline)) { slice(std::true_type{}, nc, kc); });
+                if (edge) kloop(std::false_type{}, a6, [&](auto nc, auto kc) __attribute__((always_inline)) { slice(st2[0], std::true_type{}, nc, kc); });
                 else
 #endif
-                kloop(std::false_type{}, a6, [&](auto nc, auto kc) __attribute__((always_inline)) { slice(std::false_type{}, nc, kc); });
+                kloop(std::false_type{}, a6, [&](auto nc, auto kc) __attribute__((always_inline)) { slice(st2[0], std::false_type{}, nc, kc); });
                 __builtin_amdgcn_s_setprio(TW_PRIO_E);
             }
             e_dma = load_a(it + 3 <= nsteps + TW_PAD_STEPS - 1 ? it + 3 : nsteps + TW_PAD_STEPS - 1);
@@ -392,9 +392,17 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
             if (wave == 0) dma_barrier<5>(); else dma_barrier<4>();
             TW_STAMP(2);
             if (it < nsteps) {                     // the last row: beside the consumers' k-loop
+                // two rows at a time, slice by slice: neighbouring instructions are independent of each other
                 auto rest = [&](auto edge_tag) __attribute__((always_inline)) {
-                    static_for<4 - TW_INROWS>([&](auto rc) __attribute__((always_inline)) {
-                        static_for<8>([&](auto kc) __attribute__((always_inline)) { slice(edge_tag, std::integral_constant<int, TW_INROWS + decltype(rc)::value>{}, kc); });
+                    static_assert(TW_INROWS == 0 || TW_INROWS == 2, "rows are finished in pairs");
+                    static_for<(4 - TW_INROWS) / 2>([&](auto rc) __attribute__((always_inline)) {
+                        static_for<8>([&](auto kc) __attribute__((always_inline)) {
+                            slice(st2[0], edge_tag, std::integral_constant<int, TW_INROWS + 2 * decltype(rc)::value>{}, kc);
+                            slice(st2[1], edge_tag, std::integral_constant<int, TW_INROWS + 2 * decltype(rc)::value + 1>{}, kc);
+#ifdef TW_EPI_FENCE
+                            __builtin_amdgcn_sched_barrier(0);
+#endif
+                        });
                     });
                 };
                 if (edge) rest(std::true_type{}); else rest(std::false_type{});     // (uniform: most steps lie inside their plane)
@@ -422,7 +430,7 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
             const int vy = (ey >> 8) & 7, vx = (ey >> 11) & 63;
             char* const obase = a.out_act + off + olane;
             const bool colok = col < vx;
-            return [&, obase, pitch, vy, colok](auto nc, auto kc) __attribute__((always_inline)) {
+            return [&, obase, pitch, vy, colok](RowSt& st, auto nc, auto kc) __attribute__((always_inline)) {
                 constexpr int n = decltype(nc)::value, k = decltype(kc)::value;
                 if constexpr (k == 0) fin_sum(st, n, 0);
                 else if constexpr (k == 1) fin_act(st, 0);
@@ -442,8 +450,14 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
             TW_STAMP(0);
             if (it >= 2 && ((__builtin_amdgcn_readfirstlane(e_3.y) >> 24) & 1u)) {      // row 3 of step it - 2
                 auto sl3 = make_slice(e_3);
-                static_for<4 - TW_INROWS>([&](auto rc) __attribute__((always_inline)) {
-                    static_for<6>([&](auto kc) __attribute__((always_inline)) { sl3(std::integral_constant<int, TW_INROWS + decltype(rc)::value>{}, kc); });
+                static_for<(4 - TW_INROWS) / 2>([&](auto rc) __attribute__((always_inline)) {
+                    static_for<6>([&](auto kc) __attribute__((always_inline)) {
+                        sl3(st2[0], std::integral_constant<int, TW_INROWS + 2 * decltype(rc)::value>{}, kc);
+                        sl3(st2[1], std::integral_constant<int, TW_INROWS + 2 * decltype(rc)::value + 1>{}, kc);
+#ifdef TW_EPI_FENCE
+                        __builtin_amdgcn_sched_barrier(0);
+#endif
+                    });
                 });
             }
             e_k = load_b(it >= 1 ? it - 1 : 0);
@@ -455,7 +469,8 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
                 __builtin_amdgcn_s_setprio(TW_PRIO_K);
                 int bp = b10 - 4 - 2;              // block it - 1 begins at (4 (it - 1)) mod 10; the window starts two rows above
                 bp = bp < 0 ? bp + TW_BROWS : bp;
-                kloop(std::true_type{}, bp, make_slice(e_k));
+                auto slk = make_slice(e_k);
+                kloop(std::true_type{}, bp, [&](auto nc, auto kc) __attribute__((always_inline)) { slk(st2[0], nc, kc); });
                 __builtin_amdgcn_s_setprio(TW_PRIO_E);
             }
             e_3 = e_k;
