@@ -104,8 +104,19 @@ def cpu_baseline(model_key, h, w, tile, min_seconds=10.0):
         frac = (sh * sw) / float(h * w)
         if dt >= min_seconds or dt * 4 > 40:
             break
+    # the same oracle on ONE core, on a crop that takes a few seconds (SURVEY.md 8d asks for both figures)
+    sh1, sw1 = max(8, h // 8), max(8, w // 8)
+    img1 = uvoracle.synthetic_frame(sh1, sw1)
+    t0 = time.perf_counter()
+    if tile > 0:
+        m.upscale_image(img1, tile_size=tile, border=10, threads=1)
+    else:
+        m.apply_model(img1, threads=1)
+    dt1 = time.perf_counter() - t0
+    one_core = (sh1 * sw1) / float(h * w) / dt1
     return {
         "value": round(frac / dt, 5), "unit": "frames/s", "cores": threads, "kind": "port",
+        "value_one_core": round(one_core, 6), "sample_one_core": f"one {sw1}x{sh1} crop, 1 thread, {dt1:.1f} s",
         "sample": f"one {sw}x{sh} crop ({frac:.4f} of a frame) through oracle/oracle.c (fp32, OpenMP), "
                   f"{dt:.1f} s, scaled to whole frames; ncnn itself is not installable here",
     }
@@ -175,7 +186,72 @@ def chain_parity_probe(pre, net):
             "max_abs_lsb": int(np.abs(d).max()), "vs": "CPU oracle fp32 chain 1x->u8->2x, 128x96 frame"}
 
 
-def main():
+class SoloComm:
+    """one process, one GPU"""
+    world, rank = 1, 0
+
+    def barrier(self):
+        pass
+
+    def max_over_ranks(self, x):
+        return x
+
+    def close(self):
+        pass
+
+
+class ForkComm:
+    """N ranks started by this script itself (python bench.py --gpus N): a multiprocessing.Barrier and a shared array --
+    the frame queue has no data-path collective, and its timing fence does not need RCCL either"""
+
+    def __init__(self, rank, world, barrier, slots):
+        self.rank, self.world, self._b, self._s = rank, world, barrier, slots
+
+    def barrier(self):
+        self._b.wait()
+
+    def max_over_ranks(self, x):
+        self._s[self.rank] = x
+        self._b.wait()
+        m = max(self._s[:self.world])
+        self._b.wait()          # nobody overwrites its slot before everybody has read
+        return m
+
+    def close(self):
+        pass
+
+
+class TorchComm:
+    """launched by torch.distributed.run (the driver's N > 1 form): RCCL process group, used for the fence only"""
+
+    def __init__(self, local_rank):
+        import torch
+        import torch.distributed as dist
+        self._torch, self._dist = torch, dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+
+    def barrier(self):
+        self._dist.barrier()
+
+    def max_over_ranks(self, x):
+        t = self._torch.tensor([x], dtype=self._torch.float64, device="cuda")
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        self._dist.barrier()
+        self._dist.destroy_process_group()
+
+
+def _fork_rank(rank, world, device, barrier, slots, argv):
+    """entry point of a self-launched rank (spawn context: a fresh interpreter)"""
+    os.environ["UVA_BENCH_DEVICE"] = str(device)
+    sys.argv = argv
+    run(parse_args(argv[1:]), ForkComm(rank, world, barrier, slots), device)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -187,37 +263,61 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the 128x96 parity probe (profiling runs: every launch in the trace is then a full-size one)")
-    args = ap.parse_args()
+    ap.add_argument("--devices", default=None,
+                    help="comma-separated device ordinal per rank (default 0,1,..,N-1); '0,0' puts two ranks on one GPU, the "
+                         "reference's own way of loading a GPU with several workers (README.md:45-61)")
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps each; the median is reported (SURVEY.md 8d)")
+    return ap.parse_args(argv)
 
-    import torch
+
+def main():
+    args = parse_args()
     from upscale_video_amd import build
-    build.build_lib()
+    build.build_lib()                      # once, before any rank exists
+    if "RANK" in os.environ:               # torch.distributed.run started us (the driver's form for N > 1, also legal with 1 rank)
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        devices = [int(d) for d in args.devices.split(",")] if args.devices else None
+        device = devices[local_rank] if devices else local_rank
+        import torch
+        torch.cuda.set_device(device)
+        comm = TorchComm(device)
+        if comm.world != args.gpus and comm.rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE is %d: using the world size" % (args.gpus, comm.world), file=sys.stderr)
+        run(args, comm, device)
+        return
+    devices = [int(d) for d in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    if len(devices) != args.gpus:
+        sys.exit("--devices names %d devices for --gpus %d" % (len(devices), args.gpus))
+    if args.gpus == 1:
+        run(args, SoloComm(), devices[0])
+        return
+    # python bench.py --gpus N: start the N ranks here, one process per GPU, no RCCL anywhere
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    barrier, slots = ctx.Barrier(args.gpus), ctx.Array("d", args.gpus)
+    procs = [ctx.Process(target=_fork_rank, args=(r, args.gpus, devices[r], barrier, slots, list(sys.argv))) for r in range(args.gpus)]
+    for p in procs:
+        p.start()
+    rc = 0
+    for p in procs:
+        p.join()
+        rc = rc or p.exitcode
+    if rc:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        sys.exit("bench.py: a rank failed (exit code %s)" % rc)
+
+
+def run(args, comm, device):
+    import torch
     from upscale_video_amd import ncnn
     from upscale_video_amd.synth import synthetic_frame, synthetic_weights
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    world, rank, local_rank = comm.world, comm.rank, device
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path)"
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1 or "RANK" in os.environ:     # launched by torch.distributed.run (also with 1 rank)
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
-    def max_over_ranks(x):
-        if dist is None:
-            return x
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+    barrier, max_over_ranks = comm.barrier, comm.max_over_ranks
 
     numa_cpus = pin_to_gpu_numa_node(local_rank)     # before any page-locked allocation of this rank
     key, stem, h, w = WORKLOADS[args.workload]
@@ -272,14 +372,16 @@ def main():
         step(i)
     sync()
     net.set_profiling(True)
-    elapsed = timed_region(lambda: [step(i) for i in range(args.steps)], sync, barrier, max_over_ranks)
+    # >= 3 timed regions of exactly --steps steps each (every one bracketed by barrier + sync, MAX over ranks); the median counts
+    regions = [timed_region(lambda: [step(i) for i in range(args.steps)], sync, barrier, max_over_ranks) for _ in range(max(1, args.repeats))]
+    elapsed = sorted(regions)[len(regions) // 2]
     n_launch, trunk_ms = net.kernel_stats(1)       # generic graphs: rdb4_kernel
     _, head_ms = net.kernel_stats(0)
     n_tail, tail_ms = net.kernel_stats(2)          # generic graphs: the dense blocks' 192 -> 64 convolution
     net.set_profiling(False)
 
-    total_frames = args.steps * world
     fps = whole_job_rate(args.steps, world, elapsed)
+    steps_timed = args.steps * len(regions)        # the kernel event statistics cover every region
 
     # (E) pipelined host route, PCIe inclusive, on every rank at once: frames in page-locked host memory,
     # submit/collect with 3 frames in flight (SURVEY.md 8d "host-to-host with stream overlap")
@@ -324,7 +426,7 @@ def main():
                 "route": "K (device-resident frames and results; host_route_* fields are PCIe inclusive and never `value`)",
                 "frames_per_rank": args.steps, "tile_size": args.tile, "parallelism": f"frame-sharded x{world}, no collective",
                 "frame_tflop": round(frame_flops / 1e12, 4), "whole_path_tflops": round(frame_flops * fps / world / 1e12, 1),
-                "kernel_ms_per_frame": {"rdb4_kernel": round(trunk_ms / args.steps, 3), "conv5 (g_conv3_sw<6,1>)": round(tail_ms / args.steps, 3)},
+                "kernel_ms_per_frame": {"rdb4_kernel": round(trunk_ms / steps_timed, 3), "conv5 (g_conv3_sw<6,1>)": round(tail_ms / steps_timed, 3)},
                 "numa_cpus_rank0": (len(numa_cpus) if numa_cpus else None),
             },
             "roofline": {"kernel": "rdb4_kernel (conv1..conv4 + the 1x1 of a residual dense block, every plane of the frame, one launch)",
@@ -339,9 +441,11 @@ def main():
         print(json.dumps(result), flush=True)
     elif rank == 0:
         nf, nconv = net.num_features, net.num_convs
-        layers_per_launch = (nconv - 2) * args.steps / max(1, n_launch)       # 2 with trunk2_kernel (fused pairs)
+        layers_per_launch = (nconv - 2) * steps_timed / max(1, n_launch)      # 2 with the fused-pair kernels
         fused = layers_per_launch > 1.5
-        kernel = "trunk2_kernel" if fused else ("trunk_kernel" if nf == 64 else "conv3x3_kernel")
+        # the fused pair runs as Winograd F(2,3) (trunkw_kernel) unless UVA_TRUNK_WINO=0 selects the direct trunk2_kernel
+        kernel = (("trunkw_kernel" if os.environ.get("UVA_TRUNK_WINO", "1") != "0" else "trunk2_kernel") if nf == 64 else "pair24_kernel") if fused else \
+                 ("trunk_kernel" if nf == 64 else "conv3x3_kernel")
         trunk_flops_per_launch = layers_per_launch * 2 * 9 * nf * nf * h * w        # algorithmic: un-tiled frame
         whole_net = nf == 24 and layers_per_launch > nconv - 2.5    # sub10_kernel: all ten convolutions of the 1x net in one launch
         if whole_net:
@@ -364,10 +468,14 @@ def main():
                             f"frames and results resident in HBM",
                 "route": "K (device-resident frames and results; host_route_* fields are PCIe inclusive and never `value`)",
                 "frames_per_rank": args.steps, "tile_size": args.tile, "parallelism": f"frame-sharded x{world}, no collective",
+                "timed_regions_s": [round(x, 5) for x in regions], "reported": "median region",
+                "launcher": {"SoloComm": "one process", "ForkComm": "python bench.py --gpus N: own processes, multiprocessing barrier, no RCCL",
+                             "TorchComm": "torch.distributed.run, RCCL used for the timing fence only"}[type(comm).__name__],
+                "device_rank0": local_rank,
                 "frame_tflop": round(frame_flops / 1e12, 4),
                 "whole_path_tflops": round(frame_flops * fps / world / 1e12, 1),
-                "kernel_ms_per_frame": {"head": round(head_ms / args.steps, 4), "trunk": round(trunk_ms / args.steps, 4),
-                                        "tail": round(tail_ms / args.steps, 4)},
+                "kernel_ms_per_frame": {"head": round(head_ms / steps_timed, 4), "trunk": round(trunk_ms / steps_timed, 4),
+                                        "tail": round(tail_ms / steps_timed, 4)},
                 "numa_cpus_rank0": (len(numa_cpus) if numa_cpus else None),
             },
             "roofline": {
@@ -400,9 +508,7 @@ def main():
             if not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(key, h, w, args.tile)
         print(json.dumps(result), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    comm.close()
 
 
 if __name__ == "__main__":

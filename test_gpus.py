@@ -67,7 +67,7 @@ def time_pool(gpu_list, scale, runs, png):
     logging.info("%.3f frames/s file-to-HBM-to-host (PNG decode included, no encode)", runs / elapsed)
 
 
-def run_tests(gpus=None, scale=2, runs=10, image=None):
+def run_tests(gpus=None, scale=2, runs=10, image=None, size="1920x1080"):
     logging.basicConfig(level=logging.INFO, stream=sys.stdout, datefmt="%Y-%m-%d %H:%M:%S",
                         format="[%(asctime)s] [%(levelname)s] %(message)s")
     list_devices()
@@ -78,7 +78,8 @@ def run_tests(gpus=None, scale=2, runs=10, image=None):
         if image is None:
             from upscale_video_amd._imageio import imwrite
             image = os.path.join(scratch, "sample.png")
-            imwrite(image, synthetic_frame(1080, 1920))
+            w, h = (int(v) for v in size.lower().split("x"))
+            imwrite(image, synthetic_frame(h, w))
         time_pool(gpu_list, scale, runs, image)
 
 
@@ -87,6 +88,7 @@ if __name__ == "__main__":
     cli.add_argument("-g", "--gpus", help="worker list, one worker per entry, e.g. 0,1,1,2")
     cli.add_argument("-s", "--scale", type=int, default=2, choices=(2, 4), help="2 (default) or 4")
     cli.add_argument("-r", "--runs", type=int, default=10, help="number of timed calls (default 10)")
-    cli.add_argument("-i", "--image", help="PNG to upscale (default: a synthetic 1920x1080 frame)")
+    cli.add_argument("-i", "--image", help="PNG to upscale (default: a synthetic frame of --size)")
+    cli.add_argument("--size", default="1920x1080", help="WxH of the synthetic frame (BASELINE config 5: 3840x2160 with -g 0,1,2,3,4,5,6,7)")
     opts = cli.parse_args()
-    run_tests(opts.gpus, opts.scale, opts.runs, opts.image)
+    run_tests(opts.gpus, opts.scale, opts.runs, opts.image, opts.size)

@@ -202,6 +202,32 @@ def test_bench_under_torch_distributed_run_one_rank(tmp_path):
 
 
 @pytest.mark.gpu
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` starts its two ranks itself (no torch.distributed.run, no RCCL: the frame
+    queue has no collective and its timing fence is a multiprocessing barrier); `--devices 0,0` puts both on the box's one
+    GPU, the reference's way of loading a GPU with several workers.  ONE JSON line with n_gpus 2, and -- two ranks sharing
+    one GPU -- a whole-job rate in the neighbourhood of one rank's."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    common = ["--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-parity"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--devices", "0,0"] + common,
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["scaling"] == "weak" and "no RCCL" in d["config"]["launcher"]
+    assert len(d["config"]["timed_regions_s"]) == 3 and d["config"]["host_route_fps_pcie_inclusive"] > 0
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, timeout=900, env=env)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-4000:]
+    d1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][0])
+    assert 0.6 * d1["value"] <= d["value"] <= 1.25 * d1["value"], (d["value"], d1["value"])
+
+
+@pytest.mark.gpu
 def test_bench_valar_workload(tmp_path):
     """BASELINE config 4 as named under bench.py's contract: `--workload 4x_valar_1080p` (random-init weights: the .bin is
     a missing blob upstream) prints one JSON line with the whole-graph roofline object and both routes."""

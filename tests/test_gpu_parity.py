@@ -74,9 +74,8 @@ def test_per_layer_activations(nets, oracle_models, oracle, key):
         worst.append((idx, err, scale))
         assert err <= rel * scale + 2e-3, f"{key} conv {idx}: max err {err:.4g} vs scale {scale:.4g}; all: {worst}"
         if idx <= 2:
-            ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.maximum(np.abs(want), np.abs(got)), 2.0 ** -14))) - 10)     # fp16 spacing
-            flips = float(((got - want) != 0).mean())
-            assert flips <= 0.05 and bool((np.abs(got - want) <= 2 * ulp).all()), (key, idx, flips, worst)
+            flips = float(((got - want) != 0).mean())        # single-bit rounding flips from the fp32 summation order
+            assert flips <= 0.05 and err <= 1e-3 * scale, (key, idx, flips, worst)
 
 
 @pytest.mark.parametrize("key,h,w", [("2x", 37, 70), ("4x", 21, 45), ("1x", 50, 33), ("2x", 8, 32), ("2x", 1, 1),

@@ -89,3 +89,41 @@ def test_conv_flops_match_baseline_table():
     assert bench.conv_flops_per_px(64, 18, 2) == 1196928
     assert bench.conv_flops_per_px(64, 18, 4) == 1238400
     assert bench.conv_flops_per_px(24, 10, 1) == 85536
+
+
+def _fork_worker(rank, world, barrier, slots, q):
+    """a self-launched rank of `python bench.py --gpus N`: bench.ForkComm, no torch.distributed at all"""
+    sys.path.insert(0, ROOT)
+    import time
+    import bench
+    comm = bench.ForkComm(rank, world, barrier, slots)
+    assert "torch.distributed" not in sys.modules
+    # the slow rank sets the job time, in both regions, and every rank gets the same number
+    a = bench.timed_region(lambda: time.sleep(0.25 if rank == 1 else 0.02), lambda: None, comm.barrier, comm.max_over_ranks)
+    b = bench.timed_region(lambda: time.sleep(0.3 if rank == 0 else 0.02), lambda: None, comm.barrier, comm.max_over_ranks)
+    q.put((rank, a, b, bench.shard_frames(7, rank, world)))
+
+
+def test_self_launched_ranks_fence_without_rccl():
+    """python bench.py --gpus N starts its own ranks: barrier + MAX over ranks through multiprocessing primitives"""
+    import multiprocessing as mp
+    world = 3
+    ctx = mp.get_context("spawn")
+    barrier, slots, q = ctx.Barrier(world), ctx.Array("d", world), ctx.Queue()
+    procs = [ctx.Process(target=_fork_worker, args=(r, world, barrier, slots, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert len({round(r[1], 9) for r in res}) == 1 and len({round(r[2], 9) for r in res}) == 1      # one number for the job
+    assert 0.25 <= res[0][1] < 0.6 and 0.3 <= res[0][2] < 0.7
+    assert sorted(f for r in res for f in r[3]) == list(range(7))
+
+
+def test_bench_refuses_a_device_list_of_the_wrong_length():
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--devices", "0"], capture_output=True, text=True,
+                       env=dict(os.environ, UVA_LIB_PATH=os.path.join(ROOT, "upscale_video_amd", "libuva.so")))
+    assert r.returncode != 0 and "--devices" in (r.stderr + r.stdout)
