@@ -962,6 +962,37 @@ int get_workspace(uva_net* n, int h, int w, int tile_size, int border, Workspace
     return 0;
 }
 
+hipEvent_t take_event(uva_net* n);
+
+// A pair of events around one launch (profiling): begin() records the first, end() the second and queues the pair; a pair
+// that is not completed -- an event could not be created, a call in between failed -- gives its events back.
+struct EvPairScope {
+    uva_net* n;
+    uva_net::EvPair p;
+    bool queued = false;
+    EvPairScope(uva_net* net, int kind, bool on) : n(net), p{nullptr, nullptr, kind}
+    {
+        if (!on) return;
+        p.a = take_event(n);
+        p.b = p.a ? take_event(n) : nullptr;
+        if (p.a && !p.b) { n->ev_free.push_back(p.a); p.a = nullptr; }
+    }
+    hipError_t begin() { return p.b ? hipEventRecord(p.a, n->stream) : hipSuccess; }
+    hipError_t end()
+    {
+        if (!p.b) return hipSuccess;
+        const hipError_t e = hipEventRecord(p.b, n->stream);
+        if (e == hipSuccess) { n->ev_pairs.push_back(p); queued = true; }
+        return e;
+    }
+    ~EvPairScope()
+    {
+        if (queued) return;
+        if (p.a) n->ev_free.push_back(p.a);
+        if (p.b) n->ev_free.push_back(p.b);
+    }
+};
+
 // -> nullptr (with the error recorded) if the runtime cannot create another event
 hipEvent_t take_event(uva_net* n)
 {
@@ -1489,11 +1520,11 @@ int generic_run_planes(uva_net* n, bool f32, const std::vector<PlaneJob>& jobs)
                 HIP_TRY(hipFuncSetAttribute((const void*)rdb4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 n->attr_set[28] = true;
             }
-            uva_net::EvPair evp{nullptr, nullptr, 1};
-            if (n->prof && (evp.a = take_event(n)) && (evp.b = take_event(n))) HIP_TRY(hipEventRecord(evp.a, n->stream));
+            EvPairScope evp(n, 1, n->prof);
+            HIP_TRY(evp.begin());
             hipLaunchKernelGGL(rdb4_kernel, dim3(plan.grid), dim3(256), rdb4_lds_bytes(), n->stream, ra);
             HIP_TRY(hipGetLastError());
-            if (evp.b) { HIP_TRY(hipEventRecord(evp.b, n->stream)); n->ev_pairs.push_back(evp); }
+            HIP_TRY(evp.end());
             for (PlaneState& ps : P) finish_layer(ps);
             continue;
         }
@@ -1542,10 +1573,10 @@ int generic_run_planes(uva_net* n, bool f32, const std::vector<PlaneJob>& jobs)
                         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                         n->attr_set[slot] = true;
                     }
-                    uva_net::EvPair evp{nullptr, nullptr, 2};
-                    if (n->prof && cd.cin_pad == 192 && (evp.a = take_event(n)) && (evp.b = take_event(n))) HIP_TRY(hipEventRecord(evp.a, n->stream));
+                    EvPairScope evp(n, 2, n->prof && cd.cin_pad == 192);
+                    HIP_TRY(evp.begin());
                     hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(256), lds, n->stream, sa);
-                    if (evp.b) { HIP_TRY(hipEventRecord(evp.b, n->stream)); n->ev_pairs.push_back(evp); }
+                    HIP_TRY(evp.end());
                     return 0;
                 };
                 // 192 inputs: UVA_GENERIC_SK=1 takes g_conv3_sk (32x32x16 MFMAs, the k-loop split between wave pairs) instead of

@@ -373,6 +373,7 @@ std::vector<RdbMatch> find_rdbs(const GenericGraph& g)
         const GLayer& ls = g.layers[m.c2s];
         if (ls.kind != GLayer::CONV || ls.ksize != 1 || ls.has_bias || ls.has_act || root(ls.in[0]) != x || g.convs[ls.conv].cout != 32) continue;
         if (s1 != s2 || s1 != s3 || s1 != s4) continue;
+        if (!(s1 >= 0.f && s1 <= 1.f)) continue;     // rdb4_kernel's LeakyReLU is max(v, slope * v): the layer-by-layer kernels take the others
         // program order: everything the launch at c1 replaces comes after it, and x is written before it
         if (!(m.c1 < m.c2 && m.c1 < m.c2s && m.c2 < m.add2 && m.c2s < m.add2 && m.add2 < m.c3 && m.c3 < m.c4 && m.c4 < m.add4)) continue;
         if (producer[x] < 0 || producer[x] >= m.c1) continue;

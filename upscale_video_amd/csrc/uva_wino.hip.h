@@ -465,6 +465,20 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
             TW_STAMP(1);
             group_barrier();
             TW_STAMP(2);
+            // The raw rows of step it + 1 (landed: the producers waited for them in front of barrier 1) -> A-ring.  FIRST: the
+            // producers' epilogue runs beside it at full speed (beside a k-loop it gets one instruction through per MFMA), and
+            // nothing is left behind the k-loop, when the LDS store path would be all that moves.
+            auto raw_rows = [&]() __attribute__((always_inline)) {
+                if (it + 1 < nsteps) {
+                    int pos0 = a6 + 4 + 2;         // step it + 1's new rows follow its two shared ones
+                    pos0 = pos0 >= TW_AROWS ? pos0 - TW_AROWS : pos0;
+                    transform_rows((it + 1) & 1, pos0);
+                }
+            };
+#ifndef TW_TRANSFORM_LAST
+            raw_rows();
+#endif
+            TW_STAMP(4);
             if (kact) {
                 __builtin_amdgcn_s_setprio(TW_PRIO_K);
                 int bp = b10 - 4 - 2;              // block it - 1 begins at (4 (it - 1)) mod 10; the window starts two rows above
@@ -474,13 +488,9 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
                 __builtin_amdgcn_s_setprio(TW_PRIO_E);
             }
             e_3 = e_k;
-            TW_STAMP(4);
-            // the raw rows of step it + 1 (landed: the producers waited for them in front of barrier 1) -> A-ring
-            if (it + 1 < nsteps) {
-                int pos0 = a6 + 4 + 2;             // step it + 1's new rows follow its two shared ones
-                pos0 = pos0 >= TW_AROWS ? pos0 - TW_AROWS : pos0;
-                transform_rows((it + 1) & 1, pos0);
-            }
+#ifdef TW_TRANSFORM_LAST
+            raw_rows();
+#endif
             TW_STAMP(3);
             group_barrier();
             a6 = a6 + 4 >= TW_AROWS ? a6 + 4 - TW_AROWS : a6 + 4;

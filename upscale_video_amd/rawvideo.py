@@ -115,7 +115,10 @@ class Lane:
 
     def pop(self):
         """The oldest frame's result (blocks until the GPU is done with it)."""
+        assert self.count > 0, "pop() on an empty lane"
+
         def ensure(k):
+            assert k >= 0, "no frame in flight in any stage"
             if self.stages[k].inflight:
                 return
             ensure(k - 1)
