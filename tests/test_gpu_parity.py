@@ -398,6 +398,7 @@ def test_whole_1080p_frame_against_the_oracle(nets, oracle_models, oracle, key):
         d = np.abs(got[y:y + 540].astype(np.int16) - want[y:y + 540].astype(np.int16))
         worst, nz, se = max(worst, int(d.max())), nz + int((d > 0).sum()), se + float((d.astype(np.float64) ** 2).sum())
     psnr = 10 * np.log10(255.0 ** 2 / (se / got.size)) if se else 99.0
+    print(f"whole 1080p frame, {key}: max |diff| {worst} LSB, PSNR {psnr:.2f} dB, {100 * nz / got.size:.3f} % of the samples differ")
     assert worst <= 2, worst
     assert psnr >= 60.0, psnr
     assert nz / got.size < 0.05, nz / got.size

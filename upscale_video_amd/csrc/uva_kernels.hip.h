@@ -1963,23 +1963,9 @@ __global__ __launch_bounds__(512, 2) void trunk2_kernel(Trunk2Args a)
                     for (int c = 0; c < (NARROW ? 1 : 2); ++c)
                         if (2 * st + c + PFF < NFRAG) bq[(2 * st + c + PFF) % RQ] = read_b(2 * st + c + PFF);
                     const int R = st & 3, ch = (st >> 2) & 1, dx = st >> 3;
-#if !defined(UVA_EXP_WINO) || UVA_EXP_WINO != 2
                     const half8 b0 = bq[(2 * st) % RQ], b1 = bq[(2 * st + 1) % RQ];
-#endif
-#ifdef UVA_EXP_WINO
-                    // EXPERIMENT (wrong results): the k-loop of a Winograd F(2,3) kernel would issue 96 MFMAs for the same
-                    // 48 fragment reads -- drop the dy == 1 taps (every fragment stays in use); UVA_EXP_WINO == 2: plus four
-                    // packed fp16 adds per fragment (the input transform done at read time)
-#if UVA_EXP_WINO == 2
-                    const half8 b0x = bq[(2 * st) % RQ], b1x = bq[(2 * st + 1) % RQ];
-                    const half8 b0 = pk_sub(b0x, b1x), b1 = b1x + b0x;
-#endif
-#endif
                     for (int n = 0; n < 2; ++n) {
                         if (n == 0 ? R > 2 : R < 1) continue;       // output row n, tap (dy = R - n, dx)
-#ifdef UVA_EXP_WINO
-                        if (R - n == 1) continue;
-#endif
                         const bool first = st == n;
 #pragma unroll
                         for (int m = 0; m < 2; ++m) {
@@ -1994,14 +1980,7 @@ __global__ __launch_bounds__(512, 2) void trunk2_kernel(Trunk2Args a)
 #pragma unroll
                 for (int st = 0; st < NSTEP; ++st) {
                     const int R = st & 3;
-#ifdef UVA_EXP_WINO
-                    const bool light = true;
-#if UVA_EXP_WINO == 2
-                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-#endif
-#else
                     const bool light = R == 0 || R == 3;
-#endif
                     const bool rd = 2 * st + PFF < NFRAG;
                     constexpr int D = NARROW ? 2 : 1;
                     if (light) __builtin_amdgcn_sched_group_barrier(0x008, 2 / D, 0); else __builtin_amdgcn_sched_group_barrier(0x008, 4 / D, 0);
