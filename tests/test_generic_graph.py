@@ -158,6 +158,50 @@ def test_mini_graph_with_reference_tiling(uva, mini, oracle):
     assert d.max() <= 2 and (d > 0).mean() < 0.1, (int(d.max()), float((d > 0).mean()))
 
 
+def _valar_fixture(tmp_path):
+    """tests/golden/valar_synthetic.npz (oracle/independent_check.py: torch ops, own parser) and the weights it was made with"""
+    from upscale_video_amd import synth
+    g = np.load(os.path.join(ROOT, "tests", "golden", "valar_synthetic.npz"))
+    seed, gain = g["valar_seed_gain"]
+    b = str(tmp_path / "4x_Valar_v1.bin")
+    synth.synthetic_weights(VALAR, b, seed=int(seed), gain=float(gain))
+    return g, b
+
+
+def test_numpy_restatement_agrees_with_the_independent_evaluation_of_valar(tmp_path):
+    """the ops only 4x_Valar_v1 has (Concat, Eltwise with coefficients, LeakyReLU fused into a convolution,
+    the bias-less 1x1 convolution, nearest x2 Interp) were restated exactly once; the committed fixture is a second,
+    independent evaluation (torch.nn.functional, its own .param / .bin parser) of all 1206 layers."""
+    from oracle import generic_oracle as go
+    g, b = _valar_fixture(tmp_path)
+    om = go.Model(VALAR, b)
+    img = g["valar_12x20_in"]
+    x = img.transpose(2, 0, 1).astype(np.float32) * np.float32(1 / 255.0)
+    f = om.forward(x)
+    want = g["valar_12x20_f32"]
+    assert f.shape == want.shape == (3, 48, 80)
+    assert float(np.abs(f - want).max()) <= 2e-5 * float(np.abs(want).max()) + 1e-6
+    u = om.apply_u8(img)
+    assert np.abs(u.astype(int) - g["valar_12x20_u8"].astype(int)).max() <= 1 and (u != g["valar_12x20_u8"]).mean() <= 1e-3
+
+
+@pytest.mark.gpu
+def test_valar_graph_against_the_independent_fixture(uva, tmp_path):
+    """The HIP executor (rdb4_kernel / g_conv3_sw on the 75-wide plane, the layer-by-layer kernels on the 20-wide one) against
+    the independent torch evaluation: f32 within 4e-3 of max|out| (fp16 storage against fp32), u8 within 2 LSB."""
+    g, b = _valar_fixture(tmp_path)
+    net = uva.Net()
+    net.set_vulkan_device(0)
+    assert net.load_param(VALAR) == 0 and net.load_model(b) == 0, getattr(net, "last_error", "")
+    for tag in ("valar_12x20", "valar_70x75"):
+        img, want = g[tag + "_in"], g[tag + "_f32"]
+        got = net._extract(img.transpose(2, 0, 1).astype(np.float32) * np.float32(1 / 255.0))
+        ok, info = _close(got, want, 4e-3 if tag == "valar_70x75" else 2e-2)
+        assert ok, (tag, info)
+        u8 = net.process_u8(img, tile_size=0)
+        assert np.abs(u8.astype(int) - g[tag + "_u8"].astype(int)).max() <= 2 and psnr_u8(u8, g[tag + "_u8"]) >= 45, tag
+
+
 @pytest.mark.gpu
 def test_valar_graph_with_synthetic_weights(uva, oracle, tmp_path):
     """All 1206 layers of 4x_Valar_v1 (23 RRDBs: Concat up to 192 channels, 1x1 convolutions, Eltwise(0.2, 1.0),

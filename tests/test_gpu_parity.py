@@ -113,7 +113,12 @@ def test_process_u8_whole_frame_matches_oracle(nets, oracle_models, oracle, key,
 def test_golden_vectors(nets):
     """Committed fixtures generated by oracle/independent_check.py (independent torch evaluation)."""
     g = np.load(os.path.join(ROOT, "tests", "golden", "independent_torch.npz"))
-    tags = sorted({k[:-3] for k in g.files if k.endswith("_in") and not k.startswith("config1")})
+    tags = sorted({k[:-3] for k in g.files if k.endswith("_in") and k.split("_")[0] in ("1x", "2x", "4x")})
+    # the tiled path (75x70, 32/10: all four border branches) and config 3's chain, from the independent evaluation's own tiling loop
+    t = nets["2x"].process_u8(g["tiled_2x_70x75_t32_in"], tile_size=32, border=10)
+    assert np.abs(t.astype(int) - g["tiled_2x_70x75_t32_u8"].astype(int)).max() <= 2 and psnr_u8(t, g["tiled_2x_70x75_t32_u8"]) >= 50
+    c = nets["2x"].process_u8(nets["1x"].process_u8(g["chain_1x_2x_48x64_t32_in"], tile_size=0), tile_size=32, border=10)
+    assert np.abs(c.astype(int) - g["chain_1x_2x_48x64_t32_u8"].astype(int)).max() <= 2 and psnr_u8(c, g["chain_1x_2x_48x64_t32_u8"]) >= 50
     c1 = nets["2x"].process_u8(g["config1_2x_256x256_in"], tile_size=960, border=10)   # BASELINE config 1
     assert np.abs(c1.astype(int) - g["config1_2x_256x256_u8"].astype(int)).max() <= 2
     assert psnr_u8(c1, g["config1_2x_256x256_u8"]) >= 50

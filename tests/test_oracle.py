@@ -113,8 +113,13 @@ def test_pixelshuffle_order(oracle_models, oracle, key):
 
 def test_golden_independent_torch(oracle_models, oracle):
     g = np.load(os.path.join(ROOT, "tests", "golden", "independent_torch.npz"))
-    tags = sorted({k[:-3] for k in g.files if k.endswith("_in") and not k.startswith("config1")})
+    tags = sorted({k[:-3] for k in g.files if k.endswith("_in") and k.split("_")[0] in ("1x", "2x", "4x")})
     assert len(tags) == 6
+    # the tiled path (all four border branches) and BASELINE config 3's chain through the independent evaluation's OWN tiling loop
+    t = oracle_models["2x"].upscale_image(g["tiled_2x_70x75_t32_in"], tile_size=32, border=10)
+    assert np.abs(t.astype(int) - g["tiled_2x_70x75_t32_u8"].astype(int)).max() <= 1 and (t != g["tiled_2x_70x75_t32_u8"]).mean() <= 1e-3
+    c = oracle_models["2x"].upscale_image(oracle_models["1x"].apply_model(g["chain_1x_2x_48x64_t32_in"]), tile_size=32, border=10)
+    assert np.abs(c.astype(int) - g["chain_1x_2x_48x64_t32_u8"].astype(int)).max() <= 1 and (c != g["chain_1x_2x_48x64_t32_u8"]).mean() <= 1e-3
     # BASELINE config 1 (256x256, 2x Compact): u8 result of the independent evaluation
     c1 = oracle_models["2x"].upscale_image(g["config1_2x_256x256_in"])
     assert np.abs(c1.astype(int) - g["config1_2x_256x256_u8"].astype(int)).max() <= 1
