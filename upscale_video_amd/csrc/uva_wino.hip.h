@@ -331,6 +331,7 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
         const unsigned wlane = p < 15 ? (unsigned)(TW_BRING + (2 * (cg & 1)) * (TW_BROWB / 4) + (wave >> 1) * (TW_BROWB / 8) + p * 64 +
                                                     ((oo ^ ((p >> 1) & 3)) << 4))
                                       : (unsigned)(TW_LDS_BYTES - 64 + 16 * cg);
+        const unsigned w64 = (unsigned)(TW_BRING + (wave >> 1) * (TW_BROWB / 8) + p * 64 + ((oo ^ ((p >> 1) & 3)) << 4) + 8 * (cg & 1));
         const unsigned wrow = p < 15 ? (unsigned)TW_BROWB : 0u;      // (pair 15: every row and both units to the same spare place)
         const unsigned wj = p < 15 ? (unsigned)(TW_BROWB / 4) : 0u;
         for (int it = 0; it < niter; ++it) {
@@ -362,6 +363,20 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
                     st.q[4] = pk_sub_f16(st.t[0], st.y0); st.q[5] = pk_sub_f16(st.t[1], st.y1);      // V2 = d2 - d1
                     st.q[6] = pk_sub_f16(st.y0, st.t[2]); st.q[7] = pk_sub_f16(st.y1, st.t[3]);      // V3 = d1 - d3
                 } else if constexpr (k == 6) {
+#ifndef TW_W128
+                    // no lane exchange: every lane stores its own four channels of V0..V3 as 8-byte pieces (2-way bank conflicts --
+                    // eight even pairs onto four units -- and still 0.7 % faster than four v_permlane16_swap and two 16-byte stores
+                    // per row: -DTW_W128, profiles/r04_ab_results.txt block 9)
+                    int pos = b10 + n;
+                    pos = pos >= TW_BROWS ? pos - TW_BROWS : pos;
+                    if (p < 15) {
+                        char* const w0 = smem + w64 + (unsigned)pos * TW_BROWB;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) *(uint2*)(w0 + j * (TW_BROWB / 4)) = make_uint2(st.q[2 * j], st.q[2 * j + 1]);
+                    }
+                } else if constexpr (k == 7) {
+                } else if constexpr (k == 8) {
+#endif
                     const auto s02a = __builtin_amdgcn_permlane16_swap(st.q[0], st.q[4], false, false);
                     const auto s02b = __builtin_amdgcn_permlane16_swap(st.q[1], st.q[5], false, false);
                     const auto s13a = __builtin_amdgcn_permlane16_swap(st.q[2], st.q[6], false, false);
