@@ -50,8 +50,11 @@ def locate(off, planes, guard, pi):
 @pytest.mark.parametrize("h,w,tile,border", [
     (1080, 1920, 960, 10), (2160, 3840, 960, 10), (1080, 1920, 0, 0), (256, 256, 960, 10),
     (24, 40, 0, 0), (70, 75, 32, 10), (5, 3, 0, 0), (131, 61, 64, 10), (1, 1, 0, 0), (960, 960, 0, 0), (96, 128, 64, 10)])
-def test_walking_the_lists_like_the_kernel(uva, h, w, tile, border):
+@pytest.mark.parametrize("six", [0, 1])
+def test_walking_the_lists_like_the_kernel(uva, h, w, tile, border, six, monkeypatch):
+    monkeypatch.setenv("UVA_TW_SIX", str(six))          # 1: a workgroup's first segment starts with all six input rows
     steps, nsteps, planes, guard = schedule(uva, h, w, tile, border)
+    assert bool(((steps[:, 0, 1] >> 25) & 1).any()) == bool(six)
     grid, stride, _ = steps.shape
     cover = [np.zeros((int(p[0]), int(p[1])), np.int32) for p in planes]
     for b in range(grid):
@@ -80,7 +83,9 @@ def test_walking_the_lists_like_the_kernel(uva, h, w, tile, border):
             for r in range(4):
                 assert ((rmask >> r) & 1) == (0 <= yA + r < ph)
             assert c_lo == (1 if x0 == 0 else 0) and c_hi == min(32, pw - x0 + 1)
-            dec.append((pi, yA, x0, bb))
+            six = (int(a[1]) >> 25) & 1          # only a workgroup's first step may ask for all six input rows
+            assert six == 0 or g == 0
+            dec.append((pi, yA, x0, bb, six))
         # ---- the kernel's walk: iteration `it`, phase X: A k-loop(it); phase Y: A epilogue(it) -> B-ring, raw rows of
         # step it + 1 -> A-ring, B k-loop(it - 1); B's stores of step it - 1 follow in iteration it + 1
         aring = [None] * AROWS          # (plane, x0, input row)
@@ -88,14 +93,16 @@ def test_walking_the_lists_like_the_kernel(uva, h, w, tile, border):
         a6 = b10 = 0
 
         def put_rows(g, pos0):
-            pi, yA, x0, _ = dec[g]
+            pi, yA, x0, _, _ = dec[g]
             for wv in range(4):
                 aring[(pos0 + wv) % AROWS] = (pi, x0, yA + 1 + wv)
         if n:
-            put_rows(0, 2)              # prologue: step 0's new rows; positions 0, 1 hold nothing
+            put_rows(0, 2)              # prologue: step 0's new rows; positions 0, 1 hold nothing ...
+            if dec[0][4]:               # ... unless the entry asks for the two rows above them as well
+                aring[0], aring[1] = (dec[0][0], dec[0][2], dec[0][1] - 1), (dec[0][0], dec[0][2], dec[0][1])
         for it in range(n + 1):
             if it < n:
-                pi, yA, x0, _ = dec[it]
+                pi, yA, x0, _, _ = dec[it]
                 ph = int(planes[pi, 0])
                 rows6 = [aring[(a6 + r) % AROWS] for r in range(6)]
                 for nn in range(4):
@@ -106,23 +113,23 @@ def test_walking_the_lists_like_the_kernel(uva, h, w, tile, border):
                 if it + 1 < n:
                     put_rows(it + 1, (a6 + 4 + 2) % AROWS)
             if 1 <= it <= n:
-                pi, yA, x0, bb = dec[it - 1]
+                pi, yA, x0, bb, _ = dec[it - 1]
                 if (int(bb[1]) >> 24) & 1:
                     ph, pw = int(planes[pi, 0]), int(planes[pi, 1])
                     b_off = int(bb[0]) | ((int(bb[1]) & 0xff) << 32)
-                    vy, vx = (int(bb[1]) >> 8) & 7, (int(bb[1]) >> 11) & 63
+                    vy, vx, v0 = (int(bb[1]) >> 8) & 7, (int(bb[1]) >> 11) & 63, (int(bb[1]) >> 17) & 7
                     assert int(bb[3]) == pi and int(bb[2]) == int(planes[pi, 2]) * 128
                     row, col = locate(b_off, planes, guard, pi)
                     yo = row - 1
-                    assert col - 1 == x0 and yo == yA - 1 and 1 <= vy <= 4 and vx == min(SW, pw - x0)
-                    assert 0 <= yo and yo + vy <= ph
+                    assert col - 1 == x0 and yo == yA - 1 and 0 <= v0 < vy <= 4 and vx == min(SW, pw - x0)
+                    assert 0 <= yo + v0 and yo + vy <= ph
                     bp = (b10 - 4 - 2) % BROWS          # the kernel's window: two rows above block it - 1
                     win = [bring[(bp + r) % BROWS] for r in range(6)]
-                    for nn in range(vy):
+                    for nn in range(v0, vy):
                         for d in range(3):
                             e = win[nn + d]
                             assert e is not None and e[:3] == (pi, x0, yo + nn - 1 + d) and e[3], (b, it, nn, d, e)
-                    cover[pi][yo:yo + vy, x0:x0 + vx] += 1
+                    cover[pi][yo + v0:yo + vy, x0:x0 + vx] += 1
             a6 = (a6 + 4) % AROWS
             b10 = (b10 + 4) % BROWS
     for c in cover:

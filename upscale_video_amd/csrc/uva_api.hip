@@ -491,19 +491,25 @@ int launch_trunk2(uva_net* n, const Workspace* ws, const Trunk2Args& a)
     return 0;
 }
 
-// Step lists of trunkw_kernel: the same 30-column strips and 4-row steps as trunk2_kernel's, but a segment starts
-// WITHOUT the two input rows a step shares with the one above it: its first producer step yields two valid
-// intermediate rows and its first consumer step nothing, so k steps yield 4 (k - 1) output rows and a segment of
-// `rows` output rows beginning at row r0 has its first intermediate block at row r0 - 3.  Step g of a segment:
-//   producer: intermediate rows yA .. yA+3, yA = r0 - 3 + 4g, from the new input rows yA+1 .. yA+4 (+ the two above);
-//   consumer: output rows yA-1 .. yA+2 = r0 + 4(g-1) .. (g >= 1), from the last two rows of block g-1 and block g.
+// Step lists of trunkw_kernel: the same 30-column strips and 4-row steps as trunk2_kernel's, but a segment that is not its
+// workgroup's first starts WITHOUT the two input rows a step shares with the one above it: its first producer step yields
+// two valid intermediate rows and its first consumer step nothing, so k steps yield 4 (k - 1) output rows and a segment
+// of `rows` output rows beginning at row r0 has its first intermediate block at row r0 - 3 (a workgroup's first segment:
+// r0 - 1, 4k - 2 rows -- the kernel's prologue fetches all six rows).  Step g of a segment:
+//   producer: intermediate rows yA .. yA+3, yA = r0 - 3 (- 1) + 4g, from the new input rows yA+1 .. yA+4 (+ the two above);
+//   consumer: output rows yA-1 .. yA+2, of which those inside the segment are stored, from the last two rows of block g-1
+//             and block g.
 int build_trunkw_schedule(const std::vector<PlaneDesc>& planes, int grid, size_t guard_bytes, std::vector<Trunk2Step>& steps,
                           std::vector<int>& nsteps, int* max_steps)
 {
     constexpr int PIXB = 128;
-    struct Seg { int plane, x0, r0, rows, k; };
+    // UVA_TW_SIX=1: a workgroup's first segment starts with all six input rows (the kernel's prologue fetches them): 0.7 % fewer
+    // steps at 1080p, and measured 0.3 % SLOWER (the longest list is as long as before, the prologue longer): off by default
+    const char* const sx = std::getenv("UVA_TW_SIX");
+    const bool six_ok = sx && std::atoi(sx) != 0;
+    struct Seg { int plane, x0, r0, rows, k; bool full; };
     long long total = 0;
-    for (const auto& p : planes) total += (long long)((p.w + TW_SW - 1) / TW_SW) * ((p.h + 3) / 4 + 1);
+    for (const auto& p : planes) total += (long long)((p.w + TW_SW - 1) / TW_SW) * ((p.h + 3) / 4 + 1);     // (an upper bound: first segments need less)
     std::vector<std::vector<Seg>> per_wg;
     int L = (int)std::max<long long>(4, (total + grid - 1) / grid);
     for (;; ++L) {
@@ -515,17 +521,21 @@ int build_trunkw_schedule(const std::vector<PlaneDesc>& planes, int grid, size_t
             for (int x0 = 0; x0 < p.w; x0 += TW_SW) {
                 int y = 0;
                 while (y < p.h) {
-                    const int need = (p.h - y + 3) / 4 + 1;
+                    // a workgroup's FIRST segment gets all six input rows of its first step (the kernel's prologue fetches the two
+                    // shared ones as well): k steps yield 4k - 2 rows there, 4 (k - 1) in the segments behind it
+                    const bool full = six_ok && per_wg.back().empty();
+                    const int need = full ? (p.h - y + 2 + 3) / 4 : (p.h - y + 3) / 4 + 1;
                     if (need <= cap) {
-                        per_wg.back().push_back({(int)pi, x0, y, p.h - y, need});
+                        per_wg.back().push_back({(int)pi, x0, y, p.h - y, need, full});
                         cap -= need;
                         y = p.h;
                     } else if (cap < 3) {             // a segment of fewer than 3 steps is mostly pipeline fill
                         next_wg();
                         continue;
                     } else {
-                        per_wg.back().push_back({(int)pi, x0, y, 4 * (cap - 1), cap});
-                        y += 4 * (cap - 1);
+                        const int rows = full ? 4 * cap - 2 : 4 * (cap - 1);
+                        per_wg.back().push_back({(int)pi, x0, y, rows, cap, full});
+                        y += rows;
                         cap = 0;
                     }
                     if (cap < 1) next_wg();
@@ -553,7 +563,7 @@ int build_trunkw_schedule(const std::vector<PlaneDesc>& planes, int grid, size_t
         for (const Seg& sg : per_wg[c]) {
             const PlaneDesc& p = planes[sg.plane];
             for (int j = 0; j < sg.k; ++j, ++g) {
-                const int yA = sg.r0 - 3 + 4 * j;                        // first intermediate row of the block
+                const int yA = sg.r0 - (sg.full ? 1 : 3) + 4 * j;        // first intermediate row of the block
                 // first new input row = pixel (yA + 1, x0 - 2) = array position (yA + 2, x0 - 1)
                 const long long ao = (long long)guard_bytes +
                                      ((long long)p.act_off + (long long)(yA + 2) * p.pitch + (sg.x0 - 1)) * PIXB;
@@ -562,14 +572,18 @@ int build_trunkw_schedule(const std::vector<PlaneDesc>& planes, int grid, size_t
                 for (int r = 0; r < 4; ++r)
                     if (yA + r >= 0 && yA + r < p.h) rmask |= 1u << r;
                 const unsigned c_lo = sg.x0 == 0 ? 1 : 0, c_hi = (unsigned)std::min(32, p.w - sg.x0 + 1);
-                out[g].a = make_uint4((unsigned)ao, (unsigned)(ao >> 32) | (rmask << 8) | (c_lo << 12) | (c_hi << 18) | (1u << 24),
+                out[g].a = make_uint4((unsigned)ao, (unsigned)(ao >> 32) | (rmask << 8) | (c_lo << 12) | (c_hi << 18) | (1u << 24) |
+                                                    ((sg.full && j == 0) ? 1u << 25 : 0u),
                                       (unsigned)(p.pitch * PIXB), (unsigned)sg.plane);
-                if (j >= 1) {
-                    const int yo = sg.r0 + 4 * (j - 1);
+                // the consumer step stores rows yo + [v0, v1) of its four (yo = yA - 1): those inside the segment
+                const int yo = yA - 1;
+                const int v0 = std::max(0, sg.r0 - yo), v1 = std::min(4, sg.r0 + sg.rows - yo);
+                if (v1 > v0) {
                     const long long bo = (long long)guard_bytes +
                                          ((long long)p.act_off + (long long)(yo + 1) * p.pitch + (sg.x0 + 1)) * PIXB;
-                    const unsigned vy = (unsigned)std::min(4, sg.r0 + sg.rows - yo), vx = (unsigned)std::min(TW_SW, p.w - sg.x0);
-                    out[g].b = make_uint4((unsigned)bo, (unsigned)(bo >> 32) | (vy << 8) | (vx << 11) | (1u << 24),
+                    if (bo < 0 || (bo >> 40)) return fail("activation buffer too large for the step encoding");
+                    const unsigned vx = (unsigned)std::min(TW_SW, p.w - sg.x0);
+                    out[g].b = make_uint4((unsigned)bo, (unsigned)(bo >> 32) | ((unsigned)v1 << 8) | (vx << 11) | ((unsigned)v0 << 17) | (1u << 24),
                                           (unsigned)(p.pitch * PIXB), (unsigned)sg.plane);
                 }
             }

@@ -70,8 +70,9 @@ static_assert(TW_RAW % 128 == 0 && TW_RAWROWB % 128 == 0, "raw pixel records are
 //      from the activation buffer's base (guard included), y = offset bits 32..39 | row mask << 8 (bit n:
 //      intermediate row yA + n is inside the plane) | c_lo << 12 | c_hi << 18 (intermediate columns [c_lo, c_hi) of
 //      the 32 are inside the plane) | active << 24, z = row pitch in bytes
-//   b: x = byte offset (low 32) of output pixel (yA - 1, x0), y = offset bits 32..39 | valid rows << 8 (rows
-//      yA-1 .. yA-1+vy-1 are stored) | valid columns << 11 | active << 24, z = row pitch in bytes
+//      active << 24 | (the workgroup's first step only) all six input rows are to be fetched << 25, z = row pitch in bytes
+//   b: x = byte offset (low 32) of output pixel (yA - 1, x0), y = offset bits 32..39 | v1 << 8 | valid columns << 11 |
+//      v0 << 17 (rows yA-1 + [v0, v1) are stored) | active << 24, z = row pitch in bytes
 
 // LDS-DMA piece i of wave `wave`: piece c = 4i + wave covers units [64c, 64c + 64) of a raw slot; unit q is row
 // q / 272, record (q % 272) / 8, slot q % 8 -> (row << 13) | byte offset of that octet inside the source row
@@ -190,10 +191,7 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
     const unsigned vlane_c = vlane_of(lane);
     const unsigned t_lo = (unsigned)((lane & 15) * PIXB + (((lane >> 4) ^ (lane & 7)) << 4));
     const unsigned t_hi = (unsigned)(((lane & 15) + 1) * PIXB + (((lane >> 4) ^ (((lane & 15) + 1) & 7)) << 4));
-    auto transform_rows = [&](int slot, int pos0) __attribute__((always_inline)) {
-        int pos = pos0 + wave;
-        pos = pos >= TW_AROWS ? pos - TW_AROWS : pos;
-        const char* const rrow = smem + TW_RAW + slot * TW_RAWSLOTB + wave * TW_RAWROWB;
+    auto transform_row = [&](const char* rrow, int pos) __attribute__((always_inline)) {
         const unsigned a_lo = t_lo, a_hi = t_hi;
         char* const vrow = smem + TW_ARING + pos * TW_AROWB + vlane_c;
         half8 d[2][4];
@@ -213,16 +211,41 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
         }
     };
 
+    auto transform_rows = [&](int slot, int pos0) __attribute__((always_inline)) {
+        int pos = pos0 + wave;
+        pos = pos >= TW_AROWS ? pos - TW_AROWS : pos;
+        transform_row(smem + TW_RAW + slot * TW_RAWSLOTB + wave * TW_RAWROWB, pos);
+    };
+
     // ---- prologue: weights, parameters; A: raw rows of steps 0 and 1, rows of step 0 transformed -----------------
+    // The workgroup's first step gets all six input rows (flag in its entry): the two it would share with a step above are
+    // fetched by waves 0 and 1 into the (still unused) B-ring and transformed into A-ring rows 0 and 1.
+    const uint4 e_first = load_a(0);
+    const bool six = (__builtin_amdgcn_readfirstlane(e_first.y) >> 25) & 1u;
     if (grp == 0) {
-        issue_rows(load_a(0), 0);
+        issue_rows(e_first, 0);
         issue_rows(load_a(1), 1);
+        if (six && wave < 2) {
+            const unsigned lo = __builtin_amdgcn_readfirstlane(e_first.x), hi = __builtin_amdgcn_readfirstlane(e_first.y) & 0xffu;
+            const int pitch = __builtin_amdgcn_readfirstlane(e_first.z);
+            const char* base = a.in_act + (((unsigned long long)hi << 32) | lo) - (size_t)(2 - wave) * pitch;      // rows yA - 1, yA
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                int q = i * 64 + lane;
+                q = q < 272 ? q : 271;
+                const int rec = q >> 3, sl = q & 7, par = rec >= 17 ? 1 : 0, hh = rec - 17 * par;
+                glds16_s(base, (unsigned)((2 * hh + par) * 128 + ((sl ^ (hh & 7)) << 4)), lds0 + TW_BRING + wave * 5120 + i * 1024);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 24; ++i) asm volatile("" : "+v"(w[i]));
-        if (wave == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    group_barrier();                   // every A wave's pieces of step 0 have landed (each waited for its own)
-    if (grp == 1) transform_rows(0, 2);       // (the consumer group fills the A-ring: see its loop)
+    group_barrier();                   // every A wave's pieces have landed (each waited for its own)
+    if (grp == 1) {
+        transform_rows(0, 2);          // (the consumer group fills the A-ring: see its loop)
+        if (six && wave < 2) transform_row(smem + TW_BRING + wave * 5120, wave);
+    }
     group_barrier();
 
     const float* const bias_lds = prm_all + grp * (PARAM_LDS / 4);
@@ -442,10 +465,10 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
             const unsigned ey = __builtin_amdgcn_readfirstlane(e.y), lo = __builtin_amdgcn_readfirstlane(e.x);
             const size_t off = ((unsigned long long)(ey & 0xffu) << 32) | lo;
             const int pitch = __builtin_amdgcn_readfirstlane(e.z);
-            const int vy = (ey >> 8) & 7, vx = (ey >> 11) & 63;
+            const int vy = (ey >> 8) & 7, vx = (ey >> 11) & 63, v0 = (ey >> 17) & 7;
             char* const obase = a.out_act + off + olane;
             const bool colok = col < vx;
-            return [&, obase, pitch, vy, colok](RowSt& st, auto nc, auto kc) __attribute__((always_inline)) {
+            return [&, obase, pitch, vy, v0, colok](RowSt& st, auto nc, auto kc) __attribute__((always_inline)) {
                 constexpr int n = decltype(nc)::value, k = decltype(kc)::value;
                 if constexpr (k == 0) fin_sum(st, n, 0);
                 else if constexpr (k == 1) fin_act(st, 0);
@@ -456,7 +479,7 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
                     const auto y = __builtin_amdgcn_permlane16_swap(st.x1, st.y1, false, false);
                     st.q[0] = x[0]; st.q[1] = y[0]; st.q[2] = x[1]; st.q[3] = y[1];
                 } else if constexpr (k == 5) {
-                    char* dst = (n < vy && colok) ? obase + (size_t)n * pitch : sink;
+                    char* dst = (n >= v0 && n < vy && colok) ? obase + (size_t)n * pitch : sink;
                     *(uint4*)dst = make_uint4(st.q[0], st.q[1], st.q[2], st.q[3]);
                 }
             };
