@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UVA_ABI_VERSION 12  /* 2: + uva_net_submit_u8 / uva_net_collect_u8 / uva_host_alloc / uva_host_free;
+#define UVA_ABI_VERSION 13  /* 2: + uva_net_submit_u8 / uva_net_collect_u8 / uva_host_alloc / uva_host_free;
                                3: + uva_get_gpu_pci_bus_id, uva_debug_trunk2_schedule;
                                4: + uva_denoise_u8, uva_debug_denoise_stage; generic graphs (4x_Valar_v1) load;
                                5: + uva_debug_sub10_rows;
@@ -36,7 +36,8 @@ extern "C" {
                                9: + uva_debug_generic_segments (generic graphs: the fused residual-dense-block kernels);
                                10: + uva_debug_generic_segments_planes (a frame's reference tiles through those kernels in one launch);
                                11: + uva_debug_generic_batches;
-                               12: + uva_debug_trunkw_schedule (trunkw_kernel: fused trunk pairs as Winograd F(2,3)) */
+                               12: + uva_debug_trunkw_schedule (trunkw_kernel: fused trunk pairs as Winograd F(2,3));
+                               13: + uva_denoise_u8_device, uva_denoise_synchronize */
 
 typedef struct uva_net uva_net;
 
@@ -165,10 +166,19 @@ int uva_net_wait_for(uva_net* net, uva_net* producer);
 /* cv2.fastNlMeansDenoisingColored(cv2.UMat(img), None, K, K, 5, 9)   upscale/upscale_processing.py:350-354
  * (apply_denoise; K = 1..30 from `-m n=K`, :782-789): BGR -> 8-bit Lab (linear light), non-local means on L
  * with h_luma and on (a, b) with h_color (template 5, search 9), Lab -> BGR; on HIP device `device`.
- * in / out: host u8 HWC BGR [h][w][3].  OpenCV's integer weighting scheme is reproduced exactly; its 8-bit Lab
- * conversions (fixed-point tables) are replaced by the CIE formulas in fp32 (csrc/uva_denoise.hip.h). */
+ * in / out: host u8 HWC BGR [h][w][3].  OpenCV's integer weighting scheme and its 8-bit fixed-point Lab conversions
+ * (RGB2Lab_b / Lab2RGBinteger: gamma tables, 2^12-scaled matrices, LabCbrtTab_b) are restated from the published 4.x
+ * source (csrc/uva_denoise.hip.h; PARITY UNPINNED: no cv2 in this image to check a constant against). */
 int uva_denoise_u8(int device, const uint8_t* in, int h, int w, size_t in_stride, uint8_t* out, size_t out_stride,
                    float h_luma, float h_color);
+/* The same stage on a frame that is already in HBM (`-m n=K` in front of `-m a` and the 2x / 4x pass without leaving the
+ * GPU: the reference's order, upscale/upscale_processing.py:880-886, 888-909, 913-920): d_in / d_out are device pointers, the
+ * call returns once the work is queued on the stage's own stream.  `after` (may be null): everything that net has been
+ * asked to do so far completes first; `before` (may be null): whatever that net is asked to do from now on waits for this
+ * frame -- the two ends of uva_net_wait_for.  uva_denoise_synchronize waits for the stage's stream on `device`. */
+int uva_denoise_u8_device(int device, const void* d_in, int h, int w, size_t in_stride, void* d_out, size_t out_stride,
+                          float h_luma, float h_color, uva_net* after, uva_net* before);
+int uva_denoise_synchronize(int device);
 /* Test hook: one stage of the above on dense host arrays.  stage 0: BGR -> Lab [h][w][3]; 1: Lab -> BGR;
  * 2: non-local means on a 1-channel image; 3: on a 2-channel image (strength = h). */
 int uva_debug_denoise_stage(int device, int stage, const uint8_t* in, int h, int w, float strength, uint8_t* out);

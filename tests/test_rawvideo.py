@@ -100,10 +100,39 @@ def test_scale_1_without_the_anime_pass_copies_frames_through(tmp_path):
     assert dst.read_bytes() == data[:2 * h * w * 3]
 
 
-def test_cli_rejects_models_that_are_not_on_the_path(capsys):
-    with pytest.raises(SystemExit):
-        rawvideo.main(["-W", "8", "-H", "8", "-m", "r"])
-    assert "weights missing" in capsys.readouterr().err
+def test_cli_checks_the_model_options(capsys, tmp_path):
+    """upscale_video.py -m: a, n=K (K = 1..30), r (x_Valar_v1: scale 4, its .bin a missing blob upstream)"""
+    for argv, msg in ((["-m", "r"], "scale 4 only"), (["-m", "r", "-s", "4", "--model-path", str(tmp_path)], "missing blob"),
+                      (["-m", "n=0"], "between 1 and 30"), (["-m", "n=x"], "integer"), (["-m", "q"], "unknown model option")):
+        with pytest.raises(SystemExit):
+            rawvideo.main(["-W", "8", "-H", "8"] + argv)
+        assert msg in capsys.readouterr().err, argv
+
+
+def test_denoise_stage_keeps_its_place_in_a_lane(monkeypatch):
+    """`-m n=K,a -s 2`: the denoise stage first (the reference's order), frames in order, buffers alive until consumed"""
+    calls = []
+
+    class FakeLib:
+        def uva_denoise_u8(self, gpu, src, h, w, ss, dst, ds, hl, hc):
+            calls.append((gpu, h, w, hl, hc))
+            a = np.ctypeslib.as_array((np.ctypeslib.ctypes.c_uint8 * (h * w * 3)).from_address(src)).reshape(h, w, 3)
+            b = np.ctypeslib.as_array((np.ctypeslib.ctypes.c_uint8 * (h * w * 3)).from_address(dst)).reshape(h, w, 3)
+            b[...] = 255 - a
+            return 0
+    from upscale_video_amd import _lib
+    monkeypatch.setattr(_lib, "load", lambda: FakeLib())
+    monkeypatch.setattr(_lib, "check", lambda rc: None)
+    h, w = 6, 10
+    frames = _frames(9, h, w)
+    fin = io.BytesIO(b"".join(f.tobytes() for f in frames))
+    fout = io.BytesIO()
+    n = rawvideo.stream(fin, fout, h, w, [(("denoise", 3, 7), 0), (FakeNet(1), 0), (FakeNet(2), 32)], alloc=lambda shape: np.zeros(shape, np.uint8))
+    assert n == 9 and calls[0] == (3, h, w, 7.0, 7.0) and len(calls) == 9
+    got = np.frombuffer(fout.getvalue(), np.uint8).reshape(9, 2 * h, 2 * w, 3)
+    for i, f in enumerate(frames):
+        want = np.repeat(np.repeat((255 - f) + 1, 2, 0), 2, 1) + 1
+        assert np.array_equal(got[i], want), i
 
 
 @pytest.mark.gpu
@@ -129,6 +158,24 @@ def test_stream_equals_per_frame_calls(tmp_path):
         assert d.max() <= 3 and (mse == 0 or 10 * np.log10(255.0 ** 2 / mse) >= 48), (i, int(d.max()))
         # ... and, bit for bit, against the synchronous per-frame calls of the same engine
         assert np.array_equal(got[i], net.process_u8(pre.process_u8(f), tile_size=32, border=10)), i
+    # `-m n=3,a -s 2`: denoise -> anime pass -> 2x in the reference's order (upscale_processing.py:880-920), bit for bit the
+    # per-stage calls (the file route's arithmetic: apply_denoise, apply_model, upscale_image) ...
+    from upscale_video_amd import upscale_processing as up
+    dst3 = tmp_path / "out3.bgr24"
+    assert rawvideo.main(["-i", str(src), "-o", str(dst3), "-W", str(w), "-H", str(h), "-s", "2", "-m", "a,n=3", "--tile", "32"]) == 0
+    got3 = np.frombuffer(dst3.read_bytes(), np.uint8).reshape(n, 2 * h, 2 * w, 3)
+    for i, f in enumerate(frames):
+        assert np.array_equal(got3[i], net.process_u8(pre.process_u8(up.denoise_u8(f, 3, device=0)), tile_size=32, border=10)), i
+    # ... and the device-resident form of the same chain (uva_denoise_u8_device queued in front of the 1x net)
+    d_in, d_mid = torch.from_numpy(frames[0]).cuda(), torch.empty((h, w, 3), dtype=torch.uint8, device="cuda")
+    d_mid2, d_out = torch.empty_like(d_mid), torch.empty((2 * h, 2 * w, 3), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    pre.denoise_u8_device(d_in.data_ptr(), h, w, d_mid.data_ptr(), 3)
+    pre.process_u8_device(d_mid.data_ptr(), h, w, d_mid2.data_ptr(), tile_size=0)
+    net.wait_for(pre)
+    net.process_u8_device(d_mid2.data_ptr(), h, w, d_out.data_ptr(), tile_size=32, border=10)
+    net.synchronize()
+    assert np.array_equal(d_out.cpu().numpy(), got3[0])
     # two workers on the one GPU (`-g 0,0`, the reference's duplicate entries): same bytes, same order
     dst2 = tmp_path / "out2.bgr24"
     assert rawvideo.main(["-i", str(src), "-o", str(dst2), "-W", str(w), "-H", str(h), "-s", "2", "-m", "a", "--tile", "32", "-g", "0,0"]) == 0

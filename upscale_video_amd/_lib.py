@@ -6,12 +6,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UVA_LIB_PATH") or os.path.join(_HERE, "libuva.so")   # override: A/B builds
 
 # every symbol include/uva.h declares
-ABI_VERSION = 12  # include/uva.h UVA_ABI_VERSION
+ABI_VERSION = 13  # include/uva.h UVA_ABI_VERSION
 
 SYMBOLS = [
     "uva_get_gpu_count", "uva_get_default_gpu_index", "uva_get_gpu_info", "uva_get_gpu_pci_bus_id",
     "uva_debug_trunk2_schedule", "uva_debug_trunkw_schedule", "uva_debug_sub10_rows", "uva_net_submit_u8_png", "uva_png_workspace_bytes",
-    "uva_png_assemble", "uva_png_deflate_u8", "uva_debug_png_deflate_host", "uva_png_decode_bgr", "uva_debug_zlib_decompress", "uva_net_debug_generic_plan", "uva_debug_generic_segments", "uva_debug_generic_segments_planes", "uva_debug_generic_batches", "uva_denoise_u8", "uva_debug_denoise_stage", "uva_destroy_gpu_instance",
+    "uva_png_assemble", "uva_png_deflate_u8", "uva_debug_png_deflate_host", "uva_png_decode_bgr", "uva_debug_zlib_decompress", "uva_net_debug_generic_plan", "uva_debug_generic_segments", "uva_debug_generic_segments_planes", "uva_debug_generic_batches", "uva_denoise_u8", "uva_denoise_u8_device", "uva_denoise_synchronize", "uva_debug_denoise_stage", "uva_destroy_gpu_instance",
     "uva_net_create", "uva_net_set_device", "uva_net_load_param", "uva_net_load_model",
     "uva_net_destroy", "uva_net_scale", "uva_net_num_features", "uva_net_num_convs",
     "uva_net_extract_f32", "uva_net_process_u8", "uva_net_process_u8_device", "uva_net_synchronize",
@@ -88,6 +88,8 @@ def load():
     decl("uva_debug_trunk2_schedule", [c_i, c_i, c_i, c_i, c_i, c_p, c_sz, psz, c_p, pi, c_p, c_i, pi, pll])
     decl("uva_debug_trunkw_schedule", [c_i, c_i, c_i, c_i, c_i, c_p, c_sz, psz, c_p, pi, c_p, c_i, pi, pll])
     decl("uva_denoise_u8", [c_i, c_p, c_i, c_i, c_sz, c_p, c_sz, ctypes.c_float, ctypes.c_float])
+    decl("uva_denoise_u8_device", [c_i, c_p, c_i, c_i, c_sz, c_p, c_sz, ctypes.c_float, ctypes.c_float, c_p, c_p])
+    decl("uva_denoise_synchronize", [c_i])
     decl("uva_debug_denoise_stage", [c_i, c_i, c_p, c_i, c_i, ctypes.c_float, c_p])
     decl("uva_destroy_gpu_instance", [], "void")
     decl("uva_net_destroy", [c_p], "void")

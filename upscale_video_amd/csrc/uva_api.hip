@@ -2032,6 +2032,8 @@ int denoise_table(DenoiseCtx& c, int which, float h, int cn)
 
 extern "C" {
 
+static int denoise_launch(DenoiseCtx* c, const uint8_t* d_src, size_t src_stride, uint8_t* d_dst, size_t dst_stride, int h, int w);
+
 int uva_denoise_u8(int device, const uint8_t* in, int h, int w, size_t in_stride, uint8_t* out, size_t out_stride,
                    float h_luma, float h_color)
 {
@@ -2044,14 +2046,66 @@ int uva_denoise_u8(int device, const uint8_t* in, int h, int w, size_t in_stride
     if (denoise_ctx(device, px, &c)) return 1;
     if (denoise_table(*c, 0, h_luma, 1) || denoise_table(*c, 1, h_color, 2)) return 1;
     HIP_TRY(hipMemcpy2DAsync(c->d_in, (size_t)w * 3, in, in_stride, (size_t)w * 3, h, hipMemcpyHostToDevice, c->stream));
-    const dim3 rows((w + 255) / 256, h), tiles((w + NLM_BLK - 1) / NLM_BLK, (h + NLM_BLK - 1) / NLM_BLK);
-    hipLaunchKernelGGL(nlm_bgr2lab, rows, dim3(256), 0, c->stream, c->d_in, (size_t)w * 3, h, w, c->d_l, c->d_ab, c->d_lab);
-    hipLaunchKernelGGL(nlm_plane<1>, tiles, dim3(NLM_BLK * NLM_BLK), 0, c->stream, c->d_l, h, w, c->d_table[0], c->table_size[0], c->d_l2);
-    hipLaunchKernelGGL(nlm_plane<2>, tiles, dim3(NLM_BLK * NLM_BLK), 0, c->stream, c->d_ab, h, w, c->d_table[1], c->table_size[1], c->d_ab2);
-    hipLaunchKernelGGL(nlm_lab2bgr, rows, dim3(256), 0, c->stream, c->d_l2, c->d_ab2, h, w, c->d_out, (size_t)w * 3, c->d_lab);
-    HIP_TRY(hipGetLastError());
+    if (denoise_launch(c, c->d_in, (size_t)w * 3, c->d_out, (size_t)w * 3, h, w)) return 1;
     HIP_TRY(hipMemcpy2DAsync(out, out_stride, c->d_out, (size_t)w * 3, (size_t)w * 3, h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// The four kernels of the stage on the context's stream, frame in d_src (strided), result in d_dst (strided)
+static int denoise_launch(DenoiseCtx* c, const uint8_t* d_src, size_t src_stride, uint8_t* d_dst, size_t dst_stride, int h, int w)
+{
+    const dim3 rows((w + 255) / 256, h), tiles((w + NLM_BLK - 1) / NLM_BLK, (h + NLM_BLK - 1) / NLM_BLK);
+    hipLaunchKernelGGL(nlm_bgr2lab, rows, dim3(256), 0, c->stream, d_src, src_stride, h, w, c->d_l, c->d_ab, c->d_lab);
+    hipLaunchKernelGGL(nlm_plane<1>, tiles, dim3(NLM_BLK * NLM_BLK), 0, c->stream, c->d_l, h, w, c->d_table[0], c->table_size[0], c->d_l2);
+    hipLaunchKernelGGL(nlm_plane<2>, tiles, dim3(NLM_BLK * NLM_BLK), 0, c->stream, c->d_ab, h, w, c->d_table[1], c->table_size[1], c->d_ab2);
+    hipLaunchKernelGGL(nlm_lab2bgr, rows, dim3(256), 0, c->stream, c->d_l2, c->d_ab2, h, w, d_dst, dst_stride, c->d_lab);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int uva_denoise_u8_device(int device, const void* d_in, int h, int w, size_t in_stride, void* d_out, size_t out_stride,
+                          float h_luma, float h_color, uva_net* after, uva_net* before)
+{
+    if (!d_in || !d_out || h <= 0 || w <= 0 || (long long)h * w > (1ll << 28)) return fail("bad image");
+    if (in_stride < (size_t)w * 3 || out_stride < (size_t)w * 3) return fail("row stride too small");
+    if (!(h_luma > 0.f) || !(h_color > 0.f)) return fail("denoise strength must be positive");
+    for (uva_net* n : {after, before})
+        if (n) {
+            if (ensure_device(n)) return 1;
+            if (n->device != device) return fail("uva_denoise_u8_device: the net is on another device");
+        }
+    std::lock_guard<std::mutex> lk(g_denoise_mu);
+    DenoiseCtx* c = nullptr;
+    if (denoise_ctx(device, (size_t)h * w, &c)) return 1;
+    // the weight tables are uploaded with a blocking copy: the stream must not be reading the old ones
+    if (c->table_h[0] != h_luma || c->table_h[1] != h_color) HIP_TRY(hipStreamSynchronize(c->stream));
+    if (denoise_table(*c, 0, h_luma, 1) || denoise_table(*c, 1, h_color, 2)) return 1;
+    if (after) {                 // what `after` has been asked to do so far (it wrote d_in, or still reads d_out) comes first
+        hipEvent_t e = take_event(after);
+        if (!e) return 1;
+        HIP_TRY(hipEventRecord(e, after->stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream, e, 0));
+        after->ev_free.push_back(e);
+    }
+    if (denoise_launch(c, (const uint8_t*)d_in, in_stride, (uint8_t*)d_out, out_stride, h, w)) return 1;
+    if (before) {                // ... and whatever `before` is asked to do from now on comes after this frame
+        hipEvent_t e = take_event(before);
+        if (!e) return 1;
+        HIP_TRY(hipEventRecord(e, c->stream));
+        HIP_TRY(hipStreamWaitEvent(before->stream, e, 0));
+        before->ev_free.push_back(e);
+    }
+    return 0;
+}
+
+int uva_denoise_synchronize(int device)
+{
+    std::lock_guard<std::mutex> lk(g_denoise_mu);
+    if (device < 0 || device >= 16) return fail("bad device");
+    if (!g_denoise[device].stream) return 0;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamSynchronize(g_denoise[device].stream));
     return 0;
 }
 

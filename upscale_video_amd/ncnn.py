@@ -215,8 +215,11 @@ class Net:
         if h:
             self._L.uva_net_destroy(h)
 
+    device_index = 0
+
     def set_vulkan_device(self, device_index):
         _lib.check(self._L.uva_net_set_device(self._h, int(device_index)))
+        self.device_index = int(device_index)
 
     blob_names = ("input", "output")     # of the loaded graph (load_param)
 
@@ -333,6 +336,13 @@ class Net:
         _lib.check(self._L.uva_net_process_u8_device(
             self._h, ctypes.c_void_p(d_in), h, w, in_stride or w * 3, ctypes.c_void_p(d_out),
             out_stride or w * s * 3, int(tile_size), int(border)))
+
+    def denoise_u8_device(self, d_in, h, w, d_out, strength, after=None, in_stride=None, out_stride=None):
+        """`-m n=K` on a frame in HBM, queued IN FRONT of this net (include/uva.h uva_denoise_u8_device): everything `after`
+        (a net, or None) has been asked so far comes first, and whatever this net is asked from now on waits for the frame."""
+        _lib.check(self._L.uva_denoise_u8_device(self.device_index, ctypes.c_void_p(d_in), h, w, in_stride or w * 3, ctypes.c_void_p(d_out),
+                                                 out_stride or w * 3, float(strength), float(strength),
+                                                 after._h if after is not None else None, self._h))
 
     def wait_for(self, producer):
         """Device-side ordering: work queued on `producer` so far finishes before this net's next work."""

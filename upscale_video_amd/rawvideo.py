@@ -14,7 +14,8 @@ kernels and D2H copy of consecutive frames overlapped on three streams.  `-m a` 
 anime pass first (1x HurrDeblur, whole frame, re-quantised to u8 exactly like the PNG hop of
 upscale_processing.py:909), then the 2x/4x net with the reference's 960-px tiles.
 
-Flags follow upscale_video.py where they mean the same thing: -s/--scale 1|2|4, -m/--models a,
+Flags follow upscale_video.py where they mean the same thing: -s/--scale 1|2|4, -m/--models a,n=K,r (in the reference's
+order: denoise, anime pass, upscale; upscale/upscale_processing.py:880-920),
 -g/--gpu a list of HIP ordinals, one worker per entry (duplicates allowed): one reader deals the frames
 out round-robin, one writer puts the results out in frame order.
 """
@@ -87,6 +88,37 @@ class Stage:
         return self.net.collect_u8(self.inflight.pop(0))
 
 
+class DenoiseStage:
+    """`-m n=K` (apply_denoise, upscale/upscale_processing.py:350-354) as a stage of a lane: cv2.fastNlMeansDenoisingColored's
+    arithmetic on the lane's GPU (include/uva.h uva_denoise_u8), host frame in, host frame out like the nets' stages -- the call
+    takes about a millisecond per 1080p frame and releases the interpreter lock, the nets behind it keep their frames in flight."""
+
+    class _Scale1:
+        scale = 1
+
+    def __init__(self, gpu, strength, h, w, alloc):
+        self.gpu, self.strength = gpu, float(strength)
+        self.net = self._Scale1()
+        self.outs = [alloc((h, w, 3)) for _ in range(2 * PIPE_DEPTH + 2)]
+        self.n = 0
+        self.inflight = []
+
+    def full(self):
+        return len(self.inflight) >= 1
+
+    def submit(self, frame):
+        from . import _lib
+        out = self.outs[self.n % len(self.outs)]
+        self.n += 1
+        h, w, _ = frame.shape
+        _lib.check(_lib.load().uva_denoise_u8(self.gpu, frame.ctypes.data, h, w, frame.strides[0], out.ctypes.data, out.strides[0],
+                                              self.strength, self.strength))
+        self.inflight.append(out)
+
+    def collect(self):
+        return self.inflight.pop(0)
+
+
 class Lane:
     """The chain of nets of ONE -g entry (one or two Stages on one GPU).  Frames go in with submit() and come out,
     in the order they went in, with pop()."""
@@ -94,6 +126,9 @@ class Lane:
     def __init__(self, nets_tiles, h, w, alloc):
         self.stages = []
         for net, tile in nets_tiles:
+            if isinstance(net, tuple):         # ("denoise", gpu, K): the `-m n=K` stage
+                self.stages.append(DenoiseStage(net[1], net[2], h, w, alloc))
+                continue
             self.stages.append(Stage(net, h, w, tile, alloc))
             h, w = h * net.scale, w * net.scale
         self.count = 0                         # frames inside
@@ -229,7 +264,8 @@ def main(argv=None):
     ap.add_argument("-W", "--width", type=int, required=True)
     ap.add_argument("-H", "--height", type=int, required=True)
     ap.add_argument("-s", "--scale", type=int, default=2, choices=[1, 2, 4])
-    ap.add_argument("-m", "--models", default="", help="'a': 1x HurrDeblur pass first (upscale_video.py -m a)")
+    ap.add_argument("-m", "--models", default="", help="upscale_video.py -m: a = 1x HurrDeblur pass first, n=K = film-grain denoise "
+                                                       "(K 1..30) before everything, r = the x_Valar_v1 model (scale 4, needs its .bin)")
     ap.add_argument("-g", "--gpu", default="0",
                     help="HIP ordinals, one worker per entry, e.g. 0,1,2,3 or 0,0,1 (upscale_video.py -g; default 0)")
     ap.add_argument("--tile", type=int, default=TILE_SIZE, help="reference tile size of the final pass (960); 0 = whole frame")
@@ -238,10 +274,27 @@ def main(argv=None):
     a = ap.parse_args(argv)
     if a.width <= 0 or a.height <= 0:
         ap.error("frame size must be positive")
+    # upscale_video.py -m: a (anime pass), n=K (film-grain denoise, K = 1..30, :782-789), r (the x_Valar_v1 model instead of
+    # x_Compact_Pretrain, :913-916); the reference runs them in the order n, a, upscale (:880-920) whatever the order given
     models = [m for m in a.models.split(",") if m]
+    denoise = None
     for m in models:
-        if m != "a":
-            ap.error("only -m a is available on the MI355X path (r: weights missing upstream; n: OpenCV NLM, host only)")
+        if m.startswith("n="):
+            try:
+                denoise = int(m[2:])
+            except ValueError:
+                ap.error("-m n=K takes an integer K")
+            if not 1 <= denoise <= 30:
+                ap.error("-m n=K: K must be between 1 and 30")
+        elif m not in ("a", "r"):
+            ap.error("unknown model option %r (a, n=K, r)" % m)
+    final_stem = MODEL_FILES[a.scale]
+    if "r" in models:
+        if a.scale != 4:
+            ap.error("-m r: the reference has x_Valar_v1 at scale 4 only (models/4x_Valar_v1.param)")
+        final_stem = "4x_Valar_v1"
+        if not os.path.exists(os.path.join(a.model_path, final_stem + ".bin")):
+            ap.error("-m r: %s.bin is not in %s (a missing blob upstream: supply it with --model-path)" % (final_stem, a.model_path))
     # upscale_video.py: `-m a` runs the 1x HurrDeblur pass (process_model, :888-909), `-s 2|4` the Compact net
     # (upscale_frames, :930-944), and `-s 1` performs NO network pass of its own: its frames are only renamed
     # (:924-929).  So `-s 1` alone copies frames through, `-s 1 -m a` is the HurrDeblur pass alone.
@@ -252,10 +305,12 @@ def main(argv=None):
     nets = []                     # one chain of nets per -g entry
     for gpu in gpus:
         chain = []
+        if denoise is not None:
+            chain.append((("denoise", gpu, denoise), 0))
         if "a" in models:
             chain.append((load_net(MODEL_FILES[1], gpu, a.model_path), 0))          # apply_model: whole frame
         if a.scale != 1:
-            chain.append((load_net(MODEL_FILES[a.scale], gpu, a.model_path), a.tile))
+            chain.append((load_net(final_stem, gpu, a.model_path), a.tile))
         if chain:
             nets.append(chain)
     fin = sys.stdin.buffer if a.input == "-" else open(a.input, "rb")
