@@ -180,3 +180,37 @@ def test_stream_equals_per_frame_calls(tmp_path):
     dst2 = tmp_path / "out2.bgr24"
     assert rawvideo.main(["-i", str(src), "-o", str(dst2), "-W", str(w), "-H", str(h), "-s", "2", "-m", "a", "--tile", "32", "-g", "0,0"]) == 0
     assert dst2.read_bytes() == dst.read_bytes()
+
+
+@pytest.mark.parametrize("nlanes,nframes", [(8, 37), (8, 5), (3, 10), (2, 0)])
+def test_segments_have_their_own_reader_and_writer(tmp_path, nlanes, nframes):
+    """file -> file with several workers: one contiguous segment of frames per lane, every lane on its
+    own file handles and threads -- the bytes of the one-reader route, and no handle or thread shared between lanes"""
+    import threading
+    h, w = 6, 10
+    frames = _frames(nframes, h, w)
+    src, dst = tmp_path / "in.bgr24", tmp_path / "out.bgr24"
+    src.write_bytes(b"".join(f.tobytes() for f in frames))
+    opened = []
+
+    def opener(path, mode):
+        f = open(path, mode)
+        opened.append((str(path), mode, threading.get_ident(), f))
+        return f
+    lanes = [[(FakeNet(1), 0), (FakeNet(2), 32)] for _ in range(nlanes)]
+    n = rawvideo.stream_segments(str(src), str(dst), h, w, lanes, 2, alloc=lambda shape: np.zeros(shape, np.uint8), opener=opener)
+    assert n == nframes
+    got = np.frombuffer(dst.read_bytes(), np.uint8).reshape(nframes, 2 * h, 2 * w, 3)
+    for i, f in enumerate(frames):
+        assert np.array_equal(got[i], np.repeat(np.repeat(f + 1, 2, 0), 2, 1) + 1), i
+    busy = min(nlanes, nframes)        # lanes that got at least one frame
+    readers = [o for o in opened if o[1] == "rb"]
+    writers = [o for o in opened if o[1] == "r+b"]
+    assert len(readers) == len(writers) == busy
+    assert len({o[2] for o in readers}) == busy and len({id(o[3]) for o in readers + writers}) == 2 * busy
+    # the same bytes through ONE reader and ONE writer dealing the frames out round-robin
+    import io
+    fout = io.BytesIO()
+    rawvideo.stream(io.BytesIO(src.read_bytes()), fout, h, w, [[(FakeNet(1), 0), (FakeNet(2), 32)] for _ in range(nlanes)],
+                    alloc=lambda shape: np.zeros(shape, np.uint8))
+    assert fout.getvalue() == dst.read_bytes()

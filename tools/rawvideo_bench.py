@@ -24,6 +24,18 @@ for args in (["-s", "2"], ["-s", "2", "-g", "0,0"], ["-s", "2", "-m", "a"], ["-s
     t1 = wall(base + args + ["-i", src, "-o", "/dev/null", "--frames", "1"])
     tn = wall(base + args + ["-i", src, "-o", "/dev/null"])
     print(f"{' '.join(args):20s} file -> /dev/null : {N} frames in {tn:6.2f} s (start-up {t1:5.2f} s) = {(N - 1) / (tn - t1):7.1f} frames/s")
+# file -> FILE with several workers: one segment of frames, reader and writer per worker (stream_segments) against the
+# one-reader / one-writer round-robin route on the same files; the output is a real file in /dev/shm (page cache)
+dst = "/dev/shm/uva_out.bgr24"
+free = os.statvfs("/dev/shm").f_bavail * os.statvfs("/dev/shm").f_frsize
+M = max(8, min(N, int(free * 0.6) // (2160 * 3840 * 3)))
+for args in (["-s", "2", "-g", "0,0"], ["-s", "2", "-g", "0,0", "--round-robin"], ["-s", "2", "-g", "0,0,0,0"],
+             ["-s", "2", "-g", "0,0,0,0", "--round-robin"], ["-s", "2", "-g", "0,0,0,0,0,0,0,0"]):
+    t1 = wall(base + args + ["-i", src, "-o", dst, "--frames", str(len(args[3].split(",")))])
+    tn = wall(base + args + ["-i", src, "-o", dst, "--frames", str(M)])
+    k = len(args[3].split(","))
+    print(f"{' '.join(args):34s} file -> file      : {M} frames in {tn:6.2f} s (start-up {t1:5.2f} s) = {(M - k) / (tn - t1):7.1f} frames/s")
+    os.remove(dst)
 t1 = wall(base + ["-s", "2", "-i", src, "-o", "/dev/null", "--frames", "1"])
 tn = wall(f"cat {src} | {' '.join(base)} -s 2 2>/dev/null | cat > /dev/null", shell=True)
 print(f"-s 2         pipe -> pipe      : {N} frames in {tn:6.2f} s = {(N - 1) / (tn - t1):7.1f} frames/s")

@@ -16,8 +16,10 @@ upscale_processing.py:909), then the 2x/4x net with the reference's 960-px tiles
 
 Flags follow upscale_video.py where they mean the same thing: -s/--scale 1|2|4, -m/--models a,n=K,r (in the reference's
 order: denoise, anime pass, upscale; upscale/upscale_processing.py:880-920),
--g/--gpu a list of HIP ordinals, one worker per entry (duplicates allowed): one reader deals the frames
-out round-robin, one writer puts the results out in frame order.
+-g/--gpu a list of HIP ordinals, one worker per entry (duplicates allowed).  Pipes: one reader deals the frames
+out round-robin, one writer puts the results out in frame order.  File to file: one contiguous segment of frames per
+entry, each with its own reader, chain of nets and writer on its own file handles (stream_segments) -- no shared serial
+copy, so the route scales with the GPUs.
 """
 import argparse
 import os
@@ -230,6 +232,46 @@ def stream(fin, fout, h, w, nets_tiles, alloc=None, max_frames=None):
     return written
 
 
+def stream_segments(in_path, out_path, h, w, lanes_spec, scale_total, max_frames=None, alloc=None, opener=open):
+    """The same frames -> the same bytes as stream(), for a regular input FILE and a regular output FILE, with NO shared
+    serial copy: the frames are cut into one contiguous segment per `-g` entry (the reference's batches,
+    upscale/upscale_processing.py:923-948, are such segments) and every entry runs its own stream() -- its own reader, its own
+    pipelined chain of nets, its own writer thread -- on its own file handles, reading at its segment's offset and writing at
+    the offset its results belong to.  One reader and one writer thread copy ~10 GB/s each, two or three GPUs' worth of
+    1080p -> 4K frames; N independent pairs scale with the lanes.  Returns the number of frames written."""
+    fb_in, fb_out = h * w * 3, h * scale_total * w * scale_total * 3
+    total = os.path.getsize(in_path) // fb_in
+    if os.path.getsize(in_path) % fb_in:
+        raise EOFError("input ends inside a frame (%d bytes, frames of %d)" % (os.path.getsize(in_path), fb_in))
+    if max_frames is not None:
+        total = min(total, max_frames)
+    nl = len(lanes_spec)
+    with opener(out_path, "wb") as f:           # the output exists at its full size before anybody writes into it
+        f.truncate(total * fb_out)
+    bounds = [total * k // nl for k in range(nl + 1)]
+    done, errs = [0] * nl, []
+
+    def work(k):
+        try:
+            first, count = bounds[k], bounds[k + 1] - bounds[k]
+            if count == 0:
+                return
+            with opener(in_path, "rb") as fin, opener(out_path, "r+b") as fout:
+                fin.seek(first * fb_in)
+                fout.seek(first * fb_out)
+                done[k] = stream(fin, fout, h, w, lanes_spec[k], alloc=alloc, max_frames=count)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    threads = [threading.Thread(target=work, args=(k,), daemon=True) for k in range(nl)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errs:
+        raise errs[0]
+    return sum(done)
+
+
 def grow_pipe(f):
     """A frame is 6-100 MB and a pipe holds 64 KiB by default: ask for the largest buffer the system gives an
     unprivileged process (/proc/sys/fs/pipe-max-size, usually 1 MiB) -- 16 times fewer wake-ups per frame."""
@@ -270,6 +312,9 @@ def main(argv=None):
                     help="HIP ordinals, one worker per entry, e.g. 0,1,2,3 or 0,0,1 (upscale_video.py -g; default 0)")
     ap.add_argument("--tile", type=int, default=TILE_SIZE, help="reference tile size of the final pass (960); 0 = whole frame")
     ap.add_argument("--frames", type=int, default=None, help="stop after this many frames")
+    ap.add_argument("--round-robin", action="store_true",
+                    help="file to file with several -g entries: deal the frames out one by one through ONE reader and ONE writer "
+                         "(what pipes get) instead of one contiguous segment of frames, reader and writer per entry")
     ap.add_argument("--model-path", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "models"))
     a = ap.parse_args(argv)
     if a.width <= 0 or a.height <= 0:
@@ -313,6 +358,16 @@ def main(argv=None):
             chain.append((load_net(final_stem, gpu, a.model_path), a.tile))
         if chain:
             nets.append(chain)
+    # file -> file with several workers: one contiguous segment of frames per worker, each with its own reader and writer
+    if nets and len(nets) > 1 and not a.round_robin and a.input != "-" and a.output != "-" and os.path.isfile(a.input) and \
+            (not os.path.exists(a.output) or os.path.isfile(a.output)):
+        scale_total = 1
+        for net, _ in nets[0]:
+            scale_total *= 1 if isinstance(net, tuple) else net.scale
+        n = stream_segments(a.input, a.output, a.height, a.width, nets, scale_total, max_frames=a.frames)
+        print("%d frames" % n, file=sys.stderr)
+        ncnn.destroy_gpu_instance()
+        return 0
     fin = sys.stdin.buffer if a.input == "-" else open(a.input, "rb")
     fout = sys.stdout.buffer if a.output == "-" else open(a.output, "wb")
     for f in (fin, fout):
