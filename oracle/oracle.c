@@ -55,6 +55,9 @@ enum {
                             as fused pairs are evaluated as 1-D Winograd F(2,3) along x with the kernel's
                             rounding points (trunkw_kernel, csrc/uva_wino.hip.h): transformed inputs and
                             transformed weights rounded to fp16, products and sums in fp32 */
+    UVO_PRELU_F16 = 8,   /* with UVO_WINOGRAD_F23: the PReLU behind such a convolution on fp16 values, as trunkw_kernel's
+                            TW_ACT_F16 modes do it (csrc/uva_wino.h): the sum rounded to fp16, times the slope rounded to
+                            fp16, product rounded to fp16, then max (slope <= 1) or min (slope > 1) of the two */
 };
 
 typedef enum {
@@ -538,6 +541,24 @@ static void prelu(const layer* L, blob* b, int f16)
     }
 }
 
+/* the same PReLU the way trunkw_kernel evaluates it on packed halves (UVO_PRELU_F16): x16 = f16(x), m = f16(x16 * f16(s)),
+ * max(x16, m) for s <= 1 and min(x16, m) for s > 1 -- PReLU in both cases, with two roundings instead of one for x < 0.
+ * (The kernel computes a channel with s > 1 negated and takes max as well: -max(-x16, -m) = min(x16, m), every step exact.) */
+static void prelu_f16(const layer* L, blob* b)
+{
+    const size_t hw = (size_t)b->h * b->w;
+    for (int c = 0; c < b->c; ++c) {
+        const float s = L->num_slope > 1 ? L->slope[c] : L->slope[0];
+        const float s16 = uvo_round_f16(s);
+        float* p = b->d + (size_t)c * hw;
+        for (size_t i = 0; i < hw; ++i) {
+            const float x = uvo_round_f16(p[i]);
+            const float m = uvo_round_f16(x * s16);     /* (the product of two halves is exact in fp32: one rounding) */
+            p[i] = s <= 1.f ? (x > m ? x : m) : (x < m ? x : m);
+        }
+    }
+}
+
 /* ncnn pixelshuffle.cpp mode 0: out[c][h*r+i][w*r+j] = in[c*r*r + i*r + j][h][w] */
 static void pixelshuffle(const layer* L, const blob* in, blob* out)
 {
@@ -588,7 +609,7 @@ static int run_graph(const uvo_model* m, const float* in_chw, int h, int w, int 
 {
     const int f16 = (flags & UVO_F16_STORAGE) != 0;
     blob* bl = (blob*)calloc((size_t)m->nlayers * 2 + 4, sizeof(blob));
-    int nb = 0, rc = -1, convs = 0, tapped = 0;
+    int nb = 0, rc = -1, convs = 0, tapped = 0, last_wino = 0;
     blob* result = NULL;
     for (int i = 0; i < m->nlayers && !tapped; ++i) {
         const layer* L = &m->L[i];
@@ -622,10 +643,13 @@ static int run_graph(const uvo_model* m, const float* in_chw, int h, int w, int 
              * through the direct kernel (uva_api.hip run_graph) */
             const int second = convs + (convs & 1);
             if (f16 && (flags & UVO_WINOGRAD_F23) && m->nf == 64 && L->kernel == 3 && L->cin == 64 && L->num_output == 64 &&
-                convs >= 1 && second <= m->nconv - 2 && (tap_conv < 0 || second <= tap_conv))
+                convs >= 1 && second <= m->nconv - 2 && (tap_conv < 0 || second <= tap_conv)) {
                 conv2d_wino_f23(L, a, o, (convs & 1) ? -1 : 0, nthreads);
-            else
-            conv2d(L, f16 ? L->w16 : L->w, a, o, nthreads);
+                last_wino = 1;
+            } else {
+                conv2d(L, f16 ? L->w16 : L->w, a, o, nthreads);
+                last_wino = 0;
+            }
             free(a->d); a->d = NULL;
             if (convs == tap_conv && !(i + 1 < m->nlayers && m->L[i + 1].type == L_PRELU)) {
                 result = o; tapped = 1;
@@ -634,7 +658,8 @@ static int run_graph(const uvo_model* m, const float* in_chw, int h, int w, int 
             break;
         }
         case L_PRELU: { /* in-place in ncnn as well */
-            prelu(L, a, f16);
+            if (last_wino && (flags & UVO_PRELU_F16)) prelu_f16(L, a);
+            else prelu(L, a, f16);
             snprintf(a->name, UVO_NAME, "%s", L->out[0]);
             if (convs - 1 == tap_conv) { result = a; tapped = 1; }
             break;

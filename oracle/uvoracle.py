@@ -18,14 +18,16 @@ _SO = os.path.join(_HERE, "_build", "liboracle.so")
 F16_STORAGE = 1
 F16_INPUT = 4        # with F16_STORAGE: the float route rounds the caller's normalised input to fp16
 WINOGRAD_F23 = 2     # with F16_STORAGE: fused trunk pairs as 1-D Winograd F(2,3) with the HIP kernel's rounding points
+PRELU_F16 = 8        # with WINOGRAD_F23: the PReLU behind those convolutions on fp16 values (trunkw_kernel's TW_ACT_F16 modes)
 
 
 def product_flags(route="u8"):
     """The storage mode that restates the HIP path's rounding points: fp16 storage, and -- unless the product is run with
     UVA_TRUNK_WINO=0 (direct convolution, trunk2_kernel) or UVA_TRUNK_FUSION=0 -- the fused 64 -> 64 trunk pairs as
-    Winograd F(2,3) (trunkw_kernel).  No effect on the 24-feature net."""
+    Winograd F(2,3) (trunkw_kernel) with their PReLU on fp16 values (unless UVA_TW_ACT16=0).  No effect on the 24-feature net."""
     wino = os.environ.get("UVA_TRUNK_WINO", "1") != "0" and os.environ.get("UVA_TRUNK_FUSION", "1") != "0"
-    return F16_STORAGE | (WINOGRAD_F23 if wino else 0) | (F16_INPUT if route == "f32" else 0)
+    act16 = wino and os.environ.get("UVA_TW_ACT16", "1") != "0"
+    return F16_STORAGE | (WINOGRAD_F23 if wino else 0) | (PRELU_F16 if act16 else 0) | (F16_INPUT if route == "f32" else 0)
 
 
 def build(force=False):

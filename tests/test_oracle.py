@@ -195,3 +195,25 @@ def test_chain_1x_then_2x_is_quantised_between(oracle_models, oracle):
     assert mid.dtype == np.uint8 and mid.shape == img.shape
     out = oracle_models["2x"].upscale_image(mid)
     assert out.shape == (48, 80, 3)
+
+
+@pytest.mark.parametrize("key", ["2x", "4x"])
+def test_prelu_on_halves_mode(oracle_models, oracle, key):
+    """UVO_PRELU_F16 (the product's trunkw_kernel applies PReLU to the sum rounded to fp16): against the one-rounding PReLU of
+    the same Winograd convolution, an activation changes by at most one fp16 step, and only where it is the product
+    slope * x (x < 0): the first layer of the first fused pair, whose input is the same in both modes, shows it directly --
+    the 4x net has slopes above 1 (min instead of max) among them."""
+    m = oracle_models[key]
+    x = oracle.from_pixels_normalize(oracle.synthetic_frame(20, 24, seed=5))
+    base = oracle.F16_STORAGE | oracle.WINOGRAD_F23
+    a = m.tap(x, 2, flags=base)                       # taps at the second layer of a pair: both layers ran as Winograd
+    pre1 = m.tap(x, 1, flags=oracle.F16_STORAGE)      # (layer 1 alone, direct: the same input for both modes' layer 2)
+    b = m.tap(x, 2, flags=base | oracle.PRELU_F16)
+    assert a.shape == b.shape == pre1.shape
+    ulp = np.spacing(np.abs(a).astype(np.float16)).astype(np.float32)
+    # two layers deep a one-step difference of layer 1 has passed through layer 2's sums: a few steps, not more
+    assert np.abs(a - b).max() <= 8 * ulp.max()
+    assert np.mean(a != b) < 0.5
+    # and the two modes agree closely as images of the net
+    out_a, out_b = m.forward(x, flags=base), m.forward(x, flags=base | oracle.PRELU_F16)
+    assert np.abs(out_a - out_b).max() < 2e-2

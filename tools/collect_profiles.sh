@@ -16,7 +16,7 @@ cp "$OUT"/stats/p_kernel_stats.csv "$OUT/${TAG}_kernel_stats_rocprofv3.csv" 2>/d
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o p -- $B --steps 4 --warmup 2 > "$OUT/pmc_fetch.log" 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o p -- $B --steps 4 --warmup 2 > "$OUT/pmc_write.log" 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq" -o p -- $B --steps 4 --warmup 2 > "$OUT/pmc_sq.log" 2>&1
-python "$REPO/tools/summarize_pmc.py" "$OUT" "$TAG" "${KERNEL:-trunk2_kernel<64>}" > "$OUT/${TAG}_trunk_pmc.json"
+python "$REPO/tools/summarize_pmc.py" "$OUT" "$TAG" "${KERNEL:-trunkw_kernel<64}" > "$OUT/${TAG}_trunk_pmc.json"
 (cd "$REPO" && python bench.py --steps 100 --warmup 10 > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err")
 # keep the merge-back small: only the summaries travel
 rm -rf "$OUT"/stats "$OUT"/pmc_fetch/*kernel_trace* "$OUT"/pmc_write/*kernel_trace* "$OUT"/pmc_sq/*kernel_trace*

@@ -108,6 +108,8 @@ struct Workspace {
 struct DeviceLayer {
     half8* wpk = nullptr;
     half8* wpk_w = nullptr;   // 64 -> 64 trunk layers: pack_trunk64_wino image for trunkw_kernel
+    float* bias_w = nullptr;  // ... and its bias, negated for the channels trunkw_kernel computes negated (uva_wino.h TW_ACT_F16)
+    bool flip_w = false;      // ... which this layer has (a PReLU slope above 1)
     half8* wpk16 = nullptr;   // tail layer of the 64-feature 2x / 4x nets: pack_tail64 image for tail_kernel / tail4_kernel
     half8* wpk_s10 = nullptr; // 24-feature 1x net: pack_sub16 image for sub10_kernel, with its own (sign-folded) bias
     float* bias_s10 = nullptr;
@@ -153,6 +155,7 @@ struct uva_net {
     bool generic_lds_conv = true; // generic graphs: 3x3 convolutions through g_conv3_lds (UVA_GENERIC_LDS=0: the plain g_conv<3>)
     bool fuse_all = true;         // 24-feature 1x net: all ten convolutions in one launch (sub10_kernel); UVA_SUB10=0 turns it off
     bool fuse_pairs = true;       // 64-feature nets: trunk layers run two per launch (trunk2_kernel); UVA_TRUNK_FUSION=0 turns it off
+    bool act16 = true;            // trunkw_kernel: PReLU on packed fp16 (uva_wino.h TW_ACT_F16); UVA_TW_ACT16=0: on the fp32 sums
     bool wino = true;             // ... as 1-D Winograd F(2,3) (trunkw_kernel); UVA_TRUNK_WINO=0: trunk2_kernel (direct convolution)
     LastCall last;
     // pipelined host route (uva_net_submit_u8 / uva_net_collect_u8): H2D, kernels and D2H of
@@ -198,6 +201,7 @@ struct uva_net {
         for (auto& l : layers) {
             if (l.wpk) (void)hipFree(l.wpk);
             if (l.wpk_w) (void)hipFree(l.wpk_w);
+            if (l.bias_w) (void)hipFree(l.bias_w);
             if (l.wpk16) (void)hipFree(l.wpk16);
             if (l.wpk_s10) (void)hipFree(l.wpk_s10);
             if (l.bias_s10) (void)hipFree(l.bias_s10);
@@ -597,9 +601,16 @@ int build_trunkw_schedule(const std::vector<PlaneDesc>& planes, int grid, size_t
     return 0;
 }
 
-int launch_trunkw(uva_net* n, const Workspace* ws, const TrunkwArgs& a)
+// layers i, i + 1 of the net in one trunkw_kernel launch
+int launch_trunkw(uva_net* n, const Workspace* ws, TrunkwArgs& a, int i)
 {
-    HIP_TRY(launch_trunkw_kernel(n->stream, ws->grid2, a));
+    for (int k = 0; k < 2; ++k) {
+        a.wpk[k] = n->layers[i + k].wpk_w;
+        a.bias[k] = n->act16 ? n->layers[i + k].bias_w : n->layers[i + k].bias;
+        a.slope[k] = n->layers[i + k].slope;
+    }
+    const int act = !n->act16 ? TW_ACT_F32 : n->layers[i + 1].flip_w ? TW_ACT_F16_FLIP : TW_ACT_F16;
+    HIP_TRY(launch_trunkw_kernel(n->stream, ws->grid2, a, act));
     return 0;
 }
 
@@ -743,6 +754,7 @@ int ensure_device(uva_net* n)
     HIP_TRY(hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking));
     if (const char* e = std::getenv("UVA_TRUNK_FUSION")) n->fuse_pairs = std::atoi(e) != 0;
     if (const char* e = std::getenv("UVA_TRUNK_WINO")) n->wino = std::atoi(e) != 0;
+    if (const char* e = std::getenv("UVA_TW_ACT16")) n->act16 = std::atoi(e) != 0;
     if (const char* e = std::getenv("UVA_SUB10")) n->fuse_all = std::atoi(e) != 0;
     if (const char* e = std::getenv("UVA_GENERIC_LDS")) n->generic_lds_conv = std::atoi(e) != 0;
     if (const char* e = std::getenv("UVA_GENERIC_FUSE_ADD")) n->generic_fuse_add = std::atoi(e) != 0;
@@ -793,8 +805,23 @@ int ensure_device(uva_net* n)
         if (upload(&dl.wpk, pk.data(), pk.size() * 2, n->stream)) return 1;
         std::vector<uint16_t> pkw;
         if (g.nf == 64 && i > 0 && i + 1 < g.convs.size()) {
-            pack_trunk64_wino(g.convs[i], pkw);
+            // Pairs are (1, 2), (3, 4), ...: an odd layer is the first of its launch.  With the PReLU on packed fp16 a channel
+            // whose slope exceeds 1 is computed negated (uva_wino.h): the first layer's stay so on their way through LDS into
+            // the second layer (in_sign), the second layer's get their sign back in front of the stores.
+            std::vector<float> sin(64, 1.f), sout(64, 1.f), bw(64, 0.f);
+            if (n->act16) {
+                if (!(i & 1))
+                    for (int c = 0; c < 64; ++c) sin[c] = g.slopes[i - 1][c] > 1.f ? -1.f : 1.f;
+                for (int c = 0; c < 64; ++c) {
+                    sout[c] = g.slopes[i][c] > 1.f ? -1.f : 1.f;
+                    dl.flip_w = dl.flip_w || sout[c] < 0.f;
+                }
+            }
+            for (int c = 0; c < 64; ++c) bw[c] = sout[c] * g.convs[i].bias[c];
+            pack_trunk64_wino(g.convs[i], pkw, sin.data(), sout.data());
             if (upload(&dl.wpk_w, pkw.data(), pkw.size() * 2, n->stream)) return 1;
+            if (upload(&dl.bias_w, bw.data(), bw.size() * 4, n->stream)) return 1;
+            HIP_TRY(hipStreamSynchronize(n->stream));
         }
         std::vector<uint16_t> pk16;
         if (g.nf == 64 && (g.scale == 2 || g.scale == 4) && i + 1 == g.convs.size()) {
@@ -1136,16 +1163,11 @@ int run_graph(uva_net* n, Workspace* ws, bool f32, const void* src, size_t src_s
             std::memset(&wa, 0, sizeof wa);
             wa.in_act = ws->act_base[cur];
             wa.out_act = ws->act_base[cur ^ 1];
-            for (int k = 0; k < 2; ++k) {
-                wa.wpk[k] = n->layers[i + k].wpk_w;
-                wa.bias[k] = n->layers[i + k].bias;
-                wa.slope[k] = n->layers[i + k].slope;
-            }
             wa.steps = ws->d_stepsw;
             wa.nsteps = ws->d_nstepsw;
             wa.max_steps = ws->max_stepsw;
             wa.sink = n->d_sink;
-            if (launch_trunkw(n, ws, wa)) return 1;
+            if (launch_trunkw(n, ws, wa, i)) return 1;
             ++ev.ntrunk;
             ++i;
             cur ^= 1;
@@ -2788,15 +2810,14 @@ int uva_net_debug_trunk_stamps(uva_net* n, unsigned long long* out, int max_tile
         std::memset(&wa, 0, sizeof wa);
         wa.in_act = ws->act_base[0];
         wa.out_act = ws->act_base[1];
-        for (int k = 0; k < 2; ++k) { wa.wpk[k] = n->layers[1 + k].wpk_w; wa.bias[k] = n->layers[1 + k].bias; wa.slope[k] = n->layers[1 + k].slope; }
         wa.steps = ws->d_stepsw; wa.nsteps = ws->d_nstepsw; wa.max_steps = ws->max_stepsw; wa.sink = n->d_sink;
         if (2 * (ws->max_stepsw + 3) + 1 > max_tiles) { (void)hipFree(d); return fail("max_tiles too small"); }
-        int rc8 = launch_trunkw(n, ws, wa);
+        int rc8 = launch_trunkw(n, ws, wa, 1);
         HIP_TRY(hipEventRecord(e0, n->stream));
-        for (int r = 0; r < 50 && !rc8; ++r) rc8 = launch_trunkw(n, ws, wa);
+        for (int r = 0; r < 50 && !rc8; ++r) rc8 = launch_trunkw(n, ws, wa, 1);
         HIP_TRY(hipEventRecord(e1, n->stream));
         wa.dbg = d;
-        if (!rc8) rc8 = launch_trunkw(n, ws, wa);
+        if (!rc8) rc8 = launch_trunkw(n, ws, wa, 1);
         if (!rc8) {
             HIP_TRY(hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, n->stream));
             HIP_TRY(hipStreamSynchronize(n->stream));

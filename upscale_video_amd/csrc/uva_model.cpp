@@ -270,7 +270,7 @@ void pack_trunk64(const ConvWeights& c, std::vector<uint16_t>& out)
             }
 }
 
-void pack_trunk64_wino(const ConvWeights& c, std::vector<uint16_t>& out)
+void pack_trunk64_wino(const ConvWeights& c, std::vector<uint16_t>& out, const float* in_sign, const float* out_sign)
 {
     out.assign((size_t)4 * 3 * 2 * 4 * 64 * 8, 0);
     for (int j = 0; j < 4; ++j)
@@ -284,7 +284,8 @@ void pack_trunk64_wino(const ConvWeights& c, std::vector<uint16_t>& out)
                             const float* g = &c.w[((size_t)co * 64 + ci) * 9 + 3 * dy];
                             const double g0 = g[0], g1 = g[1], g2 = g[2];
                             const float u = j == 0 ? g[0] : j == 1 ? (float)(0.5 * (g0 + g1 + g2)) : j == 2 ? (float)(0.5 * (g0 - g1 + g2)) : g[2];
-                            out[((((((size_t)j * 3 + dy) * 2 + ch) * 4 + mb) * 64) + lane) * 8 + e] = f32_to_f16_bits(u);
+                            const float sg = (in_sign ? in_sign[ci] : 1.f) * (out_sign ? out_sign[co] : 1.f);       // (+-1: exact)
+                            out[((((((size_t)j * 3 + dy) * 2 + ch) * 4 + mb) * 64) + lane) * 8 + e] = f32_to_f16_bits(sg * u);
                         }
                     }
 }

@@ -48,7 +48,10 @@ void pack_trunk64(const ConvWeights& c, std::vector<uint16_t>& out);
 // (g0, g1, g2 = that row's three taps, taken at full precision; one rounding to fp16 at the end):
 //   U0 = g0   U1 = (g0 + g1 + g2) / 2   U2 = (g0 - g1 + g2) / 2   U3 = g2
 // lanes as in pack_trunk64.  The CPU checker (conv2d_wino_f23, test side) spells the same expressions.
-void pack_trunk64_wino(const ConvWeights& c, std::vector<uint16_t>& out);
+// in_sign[64] / out_sign[64] (+1 / -1, may be null): the layer computed on negated input channels / computing negated
+// output channels -- how trunkw_kernel's packed-fp16 PReLU max(x, slope * x) serves channels whose slope exceeds 1
+// (max(-x, -slope * x) = -PReLU(x), every step exact; see pack_sub16).
+void pack_trunk64_wino(const ConvWeights& c, std::vector<uint16_t>& out, const float* in_sign = nullptr, const float* out_sign = nullptr);
 // tail_kernel<64, R> (v_mfma_f32_16x16x32_f16, cin = 64, cout = 3*R*R padded to a multiple of 16):
 // image [18 k-steps][MB = ceil(cout/16) blocks][64 lanes][8] fp16, lanes and k-steps as pack_trunk64.
 void pack_tail64(const ConvWeights& c, std::vector<uint16_t>& out);

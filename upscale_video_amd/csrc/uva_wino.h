@@ -26,7 +26,16 @@ struct TrunkwArgs {
                                   // 3: phase Y work done, 4: (A) the epilogue's ring writes done}], entry time at [16 * niter]
 };
 
-// One launch of trunkw_kernel<64> on `grid` workgroups.  Returns hipSuccess or the failing call's error.
-hipError_t launch_trunkw_kernel(hipStream_t stream, int grid, const TrunkwArgs& a);
+// How a launch applies PReLU (bias and slopes of both layers as float arrays either way):
+//   TW_ACT_F32     on the fp32 sums, v_med3_f32(x, slope * x, +-inf), then one rounding to fp16 (trunk2_kernel's way)
+//   TW_ACT_F16     sums rounded to fp16 first, then max(x, slope16 * x) on packed halves (4 instructions fewer per block row
+//                  and group).  That IS PReLU for slope <= 1; a channel with a larger slope must arrive NEGATED (weights and
+//                  bias of its layer packed with out_sign -1, the next layer's with in_sign -1: uva_model.h) ...
+//   TW_ACT_F16_FLIP ... which for the FIRST layer of a launch stays inside the launch; the second layer's negated channels
+//                  (those whose slope[1] exceeds 1) get their sign back in front of the stores to HBM.
+enum { TW_ACT_F32 = 0, TW_ACT_F16 = 1, TW_ACT_F16_FLIP = 2 };
+
+// One launch of trunkw_kernel<64, act> on `grid` workgroups.  Returns hipSuccess or the failing call's error.
+hipError_t launch_trunkw_kernel(hipStream_t stream, int grid, const TrunkwArgs& a, int act);
 
 }  // namespace uva

@@ -4,9 +4,10 @@
 
 namespace uva {
 
-hipError_t launch_trunkw_kernel(hipStream_t stream, int grid, const TrunkwArgs& a)
+template <int ACT>
+static hipError_t launch_act(hipStream_t stream, int grid, const TrunkwArgs& a)
 {
-    auto kfn = trunkw_kernel<64>;
+    auto kfn = trunkw_kernel<64, ACT>;
     static bool attr_done[64] = {false};          // per device: the kernel's 158.5 KB of dynamic LDS must be allowed once
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -18,6 +19,16 @@ hipError_t launch_trunkw_kernel(hipStream_t stream, int grid, const TrunkwArgs& 
     }
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), TW_LDS_BYTES, stream, a);
     return hipGetLastError();
+}
+
+hipError_t launch_trunkw_kernel(hipStream_t stream, int grid, const TrunkwArgs& a, int act)
+{
+    switch (act) {
+    case TW_ACT_F32: return launch_act<TW_ACT_F32>(stream, grid, a);
+    case TW_ACT_F16: return launch_act<TW_ACT_F16>(stream, grid, a);
+    case TW_ACT_F16_FLIP: return launch_act<TW_ACT_F16_FLIP>(stream, grid, a);
+    }
+    return hipErrorInvalidValue;
 }
 
 }  // namespace uva

@@ -108,13 +108,16 @@ __device__ __forceinline__ unsigned pk_add_f16(unsigned a, unsigned b)
 #define TW_STAMP(k) do { } while (0)
 #endif
 
-template <int NF>
+template <int NF, int ACT>
 __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
 {
     static_assert(NF == 64, "written for 64 features");
     constexpr int PIXB = 128;
 #ifndef TW_PFF
 #define TW_PFF 6
+#endif
+#ifndef TW_XA
+#define TW_XA 0               // raw rows of a step transformed by the PRODUCER group (0, 2 or 4; the consumers take the rest)
 #endif
 #ifndef TW_INROWS
 #define TW_INROWS 0           // rows of a block whose epilogue slices run inside the k-loop (A/B builds: 0..3)
@@ -209,6 +212,25 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
             *(half8*)(vrow + 2 * 2048 + t * 1024) = pk_sub(d[t][2], d[t][1]);
             *(half8*)(vrow + 3 * 2048 + t * 1024) = pk_sub(d[t][1], d[t][3]);
         }
+    };
+
+    // half a row (octet half t): the unit of work when both groups share a step's four rows (TW_XA = 2)
+    auto transform_half = [&](const char* rrow, int pos, int t) __attribute__((always_inline)) {
+        const unsigned a_lo = t_lo ^ (t ? 64u : 0u), a_hi = t_hi ^ (t ? 64u : 0u);
+        char* const vrow = smem + TW_ARING + pos * TW_AROWB + vlane_c + t * 1024;
+        const half8 d0 = *(const half8*)(rrow + a_lo), d1 = *(const half8*)(rrow + a_lo + 17 * PIXB);
+        const half8 d2 = *(const half8*)(rrow + a_hi), d3 = *(const half8*)(rrow + a_hi + 17 * PIXB);
+        *(half8*)(vrow + 0 * 2048) = pk_sub(d0, d2);
+        *(half8*)(vrow + 1 * 2048) = d1 + d2;
+        *(half8*)(vrow + 2 * 2048) = pk_sub(d2, d1);
+        *(half8*)(vrow + 3 * 2048) = pk_sub(d1, d3);
+    };
+    // rows [2 first_pair, 2 first_pair + 2) of the slot: wave w takes half (w & 1) of row 2 first_pair + (w >> 1)
+    auto transform_pair = [&](int slot, int pos0, int first_pair) __attribute__((always_inline)) {
+        const int r = 2 * first_pair + (wave >> 1);
+        int pos = pos0 + r;
+        pos = pos >= TW_AROWS ? pos - TW_AROWS : pos;
+        transform_half(smem + TW_RAW + slot * TW_RAWSLOTB + r * TW_RAWROWB, pos, wave & 1);
     };
 
     auto transform_rows = [&](int slot, int pos0) __attribute__((always_inline)) {
@@ -323,7 +345,18 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
         st.u = (m0 + m1) + m2;
         st.v = __builtin_elementwise_fma(m3, neg1, __builtin_elementwise_fma(m2, neg1, m1));
     };
+    // TW_ACT_F16*: the slopes of the lane's four channels as packed halves
+    const half2v s16v[2] = {half2v{(_Float16)s4[0], (_Float16)s4[1]}, half2v{(_Float16)s4[2], (_Float16)s4[3]}};
     auto fin_act = [&](RowSt& st, int hh) __attribute__((always_inline)) {
+        if constexpr (ACT != TW_ACT_F32) {
+            // (builtins, not inline asm: hipcc has to see these VALU writes to keep the wait states in front of the DPP moves)
+            const half2v hu = __builtin_convertvector(st.u, half2v), hv = __builtin_convertvector(st.v, half2v);
+            const half2v mu = hu * s16v[hh], mv = hv * s16v[hh];
+            const unsigned xu = __builtin_bit_cast(unsigned, __builtin_elementwise_max(hu, mu));
+            const unsigned xv = __builtin_bit_cast(unsigned, __builtin_elementwise_max(hv, mv));
+            if (hh == 0) { st.x0 = xu; st.y0 = xv; } else { st.x1 = xu; st.y1 = xv; }
+            return;
+        }
         const f32x2 sl = {s4[2 * hh], s4[2 * hh + 1]};
         const f32x2 us = st.u * sl, vs = st.v * sl;
         const f32x2 pu = {__builtin_amdgcn_fmed3f(st.u[0], us[0], i4[2 * hh]), __builtin_amdgcn_fmed3f(st.u[1], us[1], i4[2 * hh + 1])};
@@ -414,6 +447,18 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
                     *(uint4*)(w0 + wj) = make_uint4(st.q[4], st.q[5], st.q[6], st.q[7]);
                 }
             };
+            // this group's share of the raw rows of step it + 1 -> A-ring (TW_XA of the four rows; the consumers take the rest)
+            auto raw_rows_a = [&]() __attribute__((always_inline)) {
+                if (it + 1 < nsteps) {
+                    int pos0 = a6 + 4 + 2;
+                    pos0 = pos0 >= TW_AROWS ? pos0 - TW_AROWS : pos0;
+#if TW_XA == 4
+                    transform_rows((it + 1) & 1, pos0);
+#else
+                    transform_pair((it + 1) & 1, pos0, 1);
+#endif
+                }
+            };
             if (it < nsteps) {
                 __builtin_amdgcn_s_setprio(TW_PRIO_K);
                 // steps that touch their plane's edge (uniform, few) mask what lies outside
@@ -429,6 +474,9 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
             TW_STAMP(1);
             if (wave == 0) dma_barrier<5>(); else dma_barrier<4>();
             TW_STAMP(2);
+#if TW_XA > 0 && !defined(TW_XA_LAST)
+            raw_rows_a();
+#endif
             if (it < nsteps) {                     // the last row: beside the consumers' k-loop
                 // two rows at a time, slice by slice: neighbouring instructions are independent of each other
                 auto rest = [&](auto edge_tag) __attribute__((always_inline)) {
@@ -445,6 +493,9 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
                 };
                 if (edge) rest(std::true_type{}); else rest(std::false_type{});     // (uniform: most steps lie inside their plane)
             }
+#if TW_XA > 0 && defined(TW_XA_LAST)
+            raw_rows_a();
+#endif
             e_own = load_a(it + 1 < nsteps ? it + 1 : nsteps - 1);
             TW_STAMP(3);
             group_barrier();
@@ -461,6 +512,8 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
         // after the lane exchange lane (p, cg) holds 8 consecutive channels 16 wave + 8 (cg >> 1) .. of column col
         const unsigned olane = (unsigned)(col * PIXB + 32 * wave + 16 * (cg >> 1));
         char* const sink = (char*)a.sink + lane * PIXB;
+        const unsigned flip0 = (s4[0] > 1.f ? 0x8000u : 0u) | (s4[1] > 1.f ? 0x80000000u : 0u);
+        const unsigned flip1 = (s4[2] > 1.f ? 0x8000u : 0u) | (s4[3] > 1.f ? 0x80000000u : 0u);
         auto make_slice = [&](const uint4 e) __attribute__((always_inline)) {
             const unsigned ey = __builtin_amdgcn_readfirstlane(e.y), lo = __builtin_amdgcn_readfirstlane(e.x);
             const size_t off = ((unsigned long long)(ey & 0xffu) << 32) | lo;
@@ -475,6 +528,10 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
                 else if constexpr (k == 2) fin_sum(st, n, 1);
                 else if constexpr (k == 3) fin_act(st, 1);
                 else if constexpr (k == 4) {
+                    if constexpr (ACT == TW_ACT_F16_FLIP) {       // channels computed negated (slope > 1) get their sign back
+                        st.x0 ^= flip0; st.y0 ^= flip0;
+                        st.x1 ^= flip1; st.y1 ^= flip1;
+                    }
                     const auto x = __builtin_amdgcn_permlane16_swap(st.x0, st.y0, false, false);
                     const auto y = __builtin_amdgcn_permlane16_swap(st.x1, st.y1, false, false);
                     st.q[0] = x[0]; st.q[1] = y[0]; st.q[2] = x[1]; st.q[3] = y[1];
@@ -510,7 +567,11 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
                 if (it + 1 < nsteps) {
                     int pos0 = a6 + 4 + 2;         // step it + 1's new rows follow its two shared ones
                     pos0 = pos0 >= TW_AROWS ? pos0 - TW_AROWS : pos0;
+#if TW_XA == 0
                     transform_rows((it + 1) & 1, pos0);
+#elif TW_XA == 2
+                    transform_pair((it + 1) & 1, pos0, 0);
+#endif
                 }
             };
 #ifndef TW_TRANSFORM_LAST
