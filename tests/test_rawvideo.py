@@ -195,7 +195,7 @@ def test_segments_have_their_own_reader_and_writer(tmp_path, nlanes, nframes):
 
     def opener(path, mode):
         f = open(path, mode)
-        opened.append((str(path), mode, threading.get_ident(), f))
+        opened.append((str(path), mode, threading.current_thread().name, f))
         return f
     lanes = [[(FakeNet(1), 0), (FakeNet(2), 32)] for _ in range(nlanes)]
     n = rawvideo.stream_segments(str(src), str(dst), h, w, lanes, 2, alloc=lambda shape: np.zeros(shape, np.uint8), opener=opener)
@@ -214,3 +214,34 @@ def test_segments_have_their_own_reader_and_writer(tmp_path, nlanes, nframes):
     rawvideo.stream(io.BytesIO(src.read_bytes()), fout, h, w, [[(FakeNet(1), 0), (FakeNet(2), 32)] for _ in range(nlanes)],
                     alloc=lambda shape: np.zeros(shape, np.uint8))
     assert fout.getvalue() == dst.read_bytes()
+
+
+def test_segments_to_and_from_one_file_per_lane(tmp_path):
+    """-o x,y,... : segment k of the single input goes to the k-th output file; -i a,b,... : one input file per lane;
+    the concatenation is the one-reader route's output either way"""
+    import io
+    h, w, nlanes, nframes = 6, 10, 4, 11
+    frames = _frames(nframes, h, w)
+    src = tmp_path / "in.bgr24"
+    src.write_bytes(b"".join(f.tobytes() for f in frames))
+    mk = lambda: [[(FakeNet(1), 0), (FakeNet(2), 32)] for _ in range(nlanes)]   # noqa: E731
+    alloc = lambda shape: np.zeros(shape, np.uint8)                             # noqa: E731
+    whole = io.BytesIO()
+    rawvideo.stream(io.BytesIO(src.read_bytes()), whole, h, w, mk(), alloc=alloc)
+    outs = [str(tmp_path / ("out%d.bgr24" % k)) for k in range(nlanes)]
+    assert rawvideo.stream_segments(str(src), outs, h, w, mk(), 2, alloc=alloc) == nframes
+    assert b"".join(open(o, "rb").read() for o in outs) == whole.getvalue()
+    # the segments as input files of their own, results into one file; --frames counts through the inputs in order
+    fb = h * w * 3
+    bounds = [nframes * k // nlanes for k in range(nlanes + 1)]
+    ins = []
+    for k in range(nlanes):
+        ins.append(str(tmp_path / ("in%d.bgr24" % k)))
+        open(ins[-1], "wb").write(src.read_bytes()[bounds[k] * fb:bounds[k + 1] * fb])
+    dst = str(tmp_path / "joined.bgr24")
+    assert rawvideo.stream_segments(ins, dst, h, w, mk(), 2, alloc=alloc) == nframes
+    assert open(dst, "rb").read() == whole.getvalue()
+    assert rawvideo.stream_segments(ins, dst, h, w, mk(), 2, alloc=alloc, max_frames=5) == 5
+    assert open(dst, "rb").read() == whole.getvalue()[:5 * fb * 4]
+    with pytest.raises(ValueError):
+        rawvideo.stream_segments(ins[:2], dst, h, w, mk(), 2, alloc=alloc)

@@ -24,18 +24,22 @@ for args in (["-s", "2"], ["-s", "2", "-g", "0,0"], ["-s", "2", "-m", "a"], ["-s
     t1 = wall(base + args + ["-i", src, "-o", "/dev/null", "--frames", "1"])
     tn = wall(base + args + ["-i", src, "-o", "/dev/null"])
     print(f"{' '.join(args):20s} file -> /dev/null : {N} frames in {tn:6.2f} s (start-up {t1:5.2f} s) = {(N - 1) / (tn - t1):7.1f} frames/s")
-# file -> FILE with several workers: one segment of frames, reader and writer per worker (stream_segments) against the
-# one-reader / one-writer round-robin route on the same files; the output is a real file in /dev/shm (page cache)
+# file -> FILE (a real output file in /dev/shm: page cache): one worker; several workers through ONE reader and ONE writer
+# (--round-robin), with a segment, reader and writer each into ONE shared output file, and into one output file each
 dst = "/dev/shm/uva_out.bgr24"
 free = os.statvfs("/dev/shm").f_bavail * os.statvfs("/dev/shm").f_frsize
 M = max(8, min(N, int(free * 0.6) // (2160 * 3840 * 3)))
-for args in (["-s", "2", "-g", "0,0"], ["-s", "2", "-g", "0,0", "--round-robin"], ["-s", "2", "-g", "0,0,0,0"],
-             ["-s", "2", "-g", "0,0,0,0", "--round-robin"], ["-s", "2", "-g", "0,0,0,0,0,0,0,0"]):
-    t1 = wall(base + args + ["-i", src, "-o", dst, "--frames", str(len(args[3].split(",")))])
-    tn = wall(base + args + ["-i", src, "-o", dst, "--frames", str(M)])
+for args, per_lane in ((["-s", "2", "-g", "0"], False), (["-s", "2", "-g", "0,0", "--round-robin"], False), (["-s", "2", "-g", "0,0"], False),
+                       (["-s", "2", "-g", "0,0"], True), (["-s", "2", "-g", "0,0,0,0", "--round-robin"], False), (["-s", "2", "-g", "0,0,0,0"], False),
+                       (["-s", "2", "-g", "0,0,0,0"], True), (["-s", "2", "-g", "0,0,0,0,0,0,0,0"], True)):
     k = len(args[3].split(","))
-    print(f"{' '.join(args):34s} file -> file      : {M} frames in {tn:6.2f} s (start-up {t1:5.2f} s) = {(M - k) / (tn - t1):7.1f} frames/s")
-    os.remove(dst)
+    outs = [dst + ".%d" % i for i in range(k)] if per_lane else [dst]
+    t1 = wall(base + args + ["-i", src, "-o", ",".join(outs), "--frames", str(k)])
+    tn = wall(base + args + ["-i", src, "-o", ",".join(outs), "--frames", str(M)])
+    label = " ".join(args) + (" -o one file per worker" if per_lane else "")
+    print(f"{label:52s} file -> file : {M} frames in {tn:6.2f} s (start-up {t1:5.2f} s) = {(M - k) / (tn - t1):7.1f} frames/s")
+    for o in outs:
+        os.remove(o)
 t1 = wall(base + ["-s", "2", "-i", src, "-o", "/dev/null", "--frames", "1"])
 tn = wall(f"cat {src} | {' '.join(base)} -s 2 2>/dev/null | cat > /dev/null", shell=True)
 print(f"-s 2         pipe -> pipe      : {N} frames in {tn:6.2f} s = {(N - 1) / (tn - t1):7.1f} frames/s")

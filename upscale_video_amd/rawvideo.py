@@ -19,7 +19,7 @@ order: denoise, anime pass, upscale; upscale/upscale_processing.py:880-920),
 -g/--gpu a list of HIP ordinals, one worker per entry (duplicates allowed).  Pipes: one reader deals the frames
 out round-robin, one writer puts the results out in frame order.  File to file: one contiguous segment of frames per
 entry, each with its own reader, chain of nets and writer on its own file handles (stream_segments) -- no shared serial
-copy, so the route scales with the GPUs.
+copy, so the route scales with the GPUs; `-o x,y,...` (and `-i a,b,...`) give every entry a file of its own.
 """
 import argparse
 import os
@@ -233,33 +233,59 @@ def stream(fin, fout, h, w, nets_tiles, alloc=None, max_frames=None):
 
 
 def stream_segments(in_path, out_path, h, w, lanes_spec, scale_total, max_frames=None, alloc=None, opener=open):
-    """The same frames -> the same bytes as stream(), for a regular input FILE and a regular output FILE, with NO shared
-    serial copy: the frames are cut into one contiguous segment per `-g` entry (the reference's batches,
-    upscale/upscale_processing.py:923-948, are such segments) and every entry runs its own stream() -- its own reader, its own
-    pipelined chain of nets, its own writer thread -- on its own file handles, reading at its segment's offset and writing at
-    the offset its results belong to.  One reader and one writer thread copy ~10 GB/s each, two or three GPUs' worth of
-    1080p -> 4K frames; N independent pairs scale with the lanes.  Returns the number of frames written."""
+    """The same frames -> the same bytes as stream(), for regular FILES, with NO shared serial copy: one contiguous segment of
+    frames per `-g` entry (the reference's batches, upscale/upscale_processing.py:923-948, are such segments), and every entry
+    runs its own stream() -- its own reader, its own pipelined chain of nets, its own writer thread -- on its own file handles.
+      in_path   one file: cut into len(lanes_spec) segments, each read at its offset;  a list: one input file per entry
+      out_path  one file: every entry writes at the offset its results belong to (the file is sized first);  a list: one
+                output file per entry -- separate inodes, what a file system wants of concurrent writers (buffered writes
+                to ONE file take its inode lock in turn)
+    One reader and one writer thread copy ~10 GB/s each, two or three GPUs' worth of 1080p -> 4K frames; N independent pairs
+    scale with the entries.  Returns the number of frames written."""
     fb_in, fb_out = h * w * 3, h * scale_total * w * scale_total * 3
-    total = os.path.getsize(in_path) // fb_in
-    if os.path.getsize(in_path) % fb_in:
-        raise EOFError("input ends inside a frame (%d bytes, frames of %d)" % (os.path.getsize(in_path), fb_in))
-    if max_frames is not None:
-        total = min(total, max_frames)
     nl = len(lanes_spec)
-    with opener(out_path, "wb") as f:           # the output exists at its full size before anybody writes into it
-        f.truncate(total * fb_out)
-    bounds = [total * k // nl for k in range(nl + 1)]
+    ins = list(in_path) if isinstance(in_path, (list, tuple)) else None
+    outs = list(out_path) if isinstance(out_path, (list, tuple)) else None
+    if (ins is not None and len(ins) != nl) or (outs is not None and len(outs) != nl):
+        raise ValueError("one input / output file per -g entry: %d entries" % nl)
+
+    def frames_of(path):
+        size = os.path.getsize(path)
+        if size % fb_in:
+            raise EOFError("%s ends inside a frame (%d bytes, frames of %d)" % (path, size, fb_in))
+        return size // fb_in
+    if ins is None:
+        total = frames_of(in_path)
+        if max_frames is not None:
+            total = min(total, max_frames)
+        bounds = [total * k // nl for k in range(nl + 1)]
+        counts = [bounds[k + 1] - bounds[k] for k in range(nl)]
+        in_first = bounds[:nl]
+    else:
+        counts, left = [], max_frames
+        for path in ins:                         # --frames counts through the files in order
+            c = frames_of(path) if left is None else min(frames_of(path), left)
+            left = None if left is None else left - c
+            counts.append(c)
+        in_first = [0] * nl
+        total = sum(counts)
+    out_first = [0] * nl if outs is not None else [sum(counts[:k]) for k in range(nl)]
+    if outs is None:
+        with opener(out_path, "wb") as f:       # the output exists at its full size before anybody writes into it
+            f.truncate(total * fb_out)
     done, errs = [0] * nl, []
 
     def work(k):
         try:
-            first, count = bounds[k], bounds[k + 1] - bounds[k]
-            if count == 0:
+            if counts[k] == 0:
+                if outs is not None:
+                    opener(outs[k], "wb").close()
                 return
-            with opener(in_path, "rb") as fin, opener(out_path, "r+b") as fout:
-                fin.seek(first * fb_in)
-                fout.seek(first * fb_out)
-                done[k] = stream(fin, fout, h, w, lanes_spec[k], alloc=alloc, max_frames=count)
+            with opener(in_path if ins is None else ins[k], "rb") as fin, \
+                    opener(out_path if outs is None else outs[k], "r+b" if outs is None else "wb") as fout:
+                fin.seek(in_first[k] * fb_in)
+                fout.seek(out_first[k] * fb_out)
+                done[k] = stream(fin, fout, h, w, lanes_spec[k], alloc=alloc, max_frames=counts[k])
         except Exception as e:  # noqa: BLE001
             errs.append(e)
     threads = [threading.Thread(target=work, args=(k,), daemon=True) for k in range(nl)]
@@ -301,8 +327,9 @@ def copy_through(fin, fout, h, w, max_frames=None):
 
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
-    ap.add_argument("-i", "--input", default="-", help="bgr24 rawvideo file, '-' = stdin")
-    ap.add_argument("-o", "--output", default="-", help="bgr24 rawvideo file, '-' = stdout")
+    ap.add_argument("-i", "--input", default="-", help="bgr24 rawvideo file, '-' = stdin; a,b,...: one segment file per -g entry")
+    ap.add_argument("-o", "--output", default="-", help="bgr24 rawvideo file, '-' = stdout; x,y,...: one output file per -g entry "
+                                                        "(a single input is cut into segments, segment k goes to the k-th file)")
     ap.add_argument("-W", "--width", type=int, required=True)
     ap.add_argument("-H", "--height", type=int, required=True)
     ap.add_argument("-s", "--scale", type=int, default=2, choices=[1, 2, 4])
@@ -359,12 +386,19 @@ def main(argv=None):
         if chain:
             nets.append(chain)
     # file -> file with several workers: one contiguous segment of frames per worker, each with its own reader and writer
-    if nets and len(nets) > 1 and not a.round_robin and a.input != "-" and a.output != "-" and os.path.isfile(a.input) and \
-            (not os.path.exists(a.output) or os.path.isfile(a.output)):
+    ins, outs = a.input.split(","), a.output.split(",")
+    if len(ins) > 1 or len(outs) > 1:
+        if (len(ins) > 1 and len(ins) != len(nets)) or (len(outs) > 1 and len(outs) != len(nets)) or "-" in ins + outs:
+            ap.error("-i / -o lists: one regular file per -g entry (%d entries)" % len(nets))
+    regular = all(os.path.isfile(f) for f in ins) and all(not os.path.exists(f) or os.path.isfile(f) for f in outs)
+    if nets and (len(ins) > 1 or len(outs) > 1 or (len(nets) > 1 and not a.round_robin and a.input != "-" and a.output != "-" and regular)):
+        if not regular:
+            ap.error("-i / -o lists take regular files")
         scale_total = 1
         for net, _ in nets[0]:
             scale_total *= 1 if isinstance(net, tuple) else net.scale
-        n = stream_segments(a.input, a.output, a.height, a.width, nets, scale_total, max_frames=a.frames)
+        n = stream_segments(ins if len(ins) > 1 else ins[0], outs if len(outs) > 1 else outs[0], a.height, a.width, nets, scale_total,
+                            max_frames=a.frames)
         print("%d frames" % n, file=sys.stderr)
         ncnn.destroy_gpu_instance()
         return 0
