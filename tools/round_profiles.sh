@@ -14,13 +14,16 @@ done
 python bench.py --workload 4x_valar_1080p --steps 30 --warmup 3 > "$OUT/${TAG}_bench_4x_valar_1080p.json" 2>> "$OUT/bench.err"
 python bench.py --tile 0 --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_2x_whole_frame.json" 2>> "$OUT/bench.err"
 UVA_TRUNK_FUSION=0 python bench.py --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_unfused_trunk_kernel.json" 2>> "$OUT/bench.err"
+UVA_TRUNK_WINO=0 python bench.py --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_direct_trunk2_kernel.json" 2>> "$OUT/bench.err"
+UVA_TW_ACT16=0 python bench.py --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_trunkw_fp32_prelu.json" 2>> "$OUT/bench.err"
+python bench.py --gpus 2 --devices 0,0 --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_two_ranks_one_gpu.json" 2>> "$OUT/bench.err"
 UVA_SUB10=0 python bench.py --workload 1x_hurrdeblur_1080p --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_1x_per_pair_kernels.json" 2>> "$OUT/bench.err"
 python bench.py --workload 1x_hurrdeblur_1080p --tile 960 --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_1x_tiled_960.json" 2>> "$OUT/bench.err"
 (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d /tmp/prof1x_$TAG -o p --output-format csv -- python $REPO/bench.py --workload 1x_hurrdeblur_1080p --tile 0 --steps 120 --warmup 10 --no-cpu-baseline --no-parity > /dev/null 2>&1; cp $(find /tmp/prof1x_$TAG -name "*kernel_stats.csv" | head -1) "$OUT/${TAG}_kernel_stats_1x_rocprofv3.csv")
 bash tools/pmc_sub10.sh /tmp/pmc_sub10_$TAG > "$OUT/${TAG}_sub10_pmc.txt" 2>&1
 python tools/png_route_bench.py 384 > "$OUT/${TAG}_png_route_bench.txt" 2>&1
 python tools/png_gpu_route_bench.py 240 > "$OUT/${TAG}_png_gpu_route_bench.txt" 2>&1
-python tools/rawvideo_bench.py 600 > "$OUT/${TAG}_rawvideo_bench.txt" 2>&1
+python tools/rawvideo_bench.py 400 > "$OUT/${TAG}_rawvideo_bench.txt" 2>&1
 python tools/denoise_bench.py > "$OUT/${TAG}_denoise_bench_now.txt" 2>&1
 python tools/valar_bench.py 3 > "$OUT/${TAG}_bench_valar.txt" 2>&1
 UVA_GENERIC_RDB=0 UVA_GENERIC_SW=0 python tools/valar_bench.py 3 2>&1 | sed 's/^/layer by layer (UVA_GENERIC_RDB=0 UVA_GENERIC_SW=0): /' >> "$OUT/${TAG}_bench_valar.txt"
@@ -44,6 +47,9 @@ for i in 1 2 3 4 5 6; do rocm-smi --showpower --showclocks 2>/dev/null | grep -E
 wait
 sleep 8
 python -c "import json; d=json.load(open('$OUT/power_bench.json')); print('bench --steps 6000:', d['value'], 'fps, trunk', d['config']['kernel_ms_per_frame']['trunk'], 'ms/frame, frac', d['roofline']['frac'])" >> "$OUT/${TAG}_power_during_bench.txt" 2>&1
-UVA_LIB_PATH=$REPO/upscale_video_amd/libuva_instr.so python tools/trunk2_anatomy.py > "$OUT/${TAG}_trunk2_anatomy.txt" 2>&1
+UVA_LIB_PATH=$REPO/upscale_video_amd/libuva_instr.so python tools/trunkw_anatomy.py > "$OUT/${TAG}_trunkw_anatomy.txt" 2>&1
+UVA_TRUNK_WINO=0 UVA_LIB_PATH=$REPO/upscale_video_amd/libuva_instr.so python tools/trunk2_anatomy.py > "$OUT/${TAG}_trunk2_anatomy.txt" 2>&1
 UVA_LIB_PATH=$REPO/upscale_video_amd/libuva_instr.so python tools/sub10_anatomy.py > "$OUT/${TAG}_sub10_anatomy.txt" 2>&1
+python tools/soak.py 1000 > "$OUT/${TAG}_soak.txt" 2>&1
+timeout 1500 python -m pytest tests -m gpu -q > "$OUT/${TAG}_gpu_tests.txt" 2>&1
 ls -la "$OUT"
