@@ -122,6 +122,58 @@ def cpu_baseline(model_key, h, w, tile, min_seconds=10.0):
     }
 
 
+def cpu_baseline_generic(param_path, bin_path, h, w, min_seconds=8.0):
+    """The generic graphs' CPU restatement (oracle/generic_oracle.py: numpy fp32, whatever BLAS threads numpy has) on square
+    crops of growing size until one pass takes >= min_seconds; scaled to whole frames by pixels (the arithmetic per pixel
+    does not depend on the frame size)."""
+    import numpy as np
+    from oracle import generic_oracle, uvoracle
+    m = generic_oracle.Model(param_path, bin_path)
+    dt = side = 0
+    for side in (24, 48, 96, 192):
+        img = uvoracle.synthetic_frame(side, side)
+        x = img.transpose(2, 0, 1).astype(np.float32) * np.float32(1 / 255.0)
+        t0 = time.perf_counter()
+        m.forward(x)
+        dt = time.perf_counter() - t0
+        if dt >= min_seconds or dt * 4 > 40:
+            break
+    frac = side * side / float(h * w)
+    return {
+        "value": round(frac / dt, 7), "unit": "frames/s", "cores": uvoracle.max_threads(), "kind": "port",
+        "sample": f"one {side}x{side} crop ({frac:.6f} of a frame) through oracle/generic_oracle.py (numpy fp32, its BLAS threads), "
+                  f"{dt:.1f} s, scaled to whole frames by pixels",
+    }
+
+
+def pmc_traffic_valar(launches_per_frame):
+    """HBM bytes per rdb4_kernel launch from the committed PMC summary of the Valar frame (tools/pmc_valar.sh: FETCH_SIZE
+    doubled per the gfx950 correction + WRITE_SIZE, per frame, summed over the kernel's launches) -> (bytes, file) or (None, None)."""
+    import glob
+    import re
+    for path in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valar_pmc.txt")))):
+        try:
+            fetch = write = None
+            mode = None
+            for line in open(path):
+                if line.startswith("FETCH_SIZE"):
+                    mode = "f"
+                elif line.startswith("WRITE_SIZE"):
+                    mode = "w"
+                elif line.startswith(("HBM", "SQ")):
+                    mode = None
+                m = re.match(r"\s+uva::rdb4_kernel\(uva::RdbArgs\)\s+([0-9.]+) GB", line)
+                if m and mode == "f" and fetch is None:
+                    fetch = float(m.group(1))
+                elif m and mode == "w" and write is None:
+                    write = float(m.group(1))
+            if fetch is not None and write is not None and launches_per_frame > 0:
+                return int((2 * fetch + write) * 1e9 / launches_per_frame), "profiles/" + os.path.basename(path)
+        except Exception:  # noqa: BLE001
+            pass
+    return None, None
+
+
 def pmc_traffic(args, nf, kernel):
     """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE
     collected in separate runs of this command on the same build, FETCH_SIZE doubled per
@@ -417,6 +469,7 @@ def run(args, comm, device):
         # 69 blocks' worth of FLOPs over the time of all their launches is what holds in every case
         VALAR_BLOCKS = 69
         achieved = rdb_flops * VALAR_BLOCKS * steps_timed / (trunk_ms * 1e-3) / 1e12 if trunk_ms > 0 else 0.0
+        traffic, traffic_source = pmc_traffic_valar(n_launch / max(1, steps_timed)) if args.tile == 960 and (h, w) == (1080, 1920) else (None, None)
         result = {
             "metric": "frames/sec " + args.workload, "value": round(fps, 3), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -435,11 +488,13 @@ def run(args, comm, device):
             },
             "roofline": {"kernel": "rdb4_kernel (conv1..conv4 + the 1x1 of a residual dense block, every plane of the frame, one launch)",
                          "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "flops_per_launch": rdb_flops, "avg_launch_ms": round(avg_ms, 4), "launches": n_launch,
                          "launches_per_frame": round(n_launch / max(1, steps_timed), 2)},
             "cpu_baseline": None,
         }
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline_generic(base + ".param", weights, h, w)
         if host_fps is not None:
             result["config"]["host_route_fps_pcie_inclusive"] = round(host_fps, 2)
             result["config"]["host_route_frames_per_rank"] = n_host

@@ -80,6 +80,7 @@ def run_tests(gpus=None, scale=2, runs=10, image=None, size="1920x1080"):
             image = os.path.join(scratch, "sample.png")
             w, h = (int(v) for v in size.lower().split("x"))
             imwrite(image, synthetic_frame(h, w))
+            logging.info("sample.png: a synthetic %dx%d frame", w, h)
         time_pool(gpu_list, scale, runs, image)
 
 

@@ -115,6 +115,19 @@ def test_harness_test_gpus_two_workers(caplog, tmp_path, monkeypatch):
             f.write(text + "\n")
 
 
+def test_harness_config5_sample_size(caplog, tmp_path, monkeypatch):
+    """BASELINE config 5 names a 3840x2160 input on the worker list 0..7: `test_gpus.py --size 3840x2160` writes that
+    sample; here two workers share the one GPU (`-g 0,0`), two runs, and the output frame has config 5's size"""
+    import test_gpus
+    monkeypatch.chdir(tmp_path)
+    with caplog.at_level(logging.INFO):
+        test_gpus.run_tests("0,0", 2, 2, size="3840x2160")
+    text = "\n".join(r.getMessage() for r in caplog.records)
+    assert text.count("Testing GPU: 0") == 2 and text.count("seconds to upscale sample.png") == 2
+    assert "sample.png: a synthetic 3840x2160 frame" in text
+    assert "frames/s" in text
+
+
 def test_opportunistic_pin_against_real_ncnn_and_cv2(uva, oracle, oracle_models):
     """The oracle is pinned only by an independent restatement: the reference's
     arithmetic lives in the un-pinned ncnn_vulkan / opencv-python wheels, which this image does not have.
@@ -246,6 +259,9 @@ def test_bench_valar_workload(tmp_path):
     k = d["config"]["kernel_ms_per_frame"]
     assert 0 < k["rdb4_kernel"] + k["conv5 (g_conv3_sw<6,1>)"] < d["ms_per_step"]
     assert d["config"]["host_route_fps_pcie_inclusive"] > 0 and "random-init" in d["data"]
+    # a complete line: the CPU restatement timed on a crop beside it, and the kernel's HBM bytes per launch from the PMC summary
+    assert d["cpu_baseline"]["kind"] == "port" and 0 < d["cpu_baseline"]["value"] < 0.05
+    assert d["roofline"]["traffic"] is None or (5e8 < d["roofline"]["traffic"] < 3e9 and d["roofline"]["traffic_source"].startswith("profiles/"))
 
 
 def _window_check(got, img, om_apply, rad, s, wins, win=24, max_lsb=2, min_psnr=50):
