@@ -146,6 +146,24 @@ def test_tiled_frame_matches_oracle_tiling(nets, oracle_models, oracle, key, h, 
     assert np.abs(got.astype(int) - want32.astype(int)).max() <= 2 and psnr_u8(got, want32) >= 50
 
 
+@pytest.mark.parametrize("key", ["2x", "4x"])
+def test_sign_carry_between_launches_changes_no_bit(uva, nets, oracle, key, monkeypatch):
+    """trunkw_kernel computes channels whose PReLU slope exceeds 1 negated; between two of its launches they stay negated in
+    HBM and the next launch's weights take the sign back (uva_api.hip run_graph, `carry`).  Sign flips are exact: the frame must
+    equal, byte for byte, the one a net built with UVA_TW_CARRY=0 (every launch restores the signs) gives -- tiled and whole,
+    u8 and float route"""
+    img = oracle.synthetic_frame(131, 94, seed=77)
+    monkeypatch.setenv("UVA_TW_CARRY", "0")
+    plain = load_net(uva, key)            # (the switches are read when a net's device side is built)
+    a = plain.process_u8(img, tile_size=64, border=10)
+    b = plain.process_u8(img, tile_size=0)
+    monkeypatch.delenv("UVA_TW_CARRY")
+    assert np.array_equal(nets[key].process_u8(img, tile_size=64, border=10), a)
+    assert np.array_equal(nets[key].process_u8(img, tile_size=0), b)
+    x = oracle.from_pixels_normalize(img)
+    assert np.array_equal(nets[key]._extract(x), plain._extract(x))
+
+
 def test_fused_route_equals_float_route(nets, oracle):
     """The fused u8 device call against the reference-shaped float route (from_pixels ->
     normalize -> extract -> *255 -> convertTo) run tile by tile through the same kernels."""

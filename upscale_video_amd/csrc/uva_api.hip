@@ -108,6 +108,8 @@ struct Workspace {
 struct DeviceLayer {
     half8* wpk = nullptr;
     half8* wpk_w = nullptr;   // 64 -> 64 trunk layers: pack_trunk64_wino image for trunkw_kernel
+    half8* wpk_wn = nullptr;  // ... the same for a launch's FIRST layer whose input arrives with the previous layer's slope > 1 channels
+                              // still negated (the launch before it did not restore their sign: run_graph, `carry`)
     float* bias_w = nullptr;  // ... and its bias, negated for the channels trunkw_kernel computes negated (uva_wino.h TW_ACT_F16)
     bool flip_w = false;      // ... which this layer has (a PReLU slope above 1)
     half8* wpk16 = nullptr;   // tail layer of the 64-feature 2x / 4x nets: pack_tail64 image for tail_kernel / tail4_kernel
@@ -155,6 +157,8 @@ struct uva_net {
     bool generic_lds_conv = true; // generic graphs: 3x3 convolutions through g_conv3_lds (UVA_GENERIC_LDS=0: the plain g_conv<3>)
     bool fuse_all = true;         // 24-feature 1x net: all ten convolutions in one launch (sub10_kernel); UVA_SUB10=0 turns it off
     bool fuse_pairs = true;       // 64-feature nets: trunk layers run two per launch (trunk2_kernel); UVA_TRUNK_FUSION=0 turns it off
+    bool carry = true;            // ... and between two launches the negated channels stay negated in HBM (UVA_TW_CARRY=0: every launch
+                                  // restores the signs in front of its stores)
     bool act16 = true;            // trunkw_kernel: PReLU on packed fp16 (uva_wino.h TW_ACT_F16); UVA_TW_ACT16=0: on the fp32 sums
     bool wino = true;             // ... as 1-D Winograd F(2,3) (trunkw_kernel); UVA_TRUNK_WINO=0: trunk2_kernel (direct convolution)
     LastCall last;
@@ -202,6 +206,7 @@ struct uva_net {
             if (l.wpk) (void)hipFree(l.wpk);
             if (l.wpk_w) (void)hipFree(l.wpk_w);
             if (l.bias_w) (void)hipFree(l.bias_w);
+            if (l.wpk_wn) (void)hipFree(l.wpk_wn);
             if (l.wpk16) (void)hipFree(l.wpk16);
             if (l.wpk_s10) (void)hipFree(l.wpk_s10);
             if (l.bias_s10) (void)hipFree(l.bias_s10);
@@ -601,15 +606,17 @@ int build_trunkw_schedule(const std::vector<PlaneDesc>& planes, int grid, size_t
     return 0;
 }
 
-// layers i, i + 1 of the net in one trunkw_kernel launch
-int launch_trunkw(uva_net* n, const Workspace* ws, TrunkwArgs& a, int i)
+// layers i, i + 1 of the net in one trunkw_kernel launch.  in_negated: the input's channels with a slope above 1 (layer i - 1's)
+// are still negated; carry_out: leave layer i + 1's that way for the next launch (its first layer's weights take the sign back)
+int launch_trunkw(uva_net* n, const Workspace* ws, TrunkwArgs& a, int i, bool in_negated = false, bool carry_out = false)
 {
     for (int k = 0; k < 2; ++k) {
         a.wpk[k] = n->layers[i + k].wpk_w;
         a.bias[k] = n->act16 ? n->layers[i + k].bias_w : n->layers[i + k].bias;
         a.slope[k] = n->layers[i + k].slope;
     }
-    const int act = !n->act16 ? TW_ACT_F32 : n->layers[i + 1].flip_w ? TW_ACT_F16_FLIP : TW_ACT_F16;
+    if (in_negated) a.wpk[0] = n->layers[i].wpk_wn;
+    const int act = !n->act16 ? TW_ACT_F32 : (n->layers[i + 1].flip_w && !carry_out) ? TW_ACT_F16_FLIP : TW_ACT_F16;
     HIP_TRY(launch_trunkw_kernel(n->stream, ws->grid2, a, act));
     return 0;
 }
@@ -755,6 +762,7 @@ int ensure_device(uva_net* n)
     if (const char* e = std::getenv("UVA_TRUNK_FUSION")) n->fuse_pairs = std::atoi(e) != 0;
     if (const char* e = std::getenv("UVA_TRUNK_WINO")) n->wino = std::atoi(e) != 0;
     if (const char* e = std::getenv("UVA_TW_ACT16")) n->act16 = std::atoi(e) != 0;
+    if (const char* e = std::getenv("UVA_TW_CARRY")) n->carry = std::atoi(e) != 0;
     if (const char* e = std::getenv("UVA_SUB10")) n->fuse_all = std::atoi(e) != 0;
     if (const char* e = std::getenv("UVA_GENERIC_LDS")) n->generic_lds_conv = std::atoi(e) != 0;
     if (const char* e = std::getenv("UVA_GENERIC_FUSE_ADD")) n->generic_fuse_add = std::atoi(e) != 0;
@@ -822,6 +830,19 @@ int ensure_device(uva_net* n)
             if (upload(&dl.wpk_w, pkw.data(), pkw.size() * 2, n->stream)) return 1;
             if (upload(&dl.bias_w, bw.data(), bw.size() * 4, n->stream)) return 1;
             HIP_TRY(hipStreamSynchronize(n->stream));
+            if (n->act16 && (i & 1) && i >= 3) {
+                // first layer of a launch behind another launch: a second image for an input whose flipped channels arrive negated
+                bool any = false;
+                for (int c = 0; c < 64; ++c) {
+                    sin[c] = g.slopes[i - 1][c] > 1.f ? -1.f : 1.f;
+                    any = any || sin[c] < 0.f;
+                }
+                if (any) {
+                    pack_trunk64_wino(g.convs[i], pkw, sin.data(), sout.data());
+                    if (upload(&dl.wpk_wn, pkw.data(), pkw.size() * 2, n->stream)) return 1;
+                    HIP_TRY(hipStreamSynchronize(n->stream));
+                }
+            }
         }
         std::vector<uint16_t> pk16;
         if (g.nf == 64 && (g.scale == 2 || g.scale == 4) && i + 1 == g.convs.size()) {
@@ -1155,10 +1176,17 @@ int run_graph(uva_net* n, Workspace* ws, bool f32, const void* src, size_t src_s
     // ping-pong: every launch (one trunk layer, or a fused pair of them) reads act[cur] and writes act[cur ^ 1]
     int cur = 0;
     n->last_act_buf = 0;
+    bool negated = false;         // the current activation image holds the last layer's slope > 1 channels negated (see below)
     for (int i = 1; i < nconv - 1; ++i) {
         if (stop_after >= 0 && i > stop_after) return 0;
         // two trunk layers per launch where a pair is wanted in full (a debug tap on layer i itself runs it alone)
         if (n->fuse_pairs && n->wino && ws->d_stepsw && n->layers[i].wpk_w && i + 1 < nconv - 1 && (stop_after < 0 || i + 1 <= stop_after)) {
+            // The packed-fp16 PReLU computes channels with a slope above 1 negated (uva_wino.h).  Where the NEXT launch is a
+            // trunkw pair as well, this launch leaves its second layer's that way in HBM (no sign restore: four instructions per
+            // block row) and the next launch's first layer reads them through weights packed for it (wpk_wn).  Whole frames only:
+            // a debug tap (stop_after) keeps every image in the plain convention.
+            const bool next_is_pair = stop_after < 0 && i + 3 < nconv - 1 && n->layers[i + 2].wpk_wn != nullptr;
+            const bool carry_out = n->act16 && n->carry && next_is_pair && n->layers[i + 1].flip_w;
             TrunkwArgs wa;
             std::memset(&wa, 0, sizeof wa);
             wa.in_act = ws->act_base[cur];
@@ -1167,7 +1195,8 @@ int run_graph(uva_net* n, Workspace* ws, bool f32, const void* src, size_t src_s
             wa.nsteps = ws->d_nstepsw;
             wa.max_steps = ws->max_stepsw;
             wa.sink = n->d_sink;
-            if (launch_trunkw(n, ws, wa, i)) return 1;
+            if (launch_trunkw(n, ws, wa, i, negated, carry_out)) return 1;
+            negated = carry_out;
             ++ev.ntrunk;
             ++i;
             cur ^= 1;
