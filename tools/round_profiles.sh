@@ -8,6 +8,18 @@ OUT=$REPO/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
 bash "$REPO/tools/collect_profiles.sh" "$TAG" > "$OUT/collect.log" 2>&1
 cd "$REPO"
+# same-box A/B against the previous build, when one was shipped beside the library (upscale_video_amd/libuva_prev.so)
+if [ -f upscale_video_amd/libuva_prev.so ]; then
+  P='import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], d["config"]["kernel_ms_per_frame"], d["roofline"]["frac"])'
+  for wl in 2x_compact_1080p 4x_compact_1080p; do
+    for i in 1 2 3; do
+      for v in prev new; do
+        L=$REPO/upscale_video_amd/libuva.so; [ $v = prev ] && L=$REPO/upscale_video_amd/libuva_prev.so
+        echo -n "$wl $v: "; UVA_LIB_PATH=$L python bench.py --workload $wl --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | python -c "$P"
+      done
+    done
+  done > "$OUT/${TAG}_ab_prev_new.txt" 2>&1
+fi
 for wl in 4x_compact_1080p 1x_hurrdeblur_1080p chain_1x_2x_1080p 2x_compact_2160p; do
   python bench.py --workload $wl --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_${wl}.json" 2>> "$OUT/bench.err"
 done
@@ -31,6 +43,7 @@ for kv in UVA_GENERIC_BATCH=0 UVA_GENERIC_FUSE_INTERP=0 UVA_GENERIC_SK=1; do
   env $kv python tools/valar_bench.py 3 2>&1 | grep -v amdgpu.ids | sed "s/^/$kv: /" >> "$OUT/${TAG}_bench_valar.txt"
 done
 hipcc --offload-arch=gfx950 -O3 tools/mfma_read_ratio_bench.hip -o /tmp/mrr_$TAG 2> /dev/null && /tmp/mrr_$TAG > "$OUT/${TAG}_mfma_read_ratio_bench.txt" 2>&1
+hipcc --offload-arch=gfx950 -O3 tools/hbm_stream_bench.hip -o /tmp/hsb_$TAG 2> /dev/null && /tmp/hsb_$TAG > "$OUT/${TAG}_hbm_stream_bench.txt" 2>&1
 bash tools/pmc_valar.sh > "$OUT/${TAG}_valar_pmc.txt" 2>&1
 (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d /tmp/profval_$TAG -o p --output-format csv -- python $REPO/tools/valar_bench.py 3 > /dev/null 2>&1; cp $(find /tmp/profval_$TAG -name "*kernel_stats.csv" | head -1) "$OUT/${TAG}_kernel_stats_valar_rocprofv3.csv")
 UVA_RDB_STAMPS=1 UVA_LIB_PATH=$REPO/upscale_video_amd/libuva_instr.so python tools/rdb4_anatomy.py > "$OUT/${TAG}_rdb4_anatomy.txt" 2>&1
