@@ -2378,6 +2378,10 @@ int uva_net_process_u8_device(uva_net* n, const void* d_in, int h, int w, size_t
     if (!d_in || !d_out) return fail("null frame pointer");
     if (ensure_device(n)) return 1;
     if (in_stride < (size_t)w * 3 || out_stride < (size_t)w * uva_net_scale(n) * 3) return fail("row stride too small");
+    // the tail kernels address the residual bytes with 32-bit offsets from the frame's base (the LDS-DMA's lane offset is 32-bit)
+    if ((unsigned long long)in_stride * (unsigned long long)h >= (1ull << 32) - 64 ||
+        (unsigned long long)out_stride * (unsigned long long)h * (unsigned long long)uva_net_scale(n) >= (1ull << 32) - 64)
+        return fail("frame of 4 GB or more");
     if (n->generic) return generic_process_u8_device(n, d_in, h, w, in_stride, d_out, out_stride, tile_size, border);
     Workspace* ws = nullptr;
     if (get_workspace(n, h, w, tile_size, border, &ws)) return 1;

@@ -2182,7 +2182,10 @@ __global__ __launch_bounds__(512, 2) void tail_kernel(ConvArgs a)
     constexpr int KS = 18;                    // k-steps of 32: (tap, input-channel half)
     constexpr int CPW = TG::CPW;
     constexpr int SLOTB = TG::SLOTB;
-    constexpr int PFF = 4;                    // B fragments read ahead
+#ifndef TAIL_PFF
+#define TAIL_PFF 4
+#endif
+    constexpr int PFF = TAIL_PFF;             // B fragments read ahead (an LDS read comes back after ~200-280 cycles, an MFMA issues in 16)
     constexpr int CPW_K = 8;                  // DMA pieces issued in the k-loop phase (the rest in the epilogue phase):
                                               // all 8 measured slightly better than 5 + 3
     constexpr int NSTEP = 24;
@@ -2287,31 +2290,49 @@ __global__ __launch_bounds__(512, 2) void tail_kernel(ConvArgs a)
 
     const unsigned resid_lds = lds0 + (unsigned)(resid_all - smem) + wave8 * 128;
     const char* const resid_rd = resid_all + wave8 * 128;
+    // the lane's four output channels' bias, resident (an LDS read at the top of every epilogue is a round trip of its own)
+    const f32x4 b4 = *(const f32x4*)(bias_lds + 4 * (lane >> 4));
     const bool stamp = UVA_STAMP_ON(a);
+    // A tile's schedule entry and plane fields are read (LDS, two dependent round trips) at the END of the group's previous
+    // iteration, in front of the barrier it would wait at anyway: at the top of the loop they sat in front of the k-loop
+    // (profiles/r04_ab_results.txt block 17).
+    struct TileCtx { Sched own; int pl_h, pl_w, src_y0, src_x0, core_y0, core_y1, core_x0, core_x1; };
+    auto load_ctx = [&](int k) __attribute__((always_inline)) {
+        TileCtx c;
+        c.own = read_sched(k);
+        const PlaneDesc& pl = planes_lds[c.own.plane];
+        c.pl_h = __builtin_amdgcn_readfirstlane(pl.h); c.pl_w = __builtin_amdgcn_readfirstlane(pl.w);
+        c.src_y0 = __builtin_amdgcn_readfirstlane(pl.src_y0); c.src_x0 = __builtin_amdgcn_readfirstlane(pl.src_x0);
+        c.core_y0 = __builtin_amdgcn_readfirstlane(pl.core_y0); c.core_y1 = __builtin_amdgcn_readfirstlane(pl.core_y1);
+        c.core_x0 = __builtin_amdgcn_readfirstlane(pl.core_x0); c.core_x1 = __builtin_amdgcn_readfirstlane(pl.core_x1);
+        return c;
+    };
+    TileCtx ctx = load_ctx(grp);
+    const unsigned src_lo2 = (unsigned)(size_t)a.src_u8 & 3u, src_stride32 = (unsigned)a.src_stride;
+    const unsigned dst_stride32 = (unsigned)a.dst_stride;
     for (int it = 0; it < niter0; ++it) {
         const bool active = it < niter;
         const int k = 2 * it + grp;
         if (stamp) a.dbg[8 * it + 0] = __builtin_amdgcn_s_memtime();
-        const Sched own = read_sched(k);
-        const PlaneDesc& pl = planes_lds[own.plane];
-        const int pl_h = __builtin_amdgcn_readfirstlane(pl.h), pl_w = __builtin_amdgcn_readfirstlane(pl.w);
-        const int src_y0 = __builtin_amdgcn_readfirstlane(pl.src_y0), src_x0 = __builtin_amdgcn_readfirstlane(pl.src_x0);
+        const Sched own = ctx.own;
+        const int pl_h = ctx.pl_h, pl_w = ctx.pl_w, src_y0 = ctx.src_y0, src_x0 = ctx.src_x0;
         const int y_t = own.ty * TH4 + 2 * rp;            // plane-local first row of this wave
         const int xs = own.tx * TW + 16 * cc;             // plane-local first column of this wave
-        // residual source bytes: rows y_t, y_t+1 (clamped), columns xs .. xs+15 (clamped) of the plane
+        // residual source bytes: rows y_t, y_t+1 (clamped), columns xs .. xs+15 (clamped) of the plane.  Offsets inside the
+        // frame are 32-bit (the DMA's lane offset is): uva_net_process_u8 refuses frames of 4 GB and more
         int sh[2];
         {
             const int xc = min(xs, pl_w - 1);
-            const int nb = 3 * min(16, pl_w - xc);         // valid bytes of the row segment (>= 3)
+            const unsigned nb = 3u * (unsigned)min(16, pl_w - xc);         // valid bytes of the row segment (>= 3)
             unsigned voff = 0;
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const int yc = min(y_t + n, pl_h - 1);
-                const size_t ra = (size_t)(src_y0 + yc) * a.src_stride + (size_t)(src_x0 + xc) * 3;   // byte offset in the frame
-                const size_t abs = (size_t)a.src_u8 + ra;
-                sh[n] = (int)(abs & 3);
-                const int dmax = (int)((((abs + nb - 1) & ~(size_t)3) - (abs & ~(size_t)3)) >> 2);
-                const unsigned vo = (unsigned)(ra - sh[n]) + 4u * (unsigned)min(lane & 15, dmax);
+                const unsigned ra = (unsigned)(src_y0 + yc) * src_stride32 + (unsigned)(src_x0 + xc) * 3u;   // byte offset in the frame
+                const unsigned al = src_lo2 + ra;                          // same low bits as the byte's address
+                sh[n] = (int)(al & 3u);
+                const int dmax = (int)((((al + nb - 1u) & ~3u) - (al & ~3u)) >> 2);
+                const unsigned vo = (ra - (unsigned)sh[n]) + 4u * (unsigned)min(lane & 15, dmax);
                 if ((lane >> 4) == n) voff = vo;
             }
             if (active && lane < 32) glds4_s(a.src_u8, voff, resid_lds);
@@ -2333,19 +2354,27 @@ __global__ __launch_bounds__(512, 2) void tail_kernel(ConvArgs a)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int f = 0; f < PFF; ++f) bq[f] = read_b(f);
-#pragma unroll
-            for (int st = 0; st < NSTEP; ++st) {
-                if (st + PFF < NSTEP) bq[(st + PFF) % RQ] = read_b(st + PFF);
+            __builtin_amdgcn_sched_barrier(0);
+            // The order is pinned step by step (sched_barrier): the read PFF fragments ahead, a DMA piece, this fragment's
+            // MFMAs.  Left to itself hipcc sinks every read to just in front of its MFMA ("read, wait, MFMA": sixteen
+            // lgkmcnt(0) waits per k-loop, each an LDS round trip of ~200 cycles -- the k-loop then takes 2 190 ticks for
+            // 576 cycles of MFMA issue, profiles/r04_ab_results.txt block 17).
+            static_for<NSTEP>([&](auto sc) __attribute__((always_inline)) {
+                constexpr int st = decltype(sc)::value;
+                if constexpr (st + PFF < NSTEP) bq[(st + PFF) % RQ] = read_b(st + PFF);
                 constexpr int EVERY = NSTEP / CPW_K;
-                if (st % EVERY == 1 && st / EVERY < CPW_K)
+                if constexpr (st % EVERY == 1 && st / EVERY < CPW_K)
                     trunk_issue_piece<NF>(la.base, la.pitch, la_lds, st / EVERY, wave, dma_pc[st / EVERY]);
-                const int Rr = st & 3, ch = (st >> 2) & 1, dx = st >> 3;
+                constexpr int Rr = st & 3, ch = (st >> 2) & 1, dx = st >> 3;
                 const half8 b = bq[st % RQ];
-                if (Rr <= 2)    // output row 0, tap (dy = Rr, dx)
+                if constexpr (Rr <= 2)    // output row 0, tap (dy = Rr, dx)
                     acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[((Rr * 3 + dx) * 2) + ch], b, st == 0 ? zero4 : acc[0], 0, 0, 0);
-                if (Rr >= 1)    // output row 1, tap (dy = Rr - 1, dx)
+                if constexpr (Rr >= 1)    // output row 1, tap (dy = Rr - 1, dx)
                     acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[(((Rr - 1) * 3 + dx) * 2) + ch], b, st == 1 ? zero4 : acc[1], 0, 0, 0);
-            }
+#ifndef TAIL_NO_PIN
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            });
             __builtin_amdgcn_s_setprio(0);
         }
         if (stamp) a.dbg[8 * it + 1] = __builtin_amdgcn_s_memtime();
@@ -2355,27 +2384,27 @@ __global__ __launch_bounds__(512, 2) void tail_kernel(ConvArgs a)
         else tile_barrier<CPW_K - 1>();
         if (stamp) a.dbg[8 * it + 2] = __builtin_amdgcn_s_memtime();
         // ---- epilogue phase ----------------------------------------------------------------------
-        const Sched la_next = read_sched(min(k + 2 + TRUNK_LOOKAHEAD, nsched - 1));
 #pragma unroll
         for (int i = CPW_K; i < CPW; ++i) trunk_issue_piece<NF>(la.base, la.pitch, la_lds, i, wave, dma_pc[i]);
-        la = la_next;
         if (active) {
-            const int lane_o = opaque(lane);
+            const int lane_o = lane;
             const int g = lane_o >> 4, p = lane_o & 15;          // colour channel (3: padding rows), pixel
             uint8_t* const stage = (uint8_t*)(smem + cur * SLOTB + wave * STAGEB);
-            const f32x4 b4 = *(const f32x4*)(bias_lds + 4 * g);
             const float norm = (float)(1 / 255.0);               // substract_mean_normalize norm_vals (:272, :444)
             if (g < 3) {
+                unsigned rb[2];
+#pragma unroll
+                for (int n = 0; n < 2; ++n) rb[n] = *(const uint8_t*)(resid_rd + n * 64 + sh[n] + 3 * p + g);
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
-                    const float res = (float)*(const uint8_t*)(resid_rd + n * 64 + sh[n] + 3 * p + g) * norm;
+                    const float res = (float)rb[n] * norm;
+                    // v_cvt_pk_u8_f32 rounds half to even and saturates: cv2's convertTo(CV_8U) in one instruction (as in sub10_kernel)
+                    unsigned q4 = 0;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float v = (acc[n][j] + b4[j]) + res;
-                        float q = __builtin_rintf(v * 255.0f);     // v_rndne_f32: ties to even
-                        q = fminf(fmaxf(q, 0.f), 255.f);
-                        stage[(n * R + (j >> 1)) * ROWB + (p * R + (j & 1)) * 3 + g] = (uint8_t)q;
-                    }
+                    for (int j = 0; j < 4; ++j) q4 = __builtin_amdgcn_cvt_pk_u8_f32(((acc[n][j] + b4[j]) + res) * 255.0f, j, q4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        stage[(n * R + (j >> 1)) * ROWB + (p * R + (j & 1)) * 3 + g] = (uint8_t)(q4 >> (8 * j));
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -2383,18 +2412,19 @@ __global__ __launch_bounds__(512, 2) void tail_kernel(ConvArgs a)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (stamp) a.dbg[8 * it + 4] = __builtin_amdgcn_s_memtime();
             // copy-out of the plane's core region (process_tile's crop, upscale_processing.py:464-477)
-            const int core_y0 = __builtin_amdgcn_readfirstlane(pl.core_y0), core_y1 = min(__builtin_amdgcn_readfirstlane(pl.core_y1), pl_h);
-            const int core_x0 = __builtin_amdgcn_readfirstlane(pl.core_x0), core_x1 = min(__builtin_amdgcn_readfirstlane(pl.core_x1), pl_w);
+            const int core_y0 = ctx.core_y0, core_y1 = min(ctx.core_y1, pl_h);
+            const int core_x0 = ctx.core_x0, core_x1 = min(ctx.core_x1, pl_w);
             const int x_lo = max(core_x0, xs) - xs, x_hi = min(core_x1, xs + 16) - xs;
             const int b_lo = x_lo * R * 3, b_hi = x_hi * R * 3;
-            uint8_t* const dbase = a.dst_u8 + (size_t)(src_y0 + y_t) * R * a.dst_stride + (size_t)(src_x0 + xs) * R * 3;
+            // (32-bit offset inside the output frame: uva_net_process_u8_device refuses frames of 4 GB and more)
+            uint8_t* const dbase = a.dst_u8 + ((unsigned)(src_y0 + y_t) * (unsigned)R * dst_stride32 + (unsigned)(src_x0 + xs) * (unsigned)(R * 3));
             const bool full = b_lo == 0 && b_hi == ROWB && y_t >= core_y0 && y_t + 2 <= core_y1;
             const size_t align_bits = (size_t)dbase | a.dst_stride;
             constexpr int Q = ROWB / 16, WORDS = ROWB / 4;
             if (full && (align_bits & 15) == 0) {
                 if (lane_o < 2 * R * Q) {
                     const int sr = lane_o / Q, kq = lane_o - sr * Q;
-                    *(uint4*)(dbase + (size_t)sr * a.dst_stride + 16 * kq) = *(const uint4*)(stage + sr * ROWB + 16 * kq);
+                    *(uint4*)(dbase + (unsigned)sr * dst_stride32 + 16 * kq) = *(const uint4*)(stage + sr * ROWB + 16 * kq);
                 }
             } else if (b_hi > b_lo) {
                 for (int idx = lane_o; idx < 2 * R * WORDS; idx += 64) {
@@ -2416,6 +2446,8 @@ __global__ __launch_bounds__(512, 2) void tail_kernel(ConvArgs a)
             __builtin_amdgcn_wave_barrier();
         }
         if (stamp) a.dbg[8 * it + 3] = __builtin_amdgcn_s_memtime();
+        ctx = load_ctx(min(k + 2, nsched - 1));           // the group's next tile (past the end: an inert entry)
+        la = read_sched(min(k + 2 + TRUNK_LOOKAHEAD, nsched - 1));      // ... and the tile its k-loop will fetch
         group_barrier();
         cur = cur + 2 >= TRUNK_SLOTS ? cur + 2 - TRUNK_SLOTS : cur + 2;
     }
@@ -2457,7 +2489,13 @@ __global__ __launch_bounds__(512, 2) void tail4_kernel(ConvArgs a)
     constexpr int R = 4, MB = TAIL4_MB;
     constexpr int CPW = TG::CPW;
     constexpr int SLOTB = TG::SLOTB;
-    constexpr int PFF = 3;                    // B fragments read ahead
+#ifndef TAIL4_PFF
+#define TAIL4_PFF 6
+#endif
+#ifndef TAIL4_AD
+#define TAIL4_AD 2
+#endif
+    constexpr int PFF = TAIL4_PFF;            // B fragments read ahead
     constexpr int NSTEP = 24;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2539,29 +2577,45 @@ __global__ __launch_bounds__(512, 2) void tail4_kernel(ConvArgs a)
     const char* const resid_rd = resid_all + wave8 * 128;
     const char* const wrd = w_lds + lane * 16;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // the lane's 3 x 4 output channels' bias, resident (no LDS round trip at the top of every epilogue)
+    f32x4 b4[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) b4[m] = *(const f32x4*)(bias_lds + 16 * m + 4 * (lane >> 4));
+    // the next tile's schedule entry and plane fields are read at the end of the previous iteration (see tail_kernel)
+    struct TileCtx { Sched own; int pl_h, pl_w, src_y0, src_x0, core_y0, core_y1, core_x0, core_x1; };
+    auto load_ctx = [&](int k) __attribute__((always_inline)) {
+        TileCtx c;
+        c.own = read_sched(k);
+        const PlaneDesc& pl = planes_lds[c.own.plane];
+        c.pl_h = __builtin_amdgcn_readfirstlane(pl.h); c.pl_w = __builtin_amdgcn_readfirstlane(pl.w);
+        c.src_y0 = __builtin_amdgcn_readfirstlane(pl.src_y0); c.src_x0 = __builtin_amdgcn_readfirstlane(pl.src_x0);
+        c.core_y0 = __builtin_amdgcn_readfirstlane(pl.core_y0); c.core_y1 = __builtin_amdgcn_readfirstlane(pl.core_y1);
+        c.core_x0 = __builtin_amdgcn_readfirstlane(pl.core_x0); c.core_x1 = __builtin_amdgcn_readfirstlane(pl.core_x1);
+        return c;
+    };
+    TileCtx ctx = load_ctx(grp);
+    const unsigned src_lo2 = (unsigned)(size_t)a.src_u8 & 3u, src_stride32 = (unsigned)a.src_stride;
     for (int it = 0; it < niter0; ++it) {
         const bool active = it < niter;
         const int k = 2 * it + grp;
-        const Sched own = read_sched(k);
-        const PlaneDesc& pl = planes_lds[own.plane];
-        const int pl_h = __builtin_amdgcn_readfirstlane(pl.h), pl_w = __builtin_amdgcn_readfirstlane(pl.w);
-        const int src_y0 = __builtin_amdgcn_readfirstlane(pl.src_y0), src_x0 = __builtin_amdgcn_readfirstlane(pl.src_x0);
+        const Sched own = ctx.own;
+        const int pl_h = ctx.pl_h, pl_w = ctx.pl_w, src_y0 = ctx.src_y0, src_x0 = ctx.src_x0;
         const int y_t = own.ty * TH4 + 2 * rp;            // plane-local first row of this wave
         const int xs = own.tx * TW + 16 * cc;             // plane-local first column of this wave
-        // residual source bytes: rows y_t, y_t+1 (clamped), columns xs .. xs+15 (clamped), 2 x 13 dwords
+        // residual source bytes: rows y_t, y_t+1 (clamped), columns xs .. xs+15 (clamped), 2 x 13 dwords; 32-bit frame offsets
         int sh[2];
         {
             const int xc = min(xs, pl_w - 1);
-            const int nb = 3 * min(16, pl_w - xc);
+            const unsigned nb = 3u * (unsigned)min(16, pl_w - xc);
             unsigned voff = 0;
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const int yc = min(y_t + n, pl_h - 1);
-                const size_t ra = (size_t)(src_y0 + yc) * a.src_stride + (size_t)(src_x0 + xc) * 3;
-                const size_t abs = (size_t)a.src_u8 + ra;
-                sh[n] = (int)(abs & 3);
-                const int dmax = (int)((((abs + nb - 1) & ~(size_t)3) - (abs & ~(size_t)3)) >> 2);
-                const unsigned vo = (unsigned)(ra - sh[n]) + 4u * (unsigned)min(lane & 15, dmax);
+                const unsigned ra = (unsigned)(src_y0 + yc) * src_stride32 + (unsigned)(src_x0 + xc) * 3u;
+                const unsigned al = src_lo2 + ra;
+                sh[n] = (int)(al & 3u);
+                const int dmax = (int)((((al + nb - 1u) & ~3u) - (al & ~3u)) >> 2);
+                const unsigned vo = (ra - (unsigned)sh[n]) + 4u * (unsigned)min(lane & 15, dmax);
                 if ((lane >> 4) == n) voff = vo;
             }
             if (active && lane < 32) glds4_s(a.src_u8, voff, resid_lds);
@@ -2583,31 +2637,37 @@ __global__ __launch_bounds__(512, 2) void tail4_kernel(ConvArgs a)
                 return *(const half8*)(wrd + ((((Rr * 3 + dx) * 2 + ch) * MB + m) * 1024));
             };
             constexpr int RQ = PFF + 1;
+            constexpr int AD = TAIL4_AD, AQ = AD + 2;     // weight fragments read AD steps ahead; steps st and st - 1 are in use
             half8 bq[RQ];
-            half8 a_cur[MB], a_prev[MB], a_next[MB];
+            half8 aq[AQ][MB];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int f = 0; f < PFF; ++f) bq[f] = read_b(f);
 #pragma unroll
-            for (int m = 0; m < MB; ++m) { a_next[m] = read_a(0, m); a_cur[m] = a_next[m]; }
+            for (int f = 0; f < AD; ++f)
 #pragma unroll
-            for (int st = 0; st < NSTEP; ++st) {
-                const int Rr = st & 3;
-                if (st + PFF < NSTEP) bq[(st + PFF) % RQ] = read_b(st + PFF);
+                for (int m = 0; m < MB; ++m) aq[f][m] = read_a(f, m);
+            __builtin_amdgcn_sched_barrier(0);
+            // pinned step by step like the 2x tail's (left alone hipcc waits for every fragment right in front of its MFMAs)
+            static_for<NSTEP>([&](auto sc) __attribute__((always_inline)) {
+                constexpr int st = decltype(sc)::value, Rr = st & 3;
+                if constexpr (st + PFF < NSTEP) bq[(st + PFF) % RQ] = read_b(st + PFF);
+                if constexpr (st + AD < NSTEP && ((st + AD) & 3) <= 2) {
 #pragma unroll
-                for (int m = 0; m < MB; ++m) { a_prev[m] = a_cur[m]; a_cur[m] = a_next[m]; }
-                if (st + 1 < NSTEP && ((st + 1) & 3) <= 2) {
-#pragma unroll
-                    for (int m = 0; m < MB; ++m) a_next[m] = read_a(st + 1, m);
+                    for (int m = 0; m < MB; ++m) aq[(st + AD) % AQ][m] = read_a(st + AD, m);
                 }
                 const half8 b = bq[st % RQ];
 #pragma unroll
                 for (int m = 0; m < MB; ++m) {
-                    if (Rr <= 2)    // output row 0, tap (dy = Rr, dx)
-                        acc[0][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur[m], b, st == 0 ? zero4 : acc[0][m], 0, 0, 0);
-                    if (Rr >= 1)    // output row 1, tap (dy = Rr - 1, dx): the previous step's weights
-                        acc[1][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_prev[m], b, st == 1 ? zero4 : acc[1][m], 0, 0, 0);
+                    if constexpr (Rr <= 2)    // output row 0, tap (dy = Rr, dx)
+                        acc[0][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aq[st % AQ][m], b, st == 0 ? zero4 : acc[0][m], 0, 0, 0);
+                    if constexpr (Rr >= 1)    // output row 1, tap (dy = Rr - 1, dx): the previous step's weights
+                        acc[1][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aq[(st + AQ - 1) % AQ][m], b, st == 1 ? zero4 : acc[1][m], 0, 0, 0);
                 }
-            }
+#ifndef TAIL_NO_PIN
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            });
             __builtin_amdgcn_s_setprio(0);
         }
         // nothing was issued to the memory pipe during the k-loop except the residual dwords at its
@@ -2620,34 +2680,37 @@ __global__ __launch_bounds__(512, 2) void tail4_kernel(ConvArgs a)
             const int lane_o = opaque(lane);
             const int g = lane_o >> 4, p = lane_o & 15;          // sub-row of the 4x4 output block, pixel
             const float norm = (float)(1 / 255.0);
-            const int core_y0 = __builtin_amdgcn_readfirstlane(pl.core_y0), core_y1 = min(__builtin_amdgcn_readfirstlane(pl.core_y1), pl_h);
-            const int core_x0 = __builtin_amdgcn_readfirstlane(pl.core_x0), core_x1 = min(__builtin_amdgcn_readfirstlane(pl.core_x1), pl_w);
+            const int core_y0 = ctx.core_y0, core_y1 = min(ctx.core_y1, pl_h);
+            const int core_x0 = ctx.core_x0, core_x1 = min(ctx.core_x1, pl_w);
             const bool col_ok = xs + p >= core_x0 && xs + p < core_x1;
             const bool aligned = (((size_t)a.dst_u8 | a.dst_stride) & 3) == 0;
-            f32x4 b4[MB];
-#pragma unroll
-            for (int m = 0; m < MB; ++m) b4[m] = *(const f32x4*)(bias_lds + 16 * m + 4 * g);
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const int y = y_t + n;
-                unsigned q[MB][4];
+                // (value + bias + residual) * 255 as floats; v_cvt_pk_u8_f32 rounds half to even, saturates and drops the byte
+                // into its place: cv2's convertTo(CV_8U) and the packing in one instruction per byte
+                float q[MB][4];
+                unsigned rb[MB];
+#pragma unroll
+                for (int m = 0; m < MB; ++m) rb[m] = *(const uint8_t*)(resid_rd + n * 64 + sh[n] + 3 * p + m);
 #pragma unroll
                 for (int m = 0; m < MB; ++m) {
-                    const float res = (float)*(const uint8_t*)(resid_rd + n * 64 + sh[n] + 3 * p + m) * norm;
+                    const float res = (float)rb[m] * norm;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float v = (acc[n][m][j] + b4[m][j]) + res;
-                        float r = __builtin_rintf(v * 255.0f);     // v_rndne_f32: ties to even
-                        r = fminf(fmaxf(r, 0.f), 255.f);
-                        q[m][j] = (unsigned)r;
-                    }
+                    for (int j = 0; j < 4; ++j) q[m][j] = ((acc[n][m][j] + b4[m][j]) + res) * 255.0f;
                 }
                 if (y >= core_y0 && y < core_y1 && col_ok) {
                     // output row 4y + g, pixels 4(x) .. 4(x)+3, BGR each: 12 contiguous bytes
                     uint8_t* d = a.dst_u8 + ((size_t)(src_y0 + y) * R + g) * a.dst_stride + (size_t)(src_x0 + xs + p) * R * 3;
-                    const unsigned d0 = q[0][0] | (q[1][0] << 8) | (q[2][0] << 16) | (q[0][1] << 24);
-                    const unsigned d1 = q[1][1] | (q[2][1] << 8) | (q[0][2] << 16) | (q[1][2] << 24);
-                    const unsigned d2 = q[2][2] | (q[0][3] << 8) | (q[1][3] << 16) | (q[2][3] << 24);
+                    auto pk4 = [](float b0, float b1, float b2, float b3) __attribute__((always_inline)) {
+                        unsigned r = __builtin_amdgcn_cvt_pk_u8_f32(b0, 0, 0u);
+                        r = __builtin_amdgcn_cvt_pk_u8_f32(b1, 1, r);
+                        r = __builtin_amdgcn_cvt_pk_u8_f32(b2, 2, r);
+                        return __builtin_amdgcn_cvt_pk_u8_f32(b3, 3, r);
+                    };
+                    const unsigned d0 = pk4(q[0][0], q[1][0], q[2][0], q[0][1]);
+                    const unsigned d1 = pk4(q[1][1], q[2][1], q[0][2], q[1][2]);
+                    const unsigned d2 = pk4(q[2][2], q[0][3], q[1][3], q[2][3]);
                     if (aligned) {
                         ((unsigned*)d)[0] = d0; ((unsigned*)d)[1] = d1; ((unsigned*)d)[2] = d2;
                     } else {
@@ -2662,6 +2725,7 @@ __global__ __launch_bounds__(512, 2) void tail4_kernel(ConvArgs a)
         // refill the slot this group has just consumed with tile k+3, behind the stores in the queue
 #pragma unroll
         for (int i = 0; i < CPW; ++i) trunk_issue_piece<NF>(la.base, la.pitch, lds0 + cur * SLOTB, i, wave, dma_pc[i]);
+        ctx = load_ctx(min(k + 2, nsched - 1));           // the group's next tile (past the end: an inert entry)
         group_barrier();
         cur = cur + 2 >= TAIL4_SLOTS ? cur + 2 - TAIL4_SLOTS : cur + 2;
     }
@@ -2676,8 +2740,11 @@ __global__ __launch_bounds__(512, 2) void tail4_kernel(ConvArgs a)
 // accumulator.  SRC 1: f32 planar source (an ncnn::Mat the caller normalised), rounded to fp16.
 // K is laid out as [tap][4] (3 channels + 1 zero) -> 36, padded to 3 k-steps of 16.
 // ----------------------------------------------------------------------------------------------
+#ifndef HEAD_WPE
+#define HEAD_WPE 3            // waves per SIMD the register allocation aims at (= workgroups per CU: one wave per SIMD each)
+#endif
 template <int NF, int SRC>
-__global__ __launch_bounds__(256) void head_kernel(HeadArgs a)
+__global__ __launch_bounds__(256, HEAD_WPE) void head_kernel(HeadArgs a)
 {
     constexpr int MF = (NF + 31) / 32;
     __shared__ __attribute__((aligned(16))) char hsm[NPIX * 8 + PARAM_LDS + 4 * StageGeo<NF>::BYTES];
@@ -2690,43 +2757,79 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a)
     const int half = lane >> 5;
     const int px = lane & 31;
 
-    const PlaneDesc* gpl = a.planes;
-    TileId id;
-    id.plane = __builtin_amdgcn_readfirstlane(
-        find_plane([gpl](int i) { return gpl[i].tile_begin; }, a.nplanes, (int)blockIdx.x, lane));
-    const PlaneDesc& pl = a.planes[id.plane];
-    {
-        const int local = (int)blockIdx.x - pl.tile_begin;
-        id.ty = local / pl.ntx;
-        id.tx = local - id.ty * pl.ntx;
-    }
-
-    if (threadIdx.x < 64) {
-        bias_lds[threadIdx.x] = threadIdx.x < MF * 32 ? a.bias[threadIdx.x] : 0.f;
-        const float sl = threadIdx.x < MF * 32 ? a.slope[threadIdx.x] : 0.f;
-        slope_lds[threadIdx.x] = sl;
-        slope_lds[64 + threadIdx.x] = sl <= 1.f ? __builtin_inff() : -__builtin_inff();
-    }
-    for (int p = threadIdx.x; p < NPIX; p += 256) {
-        const int r = p / PW, c = p - (p / PW) * PW;
-        const int y = id.ty * TH + r - 1, x = id.tx * TW + c - 1;
-        half4 v = {0, 0, 0, 0};
-        if (y >= 0 && y < pl.h && x >= 0 && x < pl.w) {     // zero padding at the PLANE edge
-            if constexpr (SRC == 0) {
-                const uint8_t* s = a.src_u8 + (size_t)(pl.src_y0 + y) * a.src_stride + (size_t)(pl.src_x0 + x) * 3;
-                v[0] = (_Float16)(float)s[0]; v[1] = (_Float16)(float)s[1]; v[2] = (_Float16)(float)s[2];
-            } else {
-                const size_t hw = (size_t)pl.h * pl.w, o = (size_t)y * pl.w + x;
-                v[0] = (_Float16)a.src_f32[o]; v[1] = (_Float16)a.src_f32[hw + o]; v[2] = (_Float16)a.src_f32[2 * hw + o];
-            }
-        }
-        tile[p] = v;
-    }
+    // Everything a workgroup needs from memory is requested up front -- weights, parameters, the plane lookup -- and
+    // the tile's pixels in ONE batch behind the lookup: two dependent round trips per workgroup instead of four
+    // (weights were fetched behind the pixel loop, whose iterations each waited for their own loads).  The kernel
+    // writes 128 B per pixel and computes next to nothing: its time is the length of this chain divided by the
+    // workgroups a CU holds (profiles/r04_ab_results.txt block 17).
+#ifndef HEAD_SERIAL_LOADS
     half8 w[3][MF];
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
         for (int m = 0; m < MF; ++m) w[ks][m] = a.wpk[(ks * MF + m) * 64 + lane];
+    float prm_b = 0.f, prm_s = 0.f;
+    if (threadIdx.x < MF * 32) { prm_b = a.bias[threadIdx.x]; prm_s = a.slope[threadIdx.x]; }
+#endif
+    const PlaneDesc* gpl = a.planes;
+    TileId id;
+    id.plane = __builtin_amdgcn_readfirstlane(
+        find_plane([gpl](int i) { return gpl[i].tile_begin; }, a.nplanes, (int)blockIdx.x, lane));
+    const PlaneDesc& pl = a.planes[id.plane];
+    const int pl_h = __builtin_amdgcn_readfirstlane(pl.h), pl_w = __builtin_amdgcn_readfirstlane(pl.w);
+    const int src_y0 = __builtin_amdgcn_readfirstlane(pl.src_y0), src_x0 = __builtin_amdgcn_readfirstlane(pl.src_x0);
+    {
+        const int local = (int)blockIdx.x - __builtin_amdgcn_readfirstlane(pl.tile_begin);
+        const int ntx = __builtin_amdgcn_readfirstlane(pl.ntx);
+        id.ty = local / ntx;
+        id.tx = local - id.ty * ntx;
+    }
+#ifdef HEAD_SERIAL_LOADS
+    float prm_b = 0.f, prm_s = 0.f;
+    if (threadIdx.x < MF * 32) { prm_b = a.bias[threadIdx.x]; prm_s = a.slope[threadIdx.x]; }
+#endif
+    // the halo tile's pixels: 340 for 256 threads -- two per thread, both requested before either is used
+    constexpr int PPT = (NPIX + 255) / 256;
+    float pv[PPT][3];
+    bool pin[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        // loads without a condition around them (addresses clamped into the plane, the value dropped afterwards): inside an
+        // exec-masked block hipcc waits for each pixel's bytes before it requests the next pixel's
+        const int p = min((int)threadIdx.x + 256 * k, NPIX - 1);
+        const int r = p / PW, c = p - (p / PW) * PW;
+        const int y = id.ty * TH + r - 1, x = id.tx * TW + c - 1;
+        pin[k] = y >= 0 && y < pl_h && x >= 0 && x < pl_w;      // zero padding at the PLANE edge
+        const int yc = min(max(y, 0), pl_h - 1), xc = min(max(x, 0), pl_w - 1);
+        if constexpr (SRC == 0) {
+            const uint8_t* sp = a.src_u8 + (size_t)(src_y0 + yc) * a.src_stride + (size_t)(src_x0 + xc) * 3;
+            pv[k][0] = (float)sp[0]; pv[k][1] = (float)sp[1]; pv[k][2] = (float)sp[2];
+        } else {
+            const size_t hw = (size_t)pl_h * pl_w, o = (size_t)yc * pl_w + xc;
+            pv[k][0] = a.src_f32[o]; pv[k][1] = a.src_f32[hw + o]; pv[k][2] = a.src_f32[2 * hw + o];
+        }
+    }
+    if (threadIdx.x < 64) {
+        bias_lds[threadIdx.x] = prm_b;
+        slope_lds[threadIdx.x] = prm_s;
+        slope_lds[64 + threadIdx.x] = prm_s <= 1.f ? __builtin_inff() : -__builtin_inff();
+    }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int p = threadIdx.x + 256 * k;
+        if (p < NPIX) {
+            half4 v = {(_Float16)pv[k][0], (_Float16)pv[k][1], (_Float16)pv[k][2], (_Float16)0.f};
+            if (!pin[k]) v = half4{0, 0, 0, 0};
+            tile[p] = v;
+        }
+    }
+#ifdef HEAD_SERIAL_LOADS
+    half8 w[3][MF];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int m = 0; m < MF; ++m) w[ks][m] = a.wpk[(ks * MF + m) * 64 + lane];
+#endif
     __syncthreads();
 
     f32x16 acc[2][MF];
