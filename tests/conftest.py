@@ -13,6 +13,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_cuda_first(request):
+    """Tests that hand torch CUDA tensors to the library need torch's own HIP runtime initialised BEFORE libuva.so brings up
+    the one it links against: the other way round torch reports "No HIP GPUs are available" (seen with
+    `pytest tests/test_gpu_workers.py tests/test_rawvideo.py -m gpu`; the whole suite happened to run in a good order)."""
+    if any(item.get_closest_marker("gpu") for item in request.session.items):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass
+    yield
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU oracle (test infrastructure; oracle/oracle.c built with gcc)."""

@@ -187,7 +187,8 @@ struct uva_net {
     long long next_ticket = 0;
     // profiling
     bool prof = false;
-    std::vector<hipEvent_t> ev_free;
+    std::vector<hipEvent_t> ev_free;        // timing-only events (no system-scope fence: take_event)
+    std::vector<hipEvent_t> ev_sync_free;   // ordering events between streams (take_sync_event)
     struct EvSet { hipEvent_t e[4]; int ntrunk; };
     std::vector<EvSet> ev_pending;
     struct EvPair { hipEvent_t a, b; int kind; };       // generic graphs: one launch of rdb4_kernel (kind 1) / the 192 -> 64 convolution (2)
@@ -248,6 +249,8 @@ struct uva_net {
         ev_pairs.clear();
         for (auto e : ev_free) (void)hipEventDestroy(e);
         ev_free.clear();
+        for (auto e : ev_sync_free) (void)hipEventDestroy(e);
+        ev_sync_free.clear();
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
         dev_ready = false;
@@ -1025,6 +1028,7 @@ int get_workspace(uva_net* n, int h, int w, int tile_size, int border, Workspace
 }
 
 hipEvent_t take_event(uva_net* n);
+hipEvent_t take_sync_event(uva_net* n);
 
 // A pair of events around one launch (profiling): begin() records the first, end() the second and queues the pair; a pair
 // that is not completed -- an event could not be created, a call in between failed -- gives its events back.
@@ -1063,8 +1067,27 @@ hipEvent_t take_event(uva_net* n)
         n->ev_free.pop_back();
         return e;
     }
+    // (hipEventDisableSystemFence -- no L2 write-back at a timing event -- measured: no difference in the frame time or in the
+    // kernel times the events bracket, profiles/r04_ab_results.txt block 18; default events kept)
     hipEvent_t e = nullptr;
     const hipError_t rc = hipEventCreate(&e);
+    if (rc != hipSuccess) {
+        fail(std::string("hipEventCreate: ") + hipGetErrorString(rc));
+        return nullptr;
+    }
+    return e;
+}
+
+// an event that orders one stream behind another (default flags: its release makes the producer's writes visible)
+hipEvent_t take_sync_event(uva_net* n)
+{
+    if (!n->ev_sync_free.empty()) {
+        hipEvent_t e = n->ev_sync_free.back();
+        n->ev_sync_free.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    const hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming);
     if (rc != hipSuccess) {
         fail(std::string("hipEventCreate: ") + hipGetErrorString(rc));
         return nullptr;
@@ -2133,19 +2156,19 @@ int uva_denoise_u8_device(int device, const void* d_in, int h, int w, size_t in_
     if (c->table_h[0] != h_luma || c->table_h[1] != h_color) HIP_TRY(hipStreamSynchronize(c->stream));
     if (denoise_table(*c, 0, h_luma, 1) || denoise_table(*c, 1, h_color, 2)) return 1;
     if (after) {                 // what `after` has been asked to do so far (it wrote d_in, or still reads d_out) comes first
-        hipEvent_t e = take_event(after);
+        hipEvent_t e = take_sync_event(after);
         if (!e) return 1;
         HIP_TRY(hipEventRecord(e, after->stream));
         HIP_TRY(hipStreamWaitEvent(c->stream, e, 0));
-        after->ev_free.push_back(e);
+        after->ev_sync_free.push_back(e);
     }
     if (denoise_launch(c, (const uint8_t*)d_in, in_stride, (uint8_t*)d_out, out_stride, h, w)) return 1;
     if (before) {                // ... and whatever `before` is asked to do from now on comes after this frame
-        hipEvent_t e = take_event(before);
+        hipEvent_t e = take_sync_event(before);
         if (!e) return 1;
         HIP_TRY(hipEventRecord(e, c->stream));
         HIP_TRY(hipStreamWaitEvent(before->stream, e, 0));
-        before->ev_free.push_back(e);
+        before->ev_sync_free.push_back(e);
     }
     return 0;
 }
@@ -2363,11 +2386,11 @@ int uva_net_wait_for(uva_net* n, uva_net* producer)
     if (n == producer || !producer->dev_ready) return 0;
     if (ensure_device(n)) return 1;
     if (producer->device != n->device) return fail("uva_net_wait_for: nets are on different devices");
-    hipEvent_t e = take_event(n);
+    hipEvent_t e = take_sync_event(n);
     if (!e) return 1;
     HIP_TRY(hipEventRecord(e, producer->stream));
     HIP_TRY(hipStreamWaitEvent(n->stream, e, 0));
-    n->ev_free.push_back(e);   // safe to recycle: the wait has captured the recorded state
+    n->ev_sync_free.push_back(e);   // safe to recycle: the wait has captured the recorded state
     return 0;
 }
 
