@@ -30,6 +30,21 @@ __global__ __launch_bounds__(256) void k_write_tile(uint4* dst, size_t n16)
     }
 }
 
+// head_kernel's store pattern: one block per 8-row x 32-pixel tile of a 970-wide plane (pitch 972 pixels): wave w writes rows
+// 2w, 2w+1 of the tile, 4 KB each, 124 KB apart
+__global__ __launch_bounds__(256) void k_write_tiles(char* dst, int ntx, int pitch_px)
+{
+    const int ty = blockIdx.x / ntx, tx = blockIdx.x - ty * ntx;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint4 v = make_uint4(threadIdx.x, blockIdx.x, 3, 4);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        char* row = dst + ((size_t)(ty * 8 + 2 * wave + n + 1) * pitch_px + tx * 32 + 1) * 128;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *(uint4*)(row + (k * 64 + lane) * 16) = v;
+    }
+}
+
 template <int NT>
 __global__ __launch_bounds__(256) void k_write_persist(uint4* dst, size_t n16)
 {
@@ -144,17 +159,28 @@ static void timeit(const char* name, double bytes, F&& launch)
 
 int main()
 {
-    char *a, *b;
+    // NBUF arrays per direction, used in turn: a pass over the SAME 273 MB again and again is served in part by the 256 MB
+    // Infinity Cache (first version of this file: write-only 39 us = 7.0 TB/s, which no HBM3E stack delivers)
+    constexpr int NBUF = 6;
+    char *abuf[NBUF], *bbuf[NBUF];
     unsigned* out;
-    // two arrays used alternately would hide nothing here: 273 MB is beyond the 256 MB of MALL plus L2; one array per direction
-    CK(hipMalloc(&a, BYTES + (1 << 20)));
-    CK(hipMalloc(&b, BYTES + (1 << 20)));
+    for (int i = 0; i < NBUF; ++i) {
+        CK(hipMalloc(&abuf[i], BYTES + (1 << 20)));
+        CK(hipMalloc(&bbuf[i], BYTES + (1 << 20)));
+        CK(hipMemset(abuf[i], 1, BYTES));
+        CK(hipMemset(bbuf[i], 2, BYTES));
+    }
     CK(hipMalloc(&out, 64));
-    CK(hipMemset(a, 1, BYTES));
-    CK(hipMemset(b, 2, BYTES));
+    int turn = 0;
+#define a (abuf[(turn++) % NBUF])
+#define b (bbuf[(turn++) % NBUF])
     const size_t n16 = BYTES / 16;
-    printf("array: %.1f MB\n", BYTES / 1e6);
+    printf("array: %.1f MB, %d arrays per direction used in turn\n", BYTES / 1e6, NBUF);
     timeit("W  one block per 32 KB (8336 blocks of 256)", BYTES, [&] { k_write_tile<<<(unsigned)((n16 + 2047) / 2048), 256>>>((uint4*)a, n16); });
+    {
+        const int ntx = 30, nty = 270;      // 30 full tiles per row of tiles, pitch 972: 270 x 8 + 2 rows stay inside the array
+        timeit("W  head_kernel's pattern: 8 x 32-pixel tiles, rows 124 KB apart", (double)ntx * nty * 32768, [&] { k_write_tiles<<<ntx * nty, 256>>>(a, ntx, 972); });
+    }
     for (int nwg : {1, 2, 4, 8}) {
         char nm[96];
         snprintf(nm, sizeof nm, "W  persistent, %d x 256 blocks of 256", nwg);

@@ -723,6 +723,22 @@ int launch_pair24(uva_net* n, const ConvArgs& a)
 
 int launch_head(uva_net* n, bool f32, const HeadArgs& a)
 {
+    // headp_kernel (persistent, the next tile's pixels requested while this one is computed) unless UVA_HEAD_PERSIST=0
+    static const bool persist = [] { const char* v = std::getenv("UVA_HEAD_PERSIST"); return !v || std::atoi(v) != 0; }();
+    if (persist && a.sink) {
+        const dim3 grid(std::min(a.ntiles, n->ncu * HEADP_WG_PER_CU)), block(256);
+        if (n->g.nf == 64) {
+            const size_t lds = headp_lds_bytes<64>();
+            if (f32) hipLaunchKernelGGL((headp_kernel<64, 1>), grid, block, lds, n->stream, a);
+            else hipLaunchKernelGGL((headp_kernel<64, 0>), grid, block, lds, n->stream, a);
+        } else {
+            const size_t lds = headp_lds_bytes<24>();
+            if (f32) hipLaunchKernelGGL((headp_kernel<24, 1>), grid, block, lds, n->stream, a);
+            else hipLaunchKernelGGL((headp_kernel<24, 0>), grid, block, lds, n->stream, a);
+        }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     const dim3 grid(a.ntiles), block(256);
     if (n->g.nf == 64) {
         if (f32) hipLaunchKernelGGL((head_kernel<64, 1>), grid, block, 0, n->stream, a);
@@ -1186,6 +1202,7 @@ int run_graph(uva_net* n, Workspace* ws, bool f32, const void* src, size_t src_s
     ha.bias = n->layers[0].bias;
     ha.slope = n->layers[0].slope;
     ha.in_scale = f32 ? 1.0f : (float)(1 / 255.0);
+    ha.sink = n->d_sink;
     if (launch_head(n, f32, ha)) return 1;
     if (prof) HIP_TRY(hipEventRecord(ev.e[1], n->stream));
 

@@ -136,6 +136,7 @@ struct HeadArgs {
     const float* bias;
     const float* slope;
     float in_scale;               // 1/255 for u8 sources (applied to the fp32 accumulator), else 1
+    _Float16* sink;               // headp_kernel: where lanes that own no output pixel store to (>= 1 KiB)
 };
 
 // End of a tile's k-loop: wait until all but the newest KEEP vector-memory operations of this
@@ -2867,6 +2868,201 @@ __global__ __launch_bounds__(256, HEAD_WPE) void head_kernel(HeadArgs a)
     }
     store_trunk_rows<NF, MF>(acc, slope_lds, hsm + NPIX * 8 + PARAM_LDS + wave * StageGeo<NF>::BYTES, a.out_act, pl,
                              id.ty * TH + 2 * wave, id.tx * TW, lane);
+}
+
+// ----------------------------------------------------------------------------------------------
+// headp_kernel<NF, SRC>: head_kernel's arithmetic (same K layout, same rounding points, same bytes) as a PERSISTENT,
+// software-pipelined kernel.  head_kernel writes 128 B per pixel and computes next to nothing, yet ran at half the
+// rate a plain store loop reaches (tools/hbm_stream_bench.hip: 273 MB in 39 us): a workgroup lived for its chain of
+// dependent loads -- plane lookup, pixels, (weights) -- and a CU holds three of them.  Here a workgroup keeps its
+// weights, parameters and the plane table, walks tiles blockIdx.x, + gridDim.x, ... and requests tile t + 1's pixels
+// before it computes tile t, so the only thing it waits for is the barrier between "pixels in LDS" and the MFMAs.
+// Every store is unconditional (lanes that own nothing write to the sink): a fixed number of memory operations per
+// tile, none of them inside a branch.
+// ----------------------------------------------------------------------------------------------
+constexpr int HEADP_WG_PER_CU = 3;
+template <int NF>
+constexpr int headp_lds_bytes() { return 2 * NPIX * 8 + PARAM_LDS + PLANE_LDS + 4 * StageGeo<NF>::BYTES; }
+
+template <int NF, int SRC>
+__global__ __launch_bounds__(256, HEADP_WG_PER_CU) void headp_kernel(HeadArgs a)
+{
+    constexpr int MF = (NF + 31) / 32;
+    constexpr int SPX = StageGeo<NF>::SPX, PIXB = NF * 2, SPP = NF / 8;
+    extern __shared__ __attribute__((aligned(16))) char hsm[];
+    half4* const tile0 = (half4*)hsm;
+    float* const bias_lds = (float*)(hsm + 2 * NPIX * 8);
+    float* const slope_lds = bias_lds + 64;
+    PlaneDesc* const planes_lds = (PlaneDesc*)(hsm + 2 * NPIX * 8 + PARAM_LDS);
+    int* const tbegin_lds = (int*)(hsm + 2 * NPIX * 8 + PARAM_LDS + MAX_PLANES * 64);
+    char* const stage = hsm + 2 * NPIX * 8 + PARAM_LDS + PLANE_LDS + (threadIdx.x >> 6) * StageGeo<NF>::BYTES;
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5;
+    const int px = lane & 31;
+
+    half8 w[3][MF];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int m = 0; m < MF; ++m) w[ks][m] = a.wpk[(ks * MF + m) * 64 + lane];
+    if (threadIdx.x < 64) {
+        const float b = threadIdx.x < MF * 32 ? a.bias[threadIdx.x] : 0.f;
+        const float sl = threadIdx.x < MF * 32 ? a.slope[threadIdx.x] : 0.f;
+        bias_lds[threadIdx.x] = b;
+        slope_lds[threadIdx.x] = sl;
+        slope_lds[64 + threadIdx.x] = sl <= 1.f ? __builtin_inff() : -__builtin_inff();
+    }
+    for (int i = threadIdx.x; i < a.nplanes * 16; i += 256) ((int*)planes_lds)[i] = ((const int*)a.planes)[i];
+    if ((int)threadIdx.x < a.nplanes) tbegin_lds[threadIdx.x] = a.planes[threadIdx.x].tile_begin;
+    __syncthreads();
+    PlaneTable pt;
+    pt.pl = planes_lds;
+    pt.tile_begin = tbegin_lds;
+    pt.nplanes = a.nplanes;
+
+    // this thread's (up to) two pixels of a halo tile: position p = row r, column c
+    constexpr int PPT = (NPIX + 255) / 256;
+    int pr[PPT], pc[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int p = min((int)threadIdx.x + 256 * k, NPIX - 1);
+        pr[k] = p / PW;
+        pc[k] = p - pr[k] * PW;
+    }
+    struct Tile { int plane, ty, tx, pl_h, pl_w, src_y0, src_x0; };
+    auto locate = [&](int t) __attribute__((always_inline)) {
+        const TileId id = pt.decode(t, lane);
+        Tile r;
+        r.plane = id.plane; r.ty = id.ty; r.tx = id.tx;
+        const PlaneDesc& pl = planes_lds[id.plane];
+        r.pl_h = __builtin_amdgcn_readfirstlane(pl.h); r.pl_w = __builtin_amdgcn_readfirstlane(pl.w);
+        r.src_y0 = __builtin_amdgcn_readfirstlane(pl.src_y0); r.src_x0 = __builtin_amdgcn_readfirstlane(pl.src_x0);
+        return r;
+    };
+    float pv[PPT][3];
+    bool pin[PPT];
+    // requests the tile's pixels: no condition around the loads (addresses clamped into the plane, the value dropped later)
+    auto fetch = [&](const Tile& T) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int y = T.ty * TH + pr[k] - 1, x = T.tx * TW + pc[k] - 1;
+            pin[k] = y >= 0 && y < T.pl_h && x >= 0 && x < T.pl_w;      // zero padding at the PLANE edge
+            const int yc = min(max(y, 0), T.pl_h - 1), xc = min(max(x, 0), T.pl_w - 1);
+            if constexpr (SRC == 0) {
+                const uint8_t* sp = a.src_u8 + (size_t)(T.src_y0 + yc) * a.src_stride + (size_t)(T.src_x0 + xc) * 3;
+                pv[k][0] = (float)sp[0]; pv[k][1] = (float)sp[1]; pv[k][2] = (float)sp[2];
+            } else {
+                const size_t hw = (size_t)T.pl_h * T.pl_w, o = (size_t)yc * T.pl_w + xc;
+                pv[k][0] = a.src_f32[o]; pv[k][1] = a.src_f32[hw + o]; pv[k][2] = a.src_f32[2 * hw + o];
+            }
+        }
+    };
+
+    int t = blockIdx.x;
+    if (t >= a.ntiles) return;
+    Tile cur = locate(t);
+    fetch(cur);
+    int buf = 0;
+    char* const sink = (char*)a.sink + lane * 16;
+    for (; t < a.ntiles; t += gridDim.x) {
+        half4* const tile = tile0 + buf * NPIX;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int p = threadIdx.x + 256 * k;
+            if (p < NPIX) {
+                half4 v = {(_Float16)pv[k][0], (_Float16)pv[k][1], (_Float16)pv[k][2], (_Float16)0.f};
+                if (!pin[k]) v = half4{0, 0, 0, 0};
+                tile[p] = v;
+            }
+        }
+        __syncthreads();
+        // the next tile's pixels travel while this one is computed (past the end: this tile's again, dropped)
+        const int tn = t + (int)gridDim.x < a.ntiles ? t + (int)gridDim.x : t;
+        const Tile nxt = locate(tn);
+        fetch(nxt);
+
+        f32x16 acc[2][MF];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+#pragma unroll
+            for (int m = 0; m < MF; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[n][m][r] = 0.f;
+            const int pb = (2 * wave + n) * PW + px;
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                // K octet o = 2ks + half holds taps 2o and 2o+1 (tap 9.. are zero weights)
+                const int o0 = 2 * ks, o1 = 2 * ks + 1;
+                const int tA0 = min(2 * o0, 8), tB0 = min(2 * o0 + 1, 8);
+                const int tA1 = min(2 * o1, 8), tB1 = min(2 * o1 + 1, 8);
+                const int offA = half ? (tA1 / 3) * PW + tA1 % 3 : (tA0 / 3) * PW + tA0 % 3;
+                const int offB = half ? (tB1 / 3) * PW + tB1 % 3 : (tB0 / 3) * PW + tB0 % 3;
+                const half4 lo = tile[pb + offA], hi = tile[pb + offB];
+                half8 b;
+                b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = lo[3];
+                b[4] = hi[0]; b[5] = hi[1]; b[6] = hi[2]; b[7] = hi[3];
+#pragma unroll
+                for (int m = 0; m < MF; ++m)
+                    acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks][m], b, acc[n][m], 0, 0, 0);
+            }
+        }
+        // bias, PReLU (med3 form, as store_trunk_rows), fp16 -> the wave's staging area
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+#pragma unroll
+            for (int m = 0; m < MF; ++m) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (32 * m + 8 * g >= NF) continue;   // NF is a multiple of 8: groups are all-or-nothing
+                    const int cb = 32 * m + 8 * g + 4 * half;
+                    const f32x4 b4 = *(const f32x4*)(bias_lds + cb);
+                    const f32x4 s4 = *(const f32x4*)(slope_lds + cb);
+                    const f32x4 i4 = *(const f32x4*)(slope_lds + 64 + cb);
+                    f32x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float x = acc[n][m][4 * g + j] * a.in_scale + b4[j];
+                        v[j] = __builtin_amdgcn_fmed3f(x, x * s4[j], i4[j]);
+                    }
+                    const half2v lo = __builtin_convertvector(f32x2{v[0], v[1]}, half2v);
+                    const half2v hi = __builtin_convertvector(f32x2{v[2], v[3]}, half2v);
+                    uint2 o;
+                    o.x = __builtin_bit_cast(unsigned, lo);
+                    o.y = __builtin_bit_cast(unsigned, hi);
+                    *(uint2*)(stage + (n * 32 + px) * SPX + cb * 2) = o;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {
+            const PlaneDesc& pl = planes_lds[cur.plane];
+            const int pitch = __builtin_amdgcn_readfirstlane(pl.pitch);
+            const long long act_off = ((long long)__builtin_amdgcn_readfirstlane((int)(pl.act_off >> 32)) << 32) |
+                                      (unsigned)__builtin_amdgcn_readfirstlane((int)pl.act_off);
+            const int y0 = cur.ty * TH + 2 * wave, x0 = cur.tx * TW;
+            const int vx = min(TW, cur.pl_w - x0);          // valid pixels of this tile row (uniform)
+            constexpr int NIT = (32 * SPP + 63) / 64;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int y = y0 + n;
+                char* const grow = (char*)a.out_act + ((size_t)act_off + (size_t)(y + 1) * pitch + (x0 + 1)) * PIXB;
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) {
+                    const int q = min(k * 64 + lane, 32 * SPP - 1);
+                    const int pix = q / SPP, slot = q - pix * SPP;
+                    const bool ok = y < cur.pl_h && k * 64 + lane < 32 * SPP && pix < vx;
+                    char* const dst = ok ? grow + pix * PIXB + slot * 16 : sink;
+                    *(uint4*)dst = *(const uint4*)(stage + (n * 32 + pix) * SPX + slot * 16);
+                }
+            }
+        }
+        cur = nxt;
+        buf ^= 1;
+    }
 }
 
 }  // namespace uva
