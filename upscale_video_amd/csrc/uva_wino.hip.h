@@ -101,6 +101,20 @@ __device__ __forceinline__ unsigned pk_add_f16(unsigned a, unsigned b)
 #ifndef TW_PRIO_E
 #define TW_PRIO_E 0
 #endif
+// per group (A = waves 0-3, the producers; B = waves 4-7, the consumers, whose phases are the longer ones): k-loop / elsewhere.
+// The guide's "static priority for the younger half" is TW_PRIO_KB = TW_PRIO_EB = 1 with group A at 0 throughout.
+#ifndef TW_PRIO_KA
+#define TW_PRIO_KA TW_PRIO_K
+#endif
+#ifndef TW_PRIO_EA
+#define TW_PRIO_EA TW_PRIO_E
+#endif
+#ifndef TW_PRIO_KB
+#define TW_PRIO_KB TW_PRIO_K
+#endif
+#ifndef TW_PRIO_EB
+#define TW_PRIO_EB TW_PRIO_E
+#endif
 
 #ifdef UVA_INSTRUMENT
 #define TW_STAMP(k) do { if (stamp) a.dbg[16 * it + 8 * grp + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -460,14 +474,14 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
                 }
             };
             if (it < nsteps) {
-                __builtin_amdgcn_s_setprio(TW_PRIO_K);
+                __builtin_amdgcn_s_setprio(TW_PRIO_KA);
                 // steps that touch their plane's edge (uniform, few) mask what lies outside
 #if TW_INROWS > 0
                 if (edge) kloop(std::false_type{}, a6, [&](auto nc, auto kc) __attribute__((always_inline)) { slice(st2[0], std::true_type{}, nc, kc); });
                 else
 #endif
                 kloop(std::false_type{}, a6, [&](auto nc, auto kc) __attribute__((always_inline)) { slice(st2[0], std::false_type{}, nc, kc); });
-                __builtin_amdgcn_s_setprio(TW_PRIO_E);
+                __builtin_amdgcn_s_setprio(TW_PRIO_EA);
             }
             e_dma = load_a(it + 3 <= nsteps + TW_PAD_STEPS - 1 ? it + 3 : nsteps + TW_PAD_STEPS - 1);
             // the rows of step it + 1 (issued one iteration ago) are complete once only this phase's pieces are outstanding
@@ -579,12 +593,12 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
 #endif
             TW_STAMP(4);
             if (kact) {
-                __builtin_amdgcn_s_setprio(TW_PRIO_K);
+                __builtin_amdgcn_s_setprio(TW_PRIO_KB);
                 int bp = b10 - 4 - 2;              // block it - 1 begins at (4 (it - 1)) mod 10; the window starts two rows above
                 bp = bp < 0 ? bp + TW_BROWS : bp;
                 auto slk = make_slice(e_k);
                 kloop(std::true_type{}, bp, [&](auto nc, auto kc) __attribute__((always_inline)) { slk(st2[0], nc, kc); });
-                __builtin_amdgcn_s_setprio(TW_PRIO_E);
+                __builtin_amdgcn_s_setprio(TW_PRIO_EB);
             }
             e_3 = e_k;
 #ifdef TW_TRANSFORM_LAST
