@@ -50,11 +50,16 @@ def locate(off, planes, guard, pi):
 @pytest.mark.parametrize("h,w,tile,border", [
     (1080, 1920, 960, 10), (2160, 3840, 960, 10), (1080, 1920, 0, 0), (256, 256, 960, 10),
     (24, 40, 0, 0), (70, 75, 32, 10), (5, 3, 0, 0), (131, 61, 64, 10), (1, 1, 0, 0), (960, 960, 0, 0), (96, 128, 64, 10)])
-@pytest.mark.parametrize("six", [0, 1])
+@pytest.mark.parametrize("six", [0, 1, -1])
 def test_walking_the_lists_like_the_kernel(uva, h, w, tile, border, six, monkeypatch):
-    monkeypatch.setenv("UVA_TW_SIX", str(six))          # 1: a workgroup's first segment starts with all six input rows
+    # 1: a workgroup's first segment starts with all six input rows; -1 (the default): only where that shortens the longest list
+    if six >= 0:
+        monkeypatch.setenv("UVA_TW_SIX", str(six))
+    else:
+        monkeypatch.delenv("UVA_TW_SIX", raising=False)
     steps, nsteps, planes, guard = schedule(uva, h, w, tile, border)
-    assert bool(((steps[:, 0, 1] >> 25) & 1).any()) == bool(six)
+    if six >= 0:
+        assert bool(((steps[:, 0, 1] >> 25) & 1).any()) == bool(six)
     grid, stride, _ = steps.shape
     cover = [np.zeros((int(p[0]), int(p[1])), np.int32) for p in planes]
     for b in range(grid):
@@ -137,6 +142,14 @@ def test_walking_the_lists_like_the_kernel(uva, h, w, tile, border, six, monkeyp
     # balance: the longest list is within a few steps of the mean over the workgroups that have work
     busy = int((nsteps > 0).sum())
     assert int(nsteps.max()) <= -(-int(nsteps.sum()) // busy) + 4
+
+
+def test_six_row_starts_only_where_they_shorten_the_longest_list(uva, monkeypatch):
+    monkeypatch.delenv("UVA_TW_SIX", raising=False)
+    steps, nsteps, planes, guard = schedule(uva, 1080, 1920, 960, 10)        # reference tiling: 73 steps either way
+    assert int(nsteps.max()) == 73 and not ((steps[:, 0, 1] >> 25) & 1).any()
+    steps, nsteps, planes, guard = schedule(uva, 1080, 1920, 0, 0)           # whole frame: 69 -> 68
+    assert int(nsteps.max()) == 68 and ((steps[:, 0, 1] >> 25) & 1).any()
 
 
 def test_consecutive_ranges_share_an_xcd(uva):

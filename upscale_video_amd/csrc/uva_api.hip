@@ -515,47 +515,67 @@ int build_trunkw_schedule(const std::vector<PlaneDesc>& planes, int grid, size_t
                           std::vector<int>& nsteps, int* max_steps)
 {
     constexpr int PIXB = 128;
-    // UVA_TW_SIX=1: a workgroup's first segment starts with all six input rows (the kernel's prologue fetches them): 0.7 % fewer
-    // steps at 1080p, and measured 0.3 % SLOWER (the longest list is as long as before, the prologue longer): off by default
+    // A workgroup's FIRST segment can start with the two input rows a step shares with the one above it (the kernel's prologue
+    // fetches and transforms them: entry bit 25) and then yields 4k - 2 rows in k steps instead of 4 (k - 1).  The prologue is
+    // 0.3 % of a launch (measured), so this is done only where it shortens the LONGEST list (UVA_TW_SIX: 1 always, 0 never):
+    // a whole 1080p frame 69 -> 68 steps (+0.5 %), the reference tiling 73 -> 73 (left alone).  Also measured and not kept
+    // (profiles/r04_ab_results.txt block 20): segments at the TOP of a plane starting on two zero rows written by the consumers
+    // -- with the six-row starts 73 -> 72 steps at the reference tiling, and the same launch time: a segment's fill step, in
+    // which the consumers idle, costs about half a step.
     const char* const sx = std::getenv("UVA_TW_SIX");
-    const bool six_ok = sx && std::atoi(sx) != 0;
-    struct Seg { int plane, x0, r0, rows, k; bool full; };
+    const int six_mode = sx ? (std::atoi(sx) != 0 ? 1 : 0) : -1;
+    const bool top_ok = false;
+    struct Seg { int plane, x0, r0, rows, k; bool full, zero; };
     long long total = 0;
-    for (const auto& p : planes) total += (long long)((p.w + TW_SW - 1) / TW_SW) * ((p.h + 3) / 4 + 1);     // (an upper bound: first segments need less)
-    std::vector<std::vector<Seg>> per_wg;
-    int L = (int)std::max<long long>(4, (total + grid - 1) / grid);
-    for (;; ++L) {
-        per_wg.assign(1, {});
-        int cap = L;
-        auto next_wg = [&]() { per_wg.emplace_back(); cap = L; };
-        for (size_t pi = 0; pi < planes.size(); ++pi) {
-            const PlaneDesc& p = planes[pi];
-            for (int x0 = 0; x0 < p.w; x0 += TW_SW) {
-                int y = 0;
-                while (y < p.h) {
-                    // a workgroup's FIRST segment gets all six input rows of its first step (the kernel's prologue fetches the two
-                    // shared ones as well): k steps yield 4k - 2 rows there, 4 (k - 1) in the segments behind it
-                    const bool full = six_ok && per_wg.back().empty();
-                    const int need = full ? (p.h - y + 2 + 3) / 4 : (p.h - y + 3) / 4 + 1;
-                    if (need <= cap) {
-                        per_wg.back().push_back({(int)pi, x0, y, p.h - y, need, full});
-                        cap -= need;
-                        y = p.h;
-                    } else if (cap < 3) {             // a segment of fewer than 3 steps is mostly pipeline fill
-                        next_wg();
-                        continue;
-                    } else {
-                        const int rows = full ? 4 * cap - 2 : 4 * (cap - 1);
-                        per_wg.back().push_back({(int)pi, x0, y, rows, cap, full});
-                        y += rows;
-                        cap = 0;
+    for (const auto& p : planes) total += (long long)((p.w + TW_SW - 1) / TW_SW) * ((p.h + 3) / 4 + 1);     // (an upper bound: full segments need less)
+    auto pack = [&](bool six_ok, std::vector<std::vector<Seg>>& per_wg) {
+        int L = (int)std::max<long long>(4, (total + grid - 1) / grid - 2);
+        for (;; ++L) {
+            per_wg.assign(1, {});
+            int cap = L;
+            auto next_wg = [&]() { per_wg.emplace_back(); cap = L; };
+            for (size_t pi = 0; pi < planes.size(); ++pi) {
+                const PlaneDesc& p = planes[pi];
+                for (int x0 = 0; x0 < p.w; x0 += TW_SW) {
+                    int y = 0;
+                    while (y < p.h) {
+                        const bool zero = top_ok && y == 0;
+                        const bool full = zero || (six_ok && per_wg.back().empty());
+                        const int need = full ? (p.h - y + 2 + 3) / 4 : (p.h - y + 3) / 4 + 1;
+                        if (need <= cap) {
+                            per_wg.back().push_back({(int)pi, x0, y, p.h - y, need, full, zero});
+                            cap -= need;
+                            y = p.h;
+                        } else if (cap < 3) {             // a segment of fewer than 3 steps is mostly pipeline fill
+                            next_wg();
+                            continue;
+                        } else {
+                            const int rows = full ? 4 * cap - 2 : 4 * (cap - 1);
+                            per_wg.back().push_back({(int)pi, x0, y, rows, cap, full, zero});
+                            y += rows;
+                            cap = 0;
+                        }
+                        if (cap < 1) next_wg();
                     }
-                    if (cap < 1) next_wg();
                 }
             }
+            while (!per_wg.empty() && per_wg.back().empty()) per_wg.pop_back();
+            if ((int)per_wg.size() <= grid) break;
         }
-        while (!per_wg.empty() && per_wg.back().empty()) per_wg.pop_back();
-        if ((int)per_wg.size() <= grid) break;
+        int most = 0;
+        for (const auto& v : per_wg) {
+            int k = 0;
+            for (const Seg& sg : v) k += sg.k;
+            most = std::max(most, k);
+        }
+        return most;
+    };
+    std::vector<std::vector<Seg>> per_wg;
+    if (six_mode >= 0) pack(six_mode != 0, per_wg);
+    else {
+        std::vector<std::vector<Seg>> with_six;
+        const int m0 = pack(false, per_wg), m1 = pack(true, with_six);
+        if (m1 < m0) per_wg.swap(with_six);
     }
     int most = 0;
     for (const auto& v : per_wg) {
@@ -585,7 +605,7 @@ int build_trunkw_schedule(const std::vector<PlaneDesc>& planes, int grid, size_t
                     if (yA + r >= 0 && yA + r < p.h) rmask |= 1u << r;
                 const unsigned c_lo = sg.x0 == 0 ? 1 : 0, c_hi = (unsigned)std::min(32, p.w - sg.x0 + 1);
                 out[g].a = make_uint4((unsigned)ao, (unsigned)(ao >> 32) | (rmask << 8) | (c_lo << 12) | (c_hi << 18) | (1u << 24) |
-                                                    ((sg.full && j == 0) ? 1u << 25 : 0u),
+                                                    ((sg.full && !sg.zero && j == 0) ? 1u << 25 : 0u) | ((sg.zero && j == 0) ? 1u << 26 : 0u),
                                       (unsigned)(p.pitch * PIXB), (unsigned)sg.plane);
                 // the consumer step stores rows yo + [v0, v1) of its four (yo = yA - 1): those inside the segment
                 const int yo = yA - 1;
