@@ -65,4 +65,5 @@ UVA_TRUNK_WINO=0 UVA_LIB_PATH=$REPO/upscale_video_amd/libuva_instr.so python too
 UVA_LIB_PATH=$REPO/upscale_video_amd/libuva_instr.so python tools/sub10_anatomy.py > "$OUT/${TAG}_sub10_anatomy.txt" 2>&1
 python tools/soak.py 1000 > "$OUT/${TAG}_soak.txt" 2>&1
 timeout 1500 python -m pytest tests -m gpu -q > "$OUT/${TAG}_gpu_tests.txt" 2>&1
+(python -c "import __graft_entry__ as g; g.smoke(); print('smoke: ok')" 2>&1 | tail -3) > "$OUT/${TAG}_smoke.txt"
 ls -la "$OUT"
