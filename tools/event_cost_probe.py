@@ -32,16 +32,12 @@ def run(k):
 
 run(60)
 for rnd in range(4):
-    for mode in (1, 0, 2):
-        if mode == 2 and not hasattr(net, "set_profiling_every"):
-            continue
+    for mode in (1, 0):
         net.set_profiling(bool(mode))
-        if mode == 2:
-            net.set_profiling_every(4)
         run(10)
         t0 = time.perf_counter()
         run(n)
         dt = time.perf_counter() - t0
         net.kernel_stats(1)
         net.set_profiling(False)
-        print("profiling %s: %.4f ms per frame, %.1f frames/s" % ({1: "on ", 0: "off", 2: "1/4"}[mode], dt / n * 1e3, n / dt))
+        print("profiling %s: %.4f ms per frame, %.1f frames/s" % ({1: "on ", 0: "off"}[mode], dt / n * 1e3, n / dt))
