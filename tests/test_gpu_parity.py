@@ -404,6 +404,31 @@ def test_random_geometries_match_oracle(nets, oracle_models, oracle, key):
         assert d.max() <= 2 and psnr_u8(got, want) >= 50.0, (key, case, h, w, ts, int(d.max()), psnr_u8(got, want))
 
 
+@pytest.mark.parametrize("key", ["2x", "1x"])
+def test_persistent_head_changes_no_bit(nets, oracle, key, monkeypatch):
+    """headp_kernel (persistent, software-pipelined; the default) against head_kernel (one workgroup per tile): same bytes, on a
+    frame with partial tiles on both axes, whole and tiled (the 1x net's tiled route runs the 24-feature instantiation)."""
+    net = nets[key]
+    img = oracle.synthetic_frame(203, 331, kind="random", seed=77)
+    for ts in (0, 64):
+        monkeypatch.setenv("UVA_HEAD_PERSIST", "1")
+        a = net.process_u8(img, tile_size=ts, border=10 if ts else 0)
+        monkeypatch.setenv("UVA_HEAD_PERSIST", "0")
+        b = net.process_u8(img, tile_size=ts, border=10 if ts else 0)
+        assert np.array_equal(a, b), (key, ts)
+
+
+def test_frames_of_4_gb_and_more_are_refused(nets):
+    """the tail kernels address residual and output bytes with 32-bit offsets from the frame's base: the API says no up front"""
+    import ctypes
+    import torch
+    net = nets["2x"]
+    buf = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    rc = net._L.uva_net_process_u8_device(net._h, ctypes.c_void_p(buf.data_ptr()), 8, 16, ctypes.c_size_t(1 << 29),
+                                          ctypes.c_void_p(buf.data_ptr()), ctypes.c_size_t(16 * 2 * 3), 0, 0)
+    assert rc != 0 and b"4 GB" in net._L.uva_last_error()
+
+
 @pytest.mark.parametrize("key", ["2x", "4x"])
 def test_whole_1080p_frame_against_the_oracle(nets, oracle_models, oracle, key):
     """BASELINE config 2's frame (and config 4's runnable stand-in, 4x Compact), every output sample: the

@@ -744,7 +744,8 @@ int launch_pair24(uva_net* n, const ConvArgs& a)
 int launch_head(uva_net* n, bool f32, const HeadArgs& a)
 {
     // headp_kernel (persistent, the next tile's pixels requested while this one is computed) unless UVA_HEAD_PERSIST=0
-    static const bool persist = [] { const char* v = std::getenv("UVA_HEAD_PERSIST"); return !v || std::atoi(v) != 0; }();
+    const char* const hp = std::getenv("UVA_HEAD_PERSIST");        // (read per call: the GPU test switches it between two frames)
+    const bool persist = !hp || std::atoi(hp) != 0;
     if (persist && a.sink) {
         const dim3 grid(std::min(a.ntiles, n->ncu * HEADP_WG_PER_CU)), block(256);
         if (n->g.nf == 64) {
