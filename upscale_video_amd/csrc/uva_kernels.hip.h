@@ -3008,29 +3008,29 @@ __global__ __launch_bounds__(256, HEADP_WG_PER_CU) void headp_kernel(HeadArgs a)
                     acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks][m], b, acc[n][m], 0, 0, 0);
             }
         }
-        // bias, PReLU (med3 form, as store_trunk_rows), fp16 -> the wave's staging area
+        // bias, PReLU (med3 form, as store_trunk_rows), fp16 -> the wave's staging area.  The lane's parameters are read once
+        // per channel group for both rows; scale + bias and the slope product on float pairs (v_pk_fma_f32, v_pk_mul_f32: one
+        // rounding each, as the scalar forms)
+        const f32x2 sc2 = {a.in_scale, a.in_scale};
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
+        for (int m = 0; m < MF; ++m) {
 #pragma unroll
-            for (int m = 0; m < MF; ++m) {
+            for (int g = 0; g < 4; ++g) {
+                if (32 * m + 8 * g >= NF) continue;   // NF is a multiple of 8: groups are all-or-nothing
+                const int cb = 32 * m + 8 * g + 4 * half;
+                const f32x4 b4 = *(const f32x4*)(bias_lds + cb);
+                const f32x4 s4 = *(const f32x4*)(slope_lds + cb);
+                const f32x4 i4 = *(const f32x4*)(slope_lds + 64 + cb);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    if (32 * m + 8 * g >= NF) continue;   // NF is a multiple of 8: groups are all-or-nothing
-                    const int cb = 32 * m + 8 * g + 4 * half;
-                    const f32x4 b4 = *(const f32x4*)(bias_lds + cb);
-                    const f32x4 s4 = *(const f32x4*)(slope_lds + cb);
-                    const f32x4 i4 = *(const f32x4*)(slope_lds + 64 + cb);
-                    f32x4 v;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float x = acc[n][m][4 * g + j] * a.in_scale + b4[j];
-                        v[j] = __builtin_amdgcn_fmed3f(x, x * s4[j], i4[j]);
-                    }
-                    const half2v lo = __builtin_convertvector(f32x2{v[0], v[1]}, half2v);
-                    const half2v hi = __builtin_convertvector(f32x2{v[2], v[3]}, half2v);
+                for (int n = 0; n < 2; ++n) {
+                    const f32x2 x01 = __builtin_elementwise_fma(f32x2{acc[n][m][4 * g], acc[n][m][4 * g + 1]}, sc2, f32x2{b4[0], b4[1]});
+                    const f32x2 x23 = __builtin_elementwise_fma(f32x2{acc[n][m][4 * g + 2], acc[n][m][4 * g + 3]}, sc2, f32x2{b4[2], b4[3]});
+                    const f32x2 t01 = x01 * f32x2{s4[0], s4[1]}, t23 = x23 * f32x2{s4[2], s4[3]};
+                    const f32x2 v01 = {__builtin_amdgcn_fmed3f(x01[0], t01[0], i4[0]), __builtin_amdgcn_fmed3f(x01[1], t01[1], i4[1])};
+                    const f32x2 v23 = {__builtin_amdgcn_fmed3f(x23[0], t23[0], i4[2]), __builtin_amdgcn_fmed3f(x23[1], t23[1], i4[3])};
                     uint2 o;
-                    o.x = __builtin_bit_cast(unsigned, lo);
-                    o.y = __builtin_bit_cast(unsigned, hi);
+                    o.x = __builtin_bit_cast(unsigned, __builtin_convertvector(v01, half2v));
+                    o.y = __builtin_bit_cast(unsigned, __builtin_convertvector(v23, half2v));
                     *(uint2*)(stage + (n * 32 + px) * SPX + cb * 2) = o;
                 }
             }
