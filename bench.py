@@ -442,17 +442,23 @@ def run(args, comm, device):
     for i in range(args.warmup):
         step(i)
     sync()
-    net.set_profiling(True)
-    # >= 3 timed regions of exactly --steps steps each (every one bracketed by barrier + sync, MAX over ranks); the median counts
-    regions = [timed_region(lambda: [step(i) for i in range(args.steps)], sync, barrier, max_over_ranks) for _ in range(max(1, args.repeats))]
-    elapsed = sorted(regions)[len(regions) // 2]
-    n_launch, trunk_ms = net.kernel_stats(1)       # generic graphs: rdb4_kernel
-    _, head_ms = net.kernel_stats(0)
-    n_tail, tail_ms = net.kernel_stats(2)          # generic graphs: the dense blocks' 192 -> 64 convolution
+    # >= 3 timed regions of exactly --steps steps each (every one bracketed by barrier + sync, MAX over ranks); the MEDIAN region
+    # counts -- for `value` and for the kernel event statistics alike: set_profiling(True) zeroes the counters, so every region
+    # has its own, and the roofline's launch time is the reported region's (a process's first ~40 launches run while the clock
+    # still ramps: with the driver's --steps 20 --warmup 5 they sit in the first region; profiles/r04_ab_results.txt block 21)
+    regions, region_stats = [], []
+    for _ in range(max(1, args.repeats)):
+        net.set_profiling(True)
+        regions.append(timed_region(lambda: [step(i) for i in range(args.steps)], sync, barrier, max_over_ranks))
+        region_stats.append([net.kernel_stats(k) for k in range(3)])
     net.set_profiling(False)
+    median_idx = sorted(range(len(regions)), key=lambda i: regions[i])[len(regions) // 2]
+    elapsed = regions[median_idx]
+    (_, head_ms), (n_launch, trunk_ms), (n_tail, tail_ms) = region_stats[median_idx]   # kind 1: trunk launches (generic graphs:
+                                                                                       # rdb4_kernel), kind 2: tail (conv5)
 
     fps = whole_job_rate(args.steps, world, elapsed)
-    steps_timed = args.steps * len(regions)        # the kernel event statistics cover every region
+    steps_timed = args.steps                       # the kernel event statistics are the median region's
 
     # (E) pipelined host route, PCIe inclusive, on every rank at once: frames in page-locked host memory,
     # submit/collect with 3 frames in flight (SURVEY.md 8d "host-to-host with stream overlap")
@@ -500,7 +506,7 @@ def run(args, comm, device):
                             f"frames and results resident in HBM",
                 "route": "K (device-resident frames and results; host_route_* fields are PCIe inclusive and never `value`)",
                 "frames_per_rank": args.steps, "tile_size": args.tile, "parallelism": f"frame-sharded x{world}, no collective",
-                "timed_regions_s": [round(x, 5) for x in regions], "reported": "median region",
+                "timed_regions_s": [round(x, 5) for x in regions], "reported": "median region (value and kernel event statistics)",
                 "frame_tflop": round(frame_flops / 1e12, 4), "whole_path_tflops": round(frame_flops * fps / world / 1e12, 1),
                 "kernel_ms_per_frame": {"rdb4_kernel": round(trunk_ms / steps_timed, 3), "conv5 (g_conv3_sw<6,1>)": round(tail_ms / steps_timed, 3)},
                 "numa_cpus_rank0": (len(numa_cpus) if numa_cpus else None),
@@ -548,7 +554,7 @@ def run(args, comm, device):
                             f"frames and results resident in HBM",
                 "route": "K (device-resident frames and results; host_route_* fields are PCIe inclusive and never `value`)",
                 "frames_per_rank": args.steps, "tile_size": args.tile, "parallelism": f"frame-sharded x{world}, no collective",
-                "timed_regions_s": [round(x, 5) for x in regions], "reported": "median region",
+                "timed_regions_s": [round(x, 5) for x in regions], "reported": "median region (value and kernel event statistics)",
                 "launcher": {"SoloComm": "one process", "ForkComm": "python bench.py --gpus N: own processes, multiprocessing barrier, no RCCL",
                              "TorchComm": "torch.distributed.run, RCCL used for the timing fence only"}[type(comm).__name__],
                 "device_rank0": local_rank,
