@@ -151,15 +151,20 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
 #ifdef UVA_INSTRUMENT
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
 #endif
+    // The prologue is a chain of memory round trips (7 us of a 245 us launch by in-kernel stamps).  Shortening it -- step count and
+    // first entries requested together through asm, the first rows' DMA issued before anything waits for the parameters -- changed
+    // the launch time by nothing (profiles/r04_ab_results.txt block 22: a waiting workgroup costs no energy, and energy is what a
+    // launch at the package limit is made of); the reordering that needed no asm stays.
+    const Trunk2Step* const steps = a.steps + (size_t)blockIdx.x * (a.max_steps + TW_PAD_STEPS);
+    auto load_a = [&](int g) __attribute__((always_inline)) { return scalar_load16(&steps[g].a); };
+    auto load_b = [&](int g) __attribute__((always_inline)) { return scalar_load16(&steps[g].b); };
+    const uint4 e_first = load_a(0), e_second = load_a(1);        // (every workgroup's list has TW_PAD_STEPS entries at least)
     const int nsteps = __builtin_amdgcn_readfirstlane(a.nsteps[blockIdx.x]);
     if (nsteps <= 0) return;
 #ifdef UVA_INSTRUMENT
     const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && (threadIdx.x & 255) == 0;
     if (stamp && grp == 0) a.dbg[16 * (nsteps + 2)] = t_entry;
 #endif
-    const Trunk2Step* const steps = a.steps + (size_t)blockIdx.x * (a.max_steps + TW_PAD_STEPS);
-    auto load_a = [&](int g) __attribute__((always_inline)) { return scalar_load16(&steps[g].a); };
-    auto load_b = [&](int g) __attribute__((always_inline)) { return scalar_load16(&steps[g].b); };
 
     float prm_b = 0.f, prm_s = 0.f;
     if (wave == 0) {
@@ -186,15 +191,11 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
         for (int i = 0; i < 5; ++i) {
             if (4 * i + wave >= TW_RAW_PIECES) continue;
             const unsigned pc = (dma_pc2[i >> 1] >> (16 * (i & 1))) & 0xffffu;
-            glds16_s(base, (pc >> 13) * (unsigned)pitch + (pc & 0x1fffu), lds0 + TW_RAW + slot * TW_RAWSLOTB + (4 * i + wave) * 1024);
+            // (a 24-bit multiply-add: hipcc's v_mad_u64_u32 for the plain expression takes an UNDEFINED register as the high half of
+            // its addend, which in the prologue was one a parameter load was still writing -- a wait in front of the first DMA)
+            glds16_s(base, __umul24(pc >> 13, (unsigned)pitch) + (pc & 0x1fffu), lds0 + TW_RAW + slot * TW_RAWSLOTB + (4 * i + wave) * 1024);
         }
     };
-    if (wave == 0) {
-        float* prm = prm_all + grp * (PARAM_LDS / 4);
-        prm[lane] = prm_b;
-        prm[64 + lane] = prm_s;
-        prm[128 + lane] = prm_s <= 1.f ? __builtin_inff() : -__builtin_inff();
-    }
 
     // lane part of a transformed-row address, fragment / transform view (pair pq = lane & 15, K octet oq = lane >> 4): pair
     // record (64 B) + swizzled unit.  Recomputed from an opaque copy of the lane id where it is used: everything derived
@@ -256,11 +257,10 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
     // ---- prologue: weights, parameters; A: raw rows of steps 0 and 1, rows of step 0 transformed -----------------
     // The workgroup's first step gets all six input rows (flag in its entry): the two it would share with a step above are
     // fetched by waves 0 and 1 into the (still unused) B-ring and transformed into A-ring rows 0 and 1.
-    const uint4 e_first = load_a(0);
     const bool six = (__builtin_amdgcn_readfirstlane(e_first.y) >> 25) & 1u;
     if (grp == 0) {
         issue_rows(e_first, 0);
-        issue_rows(load_a(1), 1);
+        issue_rows(e_second, 1);
         if (six && wave < 2) {
             const unsigned lo = __builtin_amdgcn_readfirstlane(e_first.x), hi = __builtin_amdgcn_readfirstlane(e_first.y) & 0xffu;
             const int pitch = __builtin_amdgcn_readfirstlane(e_first.z);
@@ -276,6 +276,12 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
 #pragma unroll
         for (int i = 0; i < 24; ++i) asm volatile("" : "+v"(w[i]));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (wave == 0) {                   // (behind the DMA issue: the wait for the parameters runs beside the rows' flight)
+        float* prm = prm_all + grp * (PARAM_LDS / 4);
+        prm[lane] = prm_b;
+        prm[64 + lane] = prm_s;
+        prm[128 + lane] = prm_s <= 1.f ? __builtin_inff() : -__builtin_inff();
     }
     group_barrier();                   // every A wave's pieces have landed (each waited for its own)
     if (grp == 1) {
