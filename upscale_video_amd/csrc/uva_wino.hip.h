@@ -468,7 +468,7 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
                 }
             };
             // this group's share of the raw rows of step it + 1 -> A-ring (TW_XA of the four rows; the consumers take the rest)
-            auto raw_rows_a = [&]() __attribute__((always_inline)) {
+            [[maybe_unused]] auto raw_rows_a = [&]() __attribute__((always_inline)) {
                 if (it + 1 < nsteps) {
                     int pos0 = a6 + 4 + 2;
                     pos0 = pos0 >= TW_AROWS ? pos0 - TW_AROWS : pos0;
