@@ -252,21 +252,32 @@ class SoloComm:
         pass
 
 
+class RankLost(RuntimeError):
+    """a rank of a self-launched job died or never arrived: the fence was aborted instead of waiting for ever"""
+
+
 class ForkComm:
     """N ranks started by this script itself (python bench.py --gpus N): a multiprocessing.Barrier and a shared array --
-    the frame queue has no data-path collective, and its timing fence does not need RCCL either"""
+    the frame queue has no data-path collective, and its timing fence does not need RCCL either.  A fence never waits for
+    ever: the parent aborts the barrier as soon as a rank has exited (launch_ranks), and every wait has a timeout of its
+    own as the backstop (UVA_BENCH_BARRIER_TIMEOUT seconds, default 900) -- either way the rank raises RankLost."""
 
-    def __init__(self, rank, world, barrier, slots):
+    def __init__(self, rank, world, barrier, slots, timeout=None):
         self.rank, self.world, self._b, self._s = rank, world, barrier, slots
+        self._timeout = float(os.environ.get("UVA_BENCH_BARRIER_TIMEOUT", "900")) if timeout is None else timeout
 
     def barrier(self):
-        self._b.wait()
+        import threading
+        try:
+            self._b.wait(self._timeout)
+        except threading.BrokenBarrierError:
+            raise RankLost("rank %d: another rank left the job (or a fence timed out after %.0f s)" % (self.rank, self._timeout)) from None
 
     def max_over_ranks(self, x):
         self._s[self.rank] = x
-        self._b.wait()
+        self.barrier()
         m = max(self._s[:self.world])
-        self._b.wait()          # nobody overwrites its slot before everybody has read
+        self.barrier()          # nobody overwrites its slot before everybody has read
         return m
 
     def close(self):
@@ -298,9 +309,80 @@ class TorchComm:
 
 def _fork_rank(rank, world, device, barrier, slots, argv):
     """entry point of a self-launched rank (spawn context: a fresh interpreter)"""
-    os.environ["UVA_BENCH_DEVICE"] = str(device)
     sys.argv = argv
     run(parse_args(argv[1:]), ForkComm(rank, world, barrier, slots), device)
+
+
+def launch_ranks(world, devices, argv, target=None, poll_s=0.2, grace_s=5.0):
+    """python bench.py --gpus N: start the N ranks here (spawn context, one process per GPU, no RCCL anywhere) and WATCH them:
+    the first rank that exits with a non-zero code -- an out-of-memory kill while page-locking its rings, a missing device 7,
+    a HIP error, an assert -- aborts the fence (the others leave their wait with RankLost instead of sitting in it until the
+    driver's timeout), the rest get `grace_s` seconds to go and are then terminated, and the job's exit code is that rank's.
+    Returns 0 or the first failing exit code (negative = killed by that signal); prints what happened to stderr."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    barrier, slots = ctx.Barrier(world), ctx.Array("d", world)
+    target = target or _fork_rank
+    procs = [ctx.Process(target=target, args=(r, world, devices[r], barrier, slots, list(argv))) for r in range(world)]
+    for p in procs:
+        p.start()
+    failed = None
+    while any(p.exitcode is None for p in procs):
+        for r, p in enumerate(procs):
+            p.join(poll_s / world)
+            if p.exitcode not in (None, 0) and failed is None:
+                failed = (r, p.exitcode)
+        if failed is not None:
+            break
+    if failed is None:
+        bad = [(r, p.exitcode) for r, p in enumerate(procs) if p.exitcode != 0]
+        if not bad:
+            return 0
+        failed = bad[0]
+    barrier.abort()                     # every rank waiting at (or arriving at) a fence raises RankLost now
+    deadline = time.monotonic() + grace_s
+    for p in procs:
+        p.join(max(0.0, deadline - time.monotonic()))
+    for p in procs:
+        if p.exitcode is None:
+            p.terminate()
+    for p in procs:
+        p.join(2.0)
+        if p.exitcode is None:
+            p.kill()
+    r, code = failed
+    what = "was killed by signal %d" % -code if code < 0 else "exited with code %d" % code
+    print("bench.py: rank %d (device %s) %s; the fence was aborted and the other %d rank(s) stopped -- no result line"
+          % (r, devices[r], what, world - 1), file=sys.stderr, flush=True)
+    return code
+
+
+def pinned_budget_check(world, ranks_here, h, w, scale, depth=3):
+    """Page-locked host memory the job's ranks on THIS node are about to take (the host route's rings: `depth` frames in and
+    `depth` results out per rank) against what the node can lock: MemAvailable and, in a container, the cgroup's memory.max.
+    Eight ranks at 3840x2160 -> 2x want 8 x 3 x (24.9 + 99.5) MB = 3.0 GB; a rank that dies in hipHostMalloc half way through
+    takes the job down (launch_ranks sees it), this says so before anything is allocated.  Returns (needed, available) bytes."""
+    per_rank = depth * (h * w * 3 + (h * scale) * (w * scale) * 3)
+    needed = per_rank * ranks_here
+    avail = None
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    try:
+        lim = open("/sys/fs/cgroup/memory.max").read().strip()
+        if lim != "max":
+            used = int(open("/sys/fs/cgroup/memory.current").read())
+            avail = min(avail, int(lim) - used) if avail is not None else int(lim) - used
+    except (OSError, ValueError):
+        pass
+    if avail is not None and needed > 0.8 * avail:
+        raise SystemExit("bench.py: the %d rank(s) of this node need %.2f GB of page-locked host memory (%d frames in flight per rank) "
+                         "and the node can give %.2f GB: fewer ranks, a smaller frame, or more memory"
+                         % (ranks_here, needed / 1e9, depth, avail / 1e9))
+    return needed, avail
 
 
 def parse_args(argv=None):
@@ -362,22 +444,9 @@ def main():
     if args.gpus == 1:
         run(args, SoloComm(), devices[0])
         return
-    # python bench.py --gpus N: start the N ranks here, one process per GPU, no RCCL anywhere
-    import multiprocessing as mp
-    ctx = mp.get_context("spawn")
-    barrier, slots = ctx.Barrier(args.gpus), ctx.Array("d", args.gpus)
-    procs = [ctx.Process(target=_fork_rank, args=(r, args.gpus, devices[r], barrier, slots, list(sys.argv))) for r in range(args.gpus)]
-    for p in procs:
-        p.start()
-    rc = 0
-    for p in procs:
-        p.join()
-        rc = rc or p.exitcode
+    rc = launch_ranks(args.gpus, devices, list(sys.argv))
     if rc:
-        for p in procs:
-            if p.is_alive():
-                p.terminate()
-        sys.exit("bench.py: a rank failed (exit code %s)" % rc)
+        sys.exit(rc if 0 < rc < 256 else 1)
 
 
 def run(args, comm, device):
@@ -463,6 +532,7 @@ def run(args, comm, device):
     # (E) pipelined host route, PCIe inclusive, on every rank at once: frames in page-locked host memory,
     # submit/collect with 3 frames in flight (SURVEY.md 8d "host-to-host with stream overlap")
     depth, n_host = 3, (max(6, min(args.steps, 12)) if generic else max(30, min(args.steps, 120)))
+    pinned_need, pinned_avail = pinned_budget_check(world, world, h, w, s, depth)      # one node: every rank is here
     host_in = frames[0].cpu().numpy()
     pin_in = [ncnn.pinned_empty((h, w, 3)) for _ in range(depth)]
     pin_out = [ncnn.pinned_empty((h * s, w * s, 3)) for _ in range(depth)]
@@ -510,6 +580,7 @@ def run(args, comm, device):
                 "frame_tflop": round(frame_flops / 1e12, 4), "whole_path_tflops": round(frame_flops * fps / world / 1e12, 1),
                 "kernel_ms_per_frame": {"rdb4_kernel": round(trunk_ms / steps_timed, 3), "conv5 (g_conv3_sw<6,1>)": round(tail_ms / steps_timed, 3)},
                 "numa_cpus_rank0": (len(numa_cpus) if numa_cpus else None),
+                "pinned_host_bytes_all_ranks": pinned_need, "host_memory_available_bytes": pinned_avail,
                 "library": library_record(),
             },
             "roofline": {"kernel": "rdb4_kernel (conv1..conv4 + the 1x1 of a residual dense block, every plane of the frame, one launch)",
@@ -563,6 +634,7 @@ def run(args, comm, device):
                 "kernel_ms_per_frame": {"head": round(head_ms / steps_timed, 4), "trunk": round(trunk_ms / steps_timed, 4),
                                         "tail": round(tail_ms / steps_timed, 4)},
                 "numa_cpus_rank0": (len(numa_cpus) if numa_cpus else None),
+                "pinned_host_bytes_all_ranks": pinned_need, "host_memory_available_bytes": pinned_avail,
                 "library": library_record(),
             },
             "roofline": {

@@ -261,6 +261,16 @@ def main():
     print(f"chain 1x -> 2x 64x48 tiled 32/10: u8 mismatches={int((u_ch != u_cc).sum())}/{u_cc.size}")
     assert np.abs(u_ch.astype(int) - u_cc.astype(int)).max() <= 1
     gold["chain_1x_2x_48x64_t32_in"], gold["chain_1x_2x_48x64_t32_u8"] = img, u_ch
+    # round 5: a tiled frame on which BOTH layers of every fused trunk pair see tile seams, strip seams and
+    # narrow last strips -- 190 columns x 200 rows, tile 64, border 10: planes 74 / 84 / 72 columns wide (two 30-column strips +
+    # a last strip of 14 / 24 / 12 columns) and 74 / 84 / 84 / 18 rows high.  fp32 throughout, like every fixture of this file:
+    # the bar for the fp16 Winograd product path against it is the fp32 one (<= 2 LSB, >= 50 dB).
+    img = uvoracle.synthetic_frame(200, 190, seed=12)
+    u_t = tiled(lambda t: run_model("2x", t)[1], 2, img, 64, 10)
+    u_c = uvoracle.load_model("2x").upscale_image(img, tile_size=64, border=10)
+    print(f"2x 190x200 tiled 64/10: u8 mismatches={int((u_t != u_c).sum())}/{u_c.size}")
+    assert np.abs(u_t.astype(int) - u_c.astype(int)).max() <= 1
+    gold["wino_seams_2x_200x190_t64_in"], gold["wino_seams_2x_200x190_t64_u8"] = img, u_t
     vgold = valar_fixture()
     if args.write_golden:
         out = os.path.join(os.path.dirname(_HERE), "tests", "golden", "independent_torch.npz")

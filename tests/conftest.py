@@ -13,6 +13,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionfinish(session, exitstatus):
+    """the measured distances of every oracle comparison of this session -> gpurun_out/parity_report.json"""
+    import parity_report
+    parity_report.write()
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """... and one line each in the log, whatever the verbosity (the driver runs `-q`)"""
+    import parity_report
+    lines = list(parity_report.summary_lines())
+    if lines:
+        terminalreporter.write_sep("-", "measured parity (tests/parity_report.py; %d comparisons)" % len(lines))
+        for ln in lines:
+            terminalreporter.write_line(ln)
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _torch_cuda_first(request):
     """Tests that hand torch CUDA tensors to the library need torch's own HIP runtime initialised BEFORE libuva.so brings up

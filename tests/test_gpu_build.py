@@ -1,0 +1,75 @@
+"""-m gpu: the headline kernel COMPILES on the GPU box, and what was compiled there computes what the shipped library computes.
+
+VERDICT r4 item 8: every driver record so far measured a library that came with the snapshot (`compiled_by_this_run: false`);
+build() on the box was exercised by nothing.  Here csrc/uva_wino.hip -- trunkw_kernel, 93 % of a frame's GPU time, its own
+translation unit -- is compiled with the box's hipcc, linked with the snapshot's other objects (csrc/_obj/ travels for this), and
+the result is run in a fresh process against the committed golden fixtures and against the shipped library, byte for byte.
+The record (compiler, seconds, both hashes) goes to gpurun_out/build_on_gpu_box.json."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+CHILD = r"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from upscale_video_amd import _lib, ncnn
+assert os.path.samefile(_lib.LIB_PATH, os.environ["UVA_LIB_PATH"])
+g = np.load(os.path.join(%(root)r, "tests", "golden", "independent_torch.npz"))
+net = ncnn.Net(); net.set_vulkan_device(0)
+base = os.path.join(%(root)r, "models", "2x_Compact_Pretrain")
+assert net.load_param(base + ".param") == 0 and net.load_model(base + ".bin") == 0
+out = {}
+for tag, ts in (("wino_seams_2x_200x190_t64", 64), ("tiled_2x_70x75_t32", 32), ("config1_2x_256x256", 960)):
+    got = net.process_u8(g[tag + "_in"], tile_size=ts, border=10)
+    d = np.abs(got.astype(int) - g[tag + "_u8"].astype(int))
+    mse = float((d.astype(float) ** 2).mean())
+    out[tag] = {"max_lsb": int(d.max()), "psnr_db": 99.0 if mse == 0 else float(10 * np.log10(255.0 ** 2 / mse)),
+                "sha256": __import__("hashlib").sha256(got.tobytes()).hexdigest()}
+print("RESULT " + json.dumps(out))
+"""
+
+
+def _run(lib):
+    env = dict(os.environ, UVA_LIB_PATH=lib)
+    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
+
+
+def _sha(path):
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def test_trunk_kernel_compiled_on_this_box_is_parity_green_and_byte_identical(tmp_path):
+    from upscale_video_amd import build
+    shipped = build.build_lib()
+    rebuilt = str(tmp_path / "libuva_rebuilt_here.so")
+    t0 = time.monotonic()
+    build.rebuild_trunkw(rebuilt)
+    seconds = time.monotonic() - t0
+    assert os.path.getsize(rebuilt) > 100_000
+    res_new, res_old = _run(rebuilt), _run(shipped)
+    for tag, r in res_new.items():
+        assert r["max_lsb"] <= 2 and r["psnr_db"] >= 50, (tag, r)                 # the fp32 golden bar
+        assert r["sha256"] == res_old[tag]["sha256"], (tag, "the kernel compiled here computes other bytes than the shipped one")
+    ver = subprocess.run([build.hipcc(), "--version"], capture_output=True, text=True).stdout.strip().splitlines()
+    rec = {"what": "csrc/uva_wino.hip (trunkw_kernel) compiled on the GPU box, linked with the snapshot's other objects",
+           "hipcc": ver[0] if ver else None, "compile_and_link_s": round(seconds, 1),
+           "rebuilt_sha256_16": _sha(rebuilt), "shipped_sha256_16": _sha(shipped),
+           "golden_fixtures": res_new, "bytes_equal_to_the_shipped_library": True}
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "build_on_gpu_box.json"), "w") as f:
+            json.dump(rec, f, indent=1)
+    print(json.dumps(rec))

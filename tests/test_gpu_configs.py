@@ -241,6 +241,70 @@ def test_bench_starts_its_own_ranks():
 
 
 @pytest.mark.gpu
+def test_config5_line_eight_ranks_on_the_one_gpu():
+    """BASELINE config 5's bench line -- `python bench.py --gpus 8 --workload 2x_compact_2160p` -- with all
+    eight ranks on the box's one GPU (`--devices 0,0,0,0,0,0,0,0`): eight spawned processes, eight sets of page-locked rings
+    (3 x (24.9 + 99.5) MB each), the multiprocessing fence around both timed regions, NUMA pinning eight times over, ONE JSON
+    line with n_gpus 8.  What an 8-GPU node adds to this is seven more devices, not another code path."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--devices", "0,0,0,0,0,0,0,0",
+                        "--workload", "2x_compact_2160p", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-parity"],
+                       capture_output=True, text=True, timeout=1200, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 4 and d["scaling"] == "weak"
+    assert "3840x2160" in d["config"]["workload"] and d["config"]["frames_per_rank"] == 4
+    assert d["config"]["pinned_host_bytes_all_ranks"] == 8 * 3 * (2160 * 3840 * 3 + 4320 * 7680 * 3)
+    assert d["value"] > 20 and d["config"]["host_route_fps_pcie_inclusive"] > 10         # one GPU's worth, shared by eight ranks
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "bench_config5_eight_ranks_one_gpu.json"), "w") as f:
+            f.write(lines[0] + "\n")
+
+
+@pytest.mark.gpu
+def test_a_rank_on_a_missing_device_ends_the_job_fast():
+    """the failure the first real 8-GPU run is most likely to meet: a rank whose device does not exist (here device 63 of a
+    one-GPU box).  The job must end with a non-zero code and a message within seconds of that rank dying -- not sit in the
+    fence until the driver's timeout."""
+    import subprocess
+    import sys
+    import time
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--devices", "0,63", "--steps", "10", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-parity"], capture_output=True, text=True, timeout=600, env=env)
+    dt = time.monotonic() - t0
+    assert r.returncode != 0, r.stdout[-2000:]
+    assert "rank 1" in r.stderr and "fence was aborted" in r.stderr, r.stderr[-3000:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert dt < 240, dt                        # two interpreter start-ups with torch + the healthy rank's set-up, no fence timeout (900 s)
+
+
+def test_harness_config5_eight_workers(caplog, tmp_path, monkeypatch):
+    """BASELINE config 5 as named -- `test_gpus.py -g 0,1,..,7` on a 3840x2160 sample -- with the eight workers on the one GPU:
+    eight pool processes, eight nets, one "Testing GPU" / "seconds to upscale" pair per run"""
+    import test_gpus
+    monkeypatch.chdir(tmp_path)
+    with caplog.at_level(logging.INFO):
+        test_gpus.run_tests("0,0,0,0,0,0,0,0", 2, 8, size="3840x2160")
+    text = "\n".join(r.getMessage() for r in caplog.records)
+    assert text.count("Testing GPU: 0") == 8 and text.count("seconds to upscale sample.png") == 8
+    assert "sample.png: a synthetic 3840x2160 frame" in text and "frames/s" in text
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "test_gpus_config5_eight_workers.txt"), "w") as f:
+            f.write(text + "\n")
+
+
+@pytest.mark.gpu
 def test_bench_valar_workload(tmp_path):
     """BASELINE config 4 as named under bench.py's contract: `--workload 4x_valar_1080p` (random-init weights: the .bin is
     a missing blob upstream) prints one JSON line with the whole-graph roofline object and both routes."""

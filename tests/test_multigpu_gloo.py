@@ -122,6 +122,87 @@ def test_self_launched_ranks_fence_without_rccl():
     assert sorted(f for r in res for f in r[3]) == list(range(7))
 
 
+def _dying_rank(rank, world, device, barrier, slots, argv):
+    """a rank of launch_ranks() that gets through one timed region and then loses rank 1 in the middle of the second --
+    what an out-of-memory kill, a missing device or a HIP error does to `python bench.py --gpus N`"""
+    sys.path.insert(0, ROOT)
+    import time
+    import bench
+    comm = bench.ForkComm(rank, world, barrier, slots)
+    bench.timed_region(lambda: time.sleep(0.05), lambda: None, comm.barrier, comm.max_over_ranks)
+    how = argv[1]
+
+    def region():
+        if rank == 1:
+            time.sleep(0.2)
+            if how == "kill":
+                os.kill(os.getpid(), 9)
+            if how == "exit":
+                os._exit(7)
+            raise RuntimeError("rank 1 fails")
+        time.sleep(0.05)
+    bench.timed_region(region, lambda: None, comm.barrier, comm.max_over_ranks)       # ranks 0 and 2 wait at the fence: RankLost
+    raise AssertionError("rank %d got through a fence that rank 1 never reached" % rank)
+
+
+@pytest.mark.parametrize("how", ["kill", "exit", "raise"])
+def test_a_dead_rank_ends_the_job_within_seconds(how, capfd):
+    """a rank that dies before a fence must not leave the others in wait() for ever (the driver's 8-GPU
+    command would burn its whole timeout and report nothing): the parent sees the exit code, aborts the barrier, stops the
+    rest and returns non-zero -- here in well under 30 s, with the fences' own timeout (900 s) never reached."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    t0 = time.monotonic()
+    rc = bench.launch_ranks(3, [0, 1, 2], ["bench.py", how], target=_dying_rank)
+    dt = time.monotonic() - t0
+    assert rc != 0 and dt < 30, (rc, dt)
+    assert rc == {"kill": -9, "exit": 7, "raise": 1}[how]
+    err = capfd.readouterr().err
+    assert "rank 1" in err and "fence was aborted" in err
+    assert "got through a fence" not in err            # nobody passed the broken fence
+    assert "RankLost" in err                           # the survivors left their wait with the named error
+
+
+def _ok_rank(rank, world, device, barrier, slots, argv):
+    sys.path.insert(0, ROOT)
+    import time
+    import bench
+    comm = bench.ForkComm(rank, world, barrier, slots)
+    for _ in range(3):
+        bench.timed_region(lambda: time.sleep(0.01 * (rank + 1)), lambda: None, comm.barrier, comm.max_over_ranks)
+
+
+def test_eight_healthy_ranks_return_zero():
+    """the documented N = 8 shape (python bench.py --gpus 8) through the same launcher: eight ranks, three fenced regions, rc 0"""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.launch_ranks(8, list(range(8)), ["bench.py"], target=_ok_rank) == 0
+
+
+def test_a_fence_times_out_on_its_own():
+    """the backstop under the parent's watch: a Barrier wait with a timeout breaks the barrier for everybody"""
+    import multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    import bench
+    ctx = mp.get_context("spawn")
+    comm = bench.ForkComm(0, 2, ctx.Barrier(2), ctx.Array("d", 2), timeout=0.3)
+    with pytest.raises(bench.RankLost):
+        comm.barrier()                                  # rank 1 never comes
+    with pytest.raises(bench.RankLost):
+        comm.max_over_ranks(1.0)                        # and the fence stays broken
+
+
+def test_pinned_budget_check_says_no_before_anything_is_allocated(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    need, avail = bench.pinned_budget_check(8, 8, 2160, 3840, 2)            # config 5: eight ranks, 3 frames in flight each
+    assert need == 8 * 3 * (2160 * 3840 * 3 + 4320 * 7680 * 3)
+    assert avail is None or avail > 0
+    with pytest.raises(SystemExit, match="page-locked"):
+        bench.pinned_budget_check(8, 8, 216000, 384000, 4)                  # 29 TB: no node has it
+
+
 def test_bench_refuses_a_device_list_of_the_wrong_length():
     import subprocess
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--devices", "0"], capture_output=True, text=True,

@@ -121,6 +121,14 @@ def test_golden_independent_torch(oracle_models, oracle):
     c = oracle_models["2x"].upscale_image(oracle_models["1x"].apply_model(g["chain_1x_2x_48x64_t32_in"]), tile_size=32, border=10)
     assert np.abs(c.astype(int) - g["chain_1x_2x_48x64_t32_u8"].astype(int)).max() <= 1 and (c != g["chain_1x_2x_48x64_t32_u8"]).mean() <= 1e-3
     # BASELINE config 1 (256x256, 2x Compact): u8 result of the independent evaluation
+    ws = oracle_models["2x"].upscale_image(g["wino_seams_2x_200x190_t64_in"], tile_size=64, border=10)   # round 5: strip + tile seams
+    assert np.abs(ws.astype(int) - g["wino_seams_2x_200x190_t64_u8"].astype(int)).max() <= 1 and (ws != g["wino_seams_2x_200x190_t64_u8"]).mean() <= 1e-3
+    # ... and the oracle's own Winograd / fp16 modes (the rounding points of the product's trunk kernel) stay inside the fp32 bar
+    from oracle import uvoracle
+    wp = oracle_models["2x"].upscale_image(g["wino_seams_2x_200x190_t64_in"], tile_size=64, border=10,
+                                           flags=uvoracle.F16_STORAGE | uvoracle.WINOGRAD_F23 | uvoracle.PRELU_F16)
+    dp = np.abs(wp.astype(int) - g["wino_seams_2x_200x190_t64_u8"].astype(int))
+    assert dp.max() <= 2 and 10 * np.log10(255.0 ** 2 / (dp.astype(float) ** 2).mean()) >= 50
     c1 = oracle_models["2x"].upscale_image(g["config1_2x_256x256_in"])
     assert np.abs(c1.astype(int) - g["config1_2x_256x256_u8"].astype(int)).max() <= 1
     assert (c1 != g["config1_2x_256x256_u8"]).mean() <= 1e-3

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""gpurun_out/parity_report.json (written by `pytest tests -m gpu`, tests/parity_report.py) -> tests/golden/parity_slack.json:
+the bars of the PRODUCT-MODE comparisons (GPU against the oracle run with the kernel's own rounding points), per model and
+route, as MEASURED MAXIMUM + MARGIN instead of a round number:
+
+    u8_differ_share  share of u8 samples that differ (by one level)          margin: one point (0.01)
+    layer_rel        per-layer activations, max |err| / the layer's range    margin: 5e-4
+    f32_abs          pre-quantisation f32 output, max |err|                  margin: 5e-4
+
+    python tools/parity_slack.py [report.json ...]      several reports (boxes, sweeps): the maximum over all of them
+
+The fp32 bars (<= 2 LSB, >= 50 dB; whole 1080p frames >= 60 dB) are independent of the kernel and stay as they are."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MARGIN = {"u8_differ_share": 0.01, "layer_rel": 5e-4, "f32_abs": 5e-4}
+
+
+def main(paths):
+    paths = paths or [os.path.join(ROOT, "gpurun_out", "parity_report.json")]
+    worst, count, fp32 = {}, {}, {}
+    for p in paths:
+        for r in json.load(open(p))["records"]:
+            if not r.get("model") or not r.get("route"):
+                continue
+            if "product rounding mode" in r["vs"]:
+                if r["kind"] == "u8":
+                    key, val = f"{r['model']}/{r['route']}/u8_differ_share", r["differ_share"]
+                elif r.get("what") == "layer_rel":
+                    key, val = f"{r['model']}/{r['route']}/layer_rel", r["rel_to_range"]
+                else:
+                    key, val = f"{r['model']}/{r['route']}/f32_abs", r["max_abs_err"]
+                worst[key] = max(worst.get(key, 0.0), val)
+                count[key] = count.get(key, 0) + 1
+            elif r["kind"] == "u8" and r["vs"].startswith("fp32 oracle"):
+                k = f"{r['model']}/{r['route']}"
+                e = fp32.setdefault(k, {"comparisons": 0, "max_lsb": 0, "min_psnr_db": 99.0, "max_differ_share": 0.0})
+                e["comparisons"] += 1
+                e["max_lsb"] = max(e["max_lsb"], r["max_lsb"])
+                e["min_psnr_db"] = round(min(e["min_psnr_db"], r["psnr_db"]), 2)
+                e["max_differ_share"] = round(max(e["max_differ_share"], r["differ_share"]), 5)
+    bars = {}
+    for key in sorted(worst):
+        what = key.rsplit("/", 1)[1]
+        bars[key] = {"measured_max": round(worst[key], 6), "margin": MARGIN[what], "bar": round(worst[key] + MARGIN[what], 6),
+                     "comparisons": count[key]}
+    out = {"about": "product-mode parity bars = measured maximum + margin (tools/parity_slack.py); the fp32 section is the measured "
+                    "headroom under the kernel-independent bars (<= 2 LSB, >= 50 dB), for the record",
+           "sources": [os.path.relpath(os.path.abspath(p), ROOT) for p in paths], "bars": bars, "fp32_measured": fp32}
+    dst = os.path.join(ROOT, "tests", "golden", "parity_slack.json")
+    with open(dst, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote", dst)
+    for k, v in bars.items():
+        print("  %-34s measured %.5f + %.4f -> bar %.5f (%d comparisons)" % (k, v["measured_max"], v["margin"], v["bar"], v["comparisons"]))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -47,6 +47,7 @@ v = B[3:niter - 3]
 print("  group B (consumer, layer i+1)")
 show("phase X: epilogue (HBM stores)", v[:, 1] - v[:, 0])
 show("wait at barrier 1", v[:, 2] - v[:, 1])
-show("phase Y: k-loop", v[:, 4] - v[:, 2])
-show("phase Y: raw rows -> A-ring", v[:, 3] - v[:, 4])
+# (stamp 4 sits between the raw-row transform and the k-loop: rounds 4's labels had the two swapped)
+show("phase Y: raw rows -> A-ring (in front of the k-loop)", v[:, 4] - v[:, 2])
+show("phase Y: k-loop (TW_RAW_INK: raw rows inside)", v[:, 3] - v[:, 4])
 show("wait at barrier 2", B[4:niter - 2, 0] - v[:, 3])

@@ -108,6 +108,29 @@ def build_variant(name, defines, verbose=False):
     return _build(os.path.join(_HERE, "libuva_%s.so" % name), os.path.join(CSRC, "_obj_" + name), list(defines), False, verbose)
 
 
+def rebuild_trunkw(out, defines=(), verbose=False):
+    """Compile csrc/uva_wino.hip (trunkw_kernel: the headline kernel, its own translation unit, seconds) HERE and link it with
+    the other objects of libuva.so as they lie under csrc/_obj/ -> `out`.  What `pytest -m gpu` uses to show that the kernel the
+    box measures also COMPILES on the box (tests/test_gpu_workers.py); objects that are missing are compiled too (minutes)."""
+    import tempfile
+    objdir = os.path.join(CSRC, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    with tempfile.TemporaryDirectory(prefix="uva_rebuild_") as tmp:
+        objs = []
+        for src in SOURCES:
+            obj = _obj(objdir, src)
+            if src == "uva_wino.hip" or _stale(obj, src):
+                dst = os.path.join(tmp, os.path.basename(obj)) if src == "uva_wino.hip" else obj
+                cmd = [hipcc()] + FLAGS + list(defines) + ["-c", os.path.join(CSRC, src), "-o", dst]
+                if verbose:
+                    print(" ".join(cmd))
+                subprocess.check_call(cmd)
+                obj = dst
+            objs.append(obj)
+        subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out])
+    return out
+
+
 def build_lib(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU).  Returns the .so path."""
     if os.environ.get("UVA_LIB_PATH"):      # an A/B build selected by the caller: leave it alone

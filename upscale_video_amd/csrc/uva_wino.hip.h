@@ -136,7 +136,28 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
 #ifndef TW_INROWS
 #define TW_INROWS 0           // rows of a block whose epilogue slices run inside the k-loop (A/B builds: 0..3)
 #endif
-    constexpr int PFF = TW_PFF;                   // fragments read ahead of their MFMAs: an LDS read takes ~280 cycles to come back
+#ifndef TW_INROWS_A
+#define TW_INROWS_A TW_INROWS // ... per group: the producers' / the consumers' rows
+#endif
+#ifndef TW_INROWS_B
+#define TW_INROWS_B TW_INROWS
+#endif
+#ifndef TW_RAW_INK
+#define TW_RAW_INK 0          // 1: the consumers transform the next step's raw rows INSIDE their k-loop (reads at fragment TW_RAW_F0, the
+#endif                        // four V rows of a channel half TW_RAW_GAP fragments later, one every TW_RAW_STRIDE fragments): their serial
+#ifndef TW_RAW_F0             // chain epilogue -> raw rows -> k-loop is what a period is made of (tools/trunkw_anatomy.py)
+#define TW_RAW_F0 0
+#endif
+#ifndef TW_RAW_GAP
+#define TW_RAW_GAP 10
+#endif
+#ifndef TW_RAW_STRIDE
+#define TW_RAW_STRIDE 2
+#endif
+#ifndef TW_PFF_B
+#define TW_PFF_B TW_PFF       // ... of the consumers' k-loop (the in-stream raw-row transform wants the registers)
+#endif
+    constexpr int PFF_A = TW_PFF;                 // fragments read ahead of their MFMAs: an LDS read takes ~280 cycles to come back
                                                   // while four waves stream fragments, and an MFMA 16 (profiles/r04_ab_results.txt)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -308,10 +329,12 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
     // last MFMA: its slices are the caller's, in the next phase.  The order is pinned fragment by fragment
     // (sched_barrier): the read PFF fragments ahead, this fragment's MFMAs, one slice.
     f32x4 acc[4][4];
-    auto kloop = [&](auto ring_tag, int base_pos, auto&& slice) __attribute__((always_inline)) {
+    auto kloop = [&](auto ring_tag, int base_pos, auto&& slice, auto&& hook) __attribute__((always_inline)) {
         constexpr bool BR = decltype(ring_tag)::value;
+        constexpr int INR = BR ? TW_INROWS_B : TW_INROWS_A;
         constexpr int ROWB = BR ? TW_BROWB : TW_AROWB, NROWS = BR ? TW_BROWS : TW_AROWS;
         constexpr int JS = ROWB / 4, CS = ROWB / 8;
+        constexpr int PFF = BR ? TW_PFF_B : PFF_A;
         constexpr int NFRAG = 48, RQ = PFF + 1;
         unsigned radr[6];
         const unsigned vlane = vlane_c;
@@ -337,13 +360,18 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
             const half8 b = bq[f % RQ];
             static_for<4>([&](auto nc) __attribute__((always_inline)) {
                 constexpr int n = decltype(nc)::value, dy = R - n;
+#ifdef TW_EXP_2D        // CEILING EXPERIMENT, WRONG RESULTS: the MFMA count of a 2-D Winograd F(2x2,3x3) k-loop (64 of the 96)
+                if constexpr (dy >= 0 && dy <= 2 && dy != 1) {
+#else
                 if constexpr (dy >= 0 && dy <= 2) {
+#endif
                     constexpr bool first = dy == 0 && ch == 0;
                     // M1 enters both results with a plus sign: its accumulator starts at the bias
                     acc[n][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[(j * 3 + dy) * 2 + ch], b, first ? (j == 1 ? bias4 : zero4) : acc[n][j], 0, 0, 0);
                 }
             });
-            if constexpr (R >= 3 && R - 3 < TW_INROWS) slice(std::integral_constant<int, R - 3>{}, std::integral_constant<int, (f & 7)>{});
+            if constexpr (R >= 3 && R - 3 < INR) slice(std::integral_constant<int, R - 3>{}, std::integral_constant<int, (f & 7)>{});
+            hook(fc);
             __builtin_amdgcn_sched_barrier(0);
         });
     };
@@ -438,6 +466,10 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
                     st.q[2] = pk_add_f16(st.y0, st.t[0]); st.q[3] = pk_add_f16(st.y1, st.t[1]);      // V1 = d1 + d2
                     st.q[4] = pk_sub_f16(st.t[0], st.y0); st.q[5] = pk_sub_f16(st.t[1], st.y1);      // V2 = d2 - d1
                     st.q[6] = pk_sub_f16(st.y0, st.t[2]); st.q[7] = pk_sub_f16(st.y1, st.t[3]);      // V3 = d1 - d3
+#if defined(TW_EXP_2D) && TW_EXP_2D >= 2   // ... + the VALU a y-transform of these values would add: 16 packed adds per row (WRONG results)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) st.q[e & 7] = pk_add_f16(st.q[e & 7], st.q[(e + 3) & 7]);
+#endif
                 } else if constexpr (k == 6) {
 #ifndef TW_W128
                     // no lane exchange: every lane stores its own four channels of V0..V3 as 8-byte pieces (2-way bank conflicts --
@@ -482,11 +514,12 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
             if (it < nsteps) {
                 __builtin_amdgcn_s_setprio(TW_PRIO_KA);
                 // steps that touch their plane's edge (uniform, few) mask what lies outside
-#if TW_INROWS > 0
-                if (edge) kloop(std::false_type{}, a6, [&](auto nc, auto kc) __attribute__((always_inline)) { slice(st2[0], std::true_type{}, nc, kc); });
+                auto no_hook = [](auto) __attribute__((always_inline)) {};
+#if TW_INROWS_A > 0
+                if (edge) kloop(std::false_type{}, a6, [&](auto nc, auto kc) __attribute__((always_inline)) { slice(st2[0], std::true_type{}, nc, kc); }, no_hook);
                 else
 #endif
-                kloop(std::false_type{}, a6, [&](auto nc, auto kc) __attribute__((always_inline)) { slice(st2[0], std::false_type{}, nc, kc); });
+                kloop(std::false_type{}, a6, [&](auto nc, auto kc) __attribute__((always_inline)) { slice(st2[0], std::false_type{}, nc, kc); }, no_hook);
                 __builtin_amdgcn_s_setprio(TW_PRIO_EA);
             }
             e_dma = load_a(it + 3 <= nsteps + TW_PAD_STEPS - 1 ? it + 3 : nsteps + TW_PAD_STEPS - 1);
@@ -500,11 +533,11 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
             if (it < nsteps) {                     // the last row: beside the consumers' k-loop
                 // two rows at a time, slice by slice: neighbouring instructions are independent of each other
                 auto rest = [&](auto edge_tag) __attribute__((always_inline)) {
-                    static_assert(TW_INROWS == 0 || TW_INROWS == 2, "rows are finished in pairs");
-                    static_for<(4 - TW_INROWS) / 2>([&](auto rc) __attribute__((always_inline)) {
+                    static_assert(TW_INROWS_A == 0 || TW_INROWS_A == 2, "rows are finished in pairs");
+                    static_for<(4 - TW_INROWS_A) / 2>([&](auto rc) __attribute__((always_inline)) {
                         static_for<8>([&](auto kc) __attribute__((always_inline)) {
-                            slice(st2[0], edge_tag, std::integral_constant<int, TW_INROWS + 2 * decltype(rc)::value>{}, kc);
-                            slice(st2[1], edge_tag, std::integral_constant<int, TW_INROWS + 2 * decltype(rc)::value + 1>{}, kc);
+                            slice(st2[0], edge_tag, std::integral_constant<int, TW_INROWS_A + 2 * decltype(rc)::value>{}, kc);
+                            slice(st2[1], edge_tag, std::integral_constant<int, TW_INROWS_A + 2 * decltype(rc)::value + 1>{}, kc);
 #ifdef TW_EPI_FENCE
                             __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -555,6 +588,10 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
                     const auto x = __builtin_amdgcn_permlane16_swap(st.x0, st.y0, false, false);
                     const auto y = __builtin_amdgcn_permlane16_swap(st.x1, st.y1, false, false);
                     st.q[0] = x[0]; st.q[1] = y[0]; st.q[2] = x[1]; st.q[3] = y[1];
+#if defined(TW_EXP_2D) && TW_EXP_2D >= 2   // ... + the second output transform's adds (WRONG results)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) st.q[e & 3] = pk_add_f16(st.q[e & 3], st.q[(e + 1) & 3]);
+#endif
                 } else if constexpr (k == 5) {
                     char* dst = (n >= v0 && n < vy && colok) ? obase + (size_t)n * pitch : sink;
                     *(uint4*)dst = make_uint4(st.q[0], st.q[1], st.q[2], st.q[3]);
@@ -565,10 +602,11 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
             TW_STAMP(0);
             if (it >= 2 && ((__builtin_amdgcn_readfirstlane(e_3.y) >> 24) & 1u)) {      // row 3 of step it - 2
                 auto sl3 = make_slice(e_3);
-                static_for<(4 - TW_INROWS) / 2>([&](auto rc) __attribute__((always_inline)) {
+                static_assert(TW_INROWS_B == 0 || TW_INROWS_B == 2, "rows are finished in pairs");
+                static_for<(4 - TW_INROWS_B) / 2>([&](auto rc) __attribute__((always_inline)) {
                     static_for<6>([&](auto kc) __attribute__((always_inline)) {
-                        sl3(st2[0], std::integral_constant<int, TW_INROWS + 2 * decltype(rc)::value>{}, kc);
-                        sl3(st2[1], std::integral_constant<int, TW_INROWS + 2 * decltype(rc)::value + 1>{}, kc);
+                        sl3(st2[0], std::integral_constant<int, TW_INROWS_B + 2 * decltype(rc)::value>{}, kc);
+                        sl3(st2[1], std::integral_constant<int, TW_INROWS_B + 2 * decltype(rc)::value + 1>{}, kc);
 #ifdef TW_EPI_FENCE
                         __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -583,7 +621,7 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
             // The raw rows of step it + 1 (landed: the producers waited for them in front of barrier 1) -> A-ring.  FIRST: the
             // producers' epilogue runs beside it at full speed (beside a k-loop it gets one instruction through per MFMA), and
             // nothing is left behind the k-loop, when the LDS store path would be all that moves.
-            auto raw_rows = [&]() __attribute__((always_inline)) {
+            [[maybe_unused]] auto raw_rows = [&]() __attribute__((always_inline)) {
                 if (it + 1 < nsteps) {
                     int pos0 = a6 + 4 + 2;         // step it + 1's new rows follow its two shared ones
                     pos0 = pos0 >= TW_AROWS ? pos0 - TW_AROWS : pos0;
@@ -594,8 +632,20 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
 #endif
                 }
             };
-#ifndef TW_TRANSFORM_LAST
+#if !defined(TW_TRANSFORM_LAST) && !TW_RAW_INK
             raw_rows();
+#endif
+#if TW_RAW_INK
+            unsigned solo = (unsigned)__builtin_amdgcn_readfirstlane((int)((kact ^ 1u) & (it + 1 < nsteps ? 1u : 0u)));
+            asm volatile("" : "+s"(solo));         // (opaque: seen as the k-loop's `else`, hipcc lays the two out as one region and spills 115 registers)
+            if (solo) {                            // (no k-loop to hide it in: the first iteration, a segment's fill step) -- half a
+                int pos = a6 + 4 + 2 + wave;       // row at a time: the 32 registers of transform_row() do not fit beside the hook's
+                pos = pos >= 2 * TW_AROWS ? pos - 2 * TW_AROWS : pos >= TW_AROWS ? pos - TW_AROWS : pos;
+                const char* const rr = smem + TW_RAW + ((it + 1) & 1) * TW_RAWSLOTB + wave * TW_RAWROWB;
+                transform_half(rr, pos, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                transform_half(rr, pos, 1);
+            }
 #endif
             TW_STAMP(4);
             if (kact) {
@@ -603,7 +653,34 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
                 int bp = b10 - 4 - 2;              // block it - 1 begins at (4 (it - 1)) mod 10; the window starts two rows above
                 bp = bp < 0 ? bp + TW_BROWS : bp;
                 auto slk = make_slice(e_k);
-                kloop(std::true_type{}, bp, [&](auto nc, auto kc) __attribute__((always_inline)) { slk(st2[0], nc, kc); });
+#if TW_RAW_INK
+                // The next step's raw row `wave` -> A-ring, cut into pieces that ride in this k-loop's instruction stream: four
+                // ds_read_b128 (d0..d3 of one channel half) at fragment F0, then one V row (four v_pk_add_f16, one ds_write_b128) every
+                // STRIDE fragments from F0 + GAP on -- an LDS round trip later --, then the other half.  Past the frame's last step
+                // it transforms whatever the look-ahead DMA brought into rows nobody reads.
+                int rpos = a6 + 4 + 2 + wave;
+                rpos = rpos >= 2 * TW_AROWS ? rpos - 2 * TW_AROWS : rpos >= TW_AROWS ? rpos - TW_AROWS : rpos;
+                const char* const rrow = smem + TW_RAW + ((it + 1) & 1) * TW_RAWSLOTB + wave * TW_RAWROWB;
+                char* const vrow = smem + TW_ARING + rpos * TW_AROWB + vlane_c;
+                half8 rd[4];
+                auto raw_hook = [&](auto fc) __attribute__((always_inline)) {
+                    constexpr int f = decltype(fc)::value;
+                    constexpr int H1 = TW_RAW_F0 + TW_RAW_GAP + 3 * TW_RAW_STRIDE + 1;          // the second half's reads
+                    static_assert(H1 + TW_RAW_GAP + 3 * TW_RAW_STRIDE < 48, "the transform ends inside the k-loop");
+                    constexpr int t = f >= H1 ? 1 : 0, g = f - (t ? H1 : TW_RAW_F0);
+                    const unsigned a_lo = t_lo ^ (t ? 64u : 0u), a_hi = t_hi ^ (t ? 64u : 0u);
+                    if constexpr (g == 0) {
+                        rd[0] = *(const half8*)(rrow + a_lo); rd[1] = *(const half8*)(rrow + a_lo + 17 * PIXB);
+                        rd[2] = *(const half8*)(rrow + a_hi); rd[3] = *(const half8*)(rrow + a_hi + 17 * PIXB);
+                    } else if constexpr (g == TW_RAW_GAP) *(half8*)(vrow + 0 * 2048 + t * 1024) = pk_sub(rd[0], rd[2]);
+                    else if constexpr (g == TW_RAW_GAP + TW_RAW_STRIDE) *(half8*)(vrow + 3 * 2048 + t * 1024) = pk_sub(rd[1], rd[3]);
+                    else if constexpr (g == TW_RAW_GAP + 2 * TW_RAW_STRIDE) *(half8*)(vrow + 1 * 2048 + t * 1024) = rd[1] + rd[2];
+                    else if constexpr (g == TW_RAW_GAP + 3 * TW_RAW_STRIDE) *(half8*)(vrow + 2 * 2048 + t * 1024) = pk_sub(rd[2], rd[1]);
+                };
+#else
+                auto raw_hook = [](auto) __attribute__((always_inline)) {};
+#endif
+                kloop(std::true_type{}, bp, [&](auto nc, auto kc) __attribute__((always_inline)) { slk(st2[0], nc, kc); }, raw_hook);
                 __builtin_amdgcn_s_setprio(TW_PRIO_EB);
             }
             e_3 = e_k;
