@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UVA_ABI_VERSION 13  /* 2: + uva_net_submit_u8 / uva_net_collect_u8 / uva_host_alloc / uva_host_free;
+#define UVA_ABI_VERSION 14  /* 2: + uva_net_submit_u8 / uva_net_collect_u8 / uva_host_alloc / uva_host_free;
                                3: + uva_get_gpu_pci_bus_id, uva_debug_trunk2_schedule;
                                4: + uva_denoise_u8, uva_debug_denoise_stage; generic graphs (4x_Valar_v1) load;
                                5: + uva_debug_sub10_rows;
@@ -37,7 +37,8 @@ extern "C" {
                                10: + uva_debug_generic_segments_planes (a frame's reference tiles through those kernels in one launch);
                                11: + uva_debug_generic_batches;
                                12: + uva_debug_trunkw_schedule (trunkw_kernel: fused trunk pairs as Winograd F(2,3));
-                               13: + uva_denoise_u8_device, uva_denoise_synchronize */
+                               13: + uva_denoise_u8_device, uva_denoise_synchronize;
+                               14: + uva_net_device */
 
 typedef struct uva_net uva_net;
 
@@ -65,6 +66,10 @@ uva_net* uva_net_create(void);
 /* net.opt.use_vulkan_compute = True; net.set_vulkan_device(gpus[gpu])   :67-68
  * device = HIP ordinal.  A negative index is rejected (no CPU path). */
 int uva_net_set_device(uva_net* net, int device);
+/* The HIP ordinal the net is bound to: what set_vulkan_device was given, 0 (ncnn's default GPU index,
+ * test_gpus.py:53) if it never was.  The shim asks the library instead of remembering (uva_denoise_u8_device takes
+ * the ordinal and refuses a net that sits elsewhere). */
+int uva_net_device(const uva_net* net);
 /* net.load_param(path)            :70   parses the ncnn text graph.  The SRVGGNetCompact
  * pattern (conv3x3+PReLU stack, conv3x3, PixelShuffle r, Interp nearest r, BinaryOp add) takes
  * the fused kernels; any other graph made of Input / Split / Convolution 3x3 or 1x1 (+ fused

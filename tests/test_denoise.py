@@ -131,3 +131,85 @@ def test_opportunistic_comparison_with_opencv(uva):
     got = up.denoise_u8(img, 3, device=0)
     d = np.abs(got.astype(int) - want.astype(int))
     assert d.max() <= 3, int(d.max())
+
+
+# ---- round 5: the second source (oracle/nlm_float_check.py: float64, the documented formulas, no table, no bin, no shift) ----
+
+def _golden_nlm():
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return (np.load(os.path.join(root, "tests", "golden", "nlm_float.npz")),
+            json.load(open(os.path.join(root, "tests", "golden", "nlm_kat.json"))))
+
+
+def _lvl(a, b):
+    return np.abs(a.astype(int) - b.astype(int))
+
+
+def test_restatement_against_the_independent_float_evaluation():
+    """VERDICT r4 item 7.  The integer restatement (what the kernels are bit-exact to) against the float64 evaluation of the
+    documented formulas, on the committed fixture, STAGE BY STAGE on identical stage inputs: every stage within ONE level --
+    Lab8 (table code vs formulas), NLM on L and on (a, b) (distance bins and fixed-point weights vs exact ones), Lab8 -> BGR
+    (truncating inverse gamma table vs rounding).  End to end the two chains drift further apart (a level of a or b is two to
+    three levels of B, G or R): stated and bounded here too, not hidden."""
+    from oracle import nlm_float_check as nf
+    from oracle import nlm_oracle as no
+    g, _ = _golden_nlm()
+    img = g["in"]
+    assert np.array_equal(img, nf.fixture())
+    i_lab = no.bgr2lab(img)
+    for K in (3, 10):
+        assert _lvl(i_lab, g[f"K{K}_float_lab8"]).max() <= 1
+        i_L, i_ab = no.nlm_plane(i_lab[..., 0], K), no.nlm_plane(np.ascontiguousarray(i_lab[..., 1:]), K)
+        dL, dab = _lvl(i_L, g[f"K{K}_float_nlm_L_on_integer_lab"]), _lvl(i_ab, g[f"K{K}_float_nlm_ab_on_integer_lab"])
+        assert dL.max() <= 1 and dab.max() <= 1 and (dL > 0).mean() < 0.04 and (dab > 0).mean() < 0.03, (K, dL.max(), dab.max())
+        back = no.lab2bgr(np.concatenate([i_L[..., None], i_ab], axis=-1))
+        fback = nf.bgr_from_lab8(np.concatenate([i_L[..., None], i_ab], axis=-1))
+        assert _lvl(back, fback).max() <= 1
+        e2e = _lvl(no.denoise_colored(img, K, K), g[f"K{K}_float_u8"])
+        assert e2e.max() <= 5 and e2e.mean() < 0.8 and (e2e > 1).mean() < 0.06, (K, e2e.max(), e2e.mean())
+    # the float evaluation itself is reproducible from its source (the fixture is not a frozen accident)
+    f_out, f_lab, _, _ = nf.denoise_colored_float(img, 3, 3)
+    assert np.array_equal(f_out, g["K3_float_u8"]) and np.array_equal(f_lab, g["K3_float_lab8"])
+
+
+def test_known_answer_vectors_anyone_can_check_offline():
+    """tests/golden/nlm_kat.json: Lab8 of the primaries and greys by the CIE formulas (cv2.cvtColor(px, cv2.COLOR_LBGR2Lab) may
+    sit one level off: its table code), the end points of LabCbrtTab_b, the end points of the weight table for h = 1, 3, 10, 30.
+    The restatement is held to them here; the file is for a reader with an OpenCV at hand."""
+    from oracle import nlm_oracle as no
+    _, kat = _golden_nlm()
+    for name, e in kat["lab8_of_bgr_by_the_cie_formulas"].items():
+        got = no.bgr2lab(np.array([[e["bgr"]]], np.uint8))[0, 0]
+        assert _lvl(got, np.array(e["lab8"])).max() <= 1, (name, got, e["lab8"])
+    assert kat["lab8_of_bgr_by_the_cie_formulas"]["white"]["lab8"] == [255, 128, 128]
+    assert kat["lab8_of_bgr_by_the_cie_formulas"]["black"]["lab8"] == [0, 128, 128]
+    tab = no.lab_cbrt_tab_b()
+    c = kat["LabCbrtTab_b"]
+    assert len(tab) == c["size"] == 3072 and tab[0] == c["first"] == 4520 and tab[2040] == c["at_2040_is_one"] == 32768
+    assert abs(int(tab[-1]) - c["last"]) <= 1                       # (cv::cbrt is a polynomial: an entry next to a .5 may differ by one)
+    assert kat["weight_table"]["fixed_point_mult"] == 103969
+    for key, e in kat["weight_table"]["entries"].items():
+        h, cn = (int(v.split("=")[1]) for v in key.split(","))
+        t = no.weight_table(h, cn)
+        nz = np.nonzero(t)[0]
+        assert len(t) == e["size"] and t[0] == e["at_0"] == 103969 and t[1] == e["at_1"], key
+        assert nz[-1] == e["last_nonzero_index"] and t[nz[-1]] == e["last_nonzero_value"], key
+
+
+@pytest.mark.gpu
+def test_gpu_stages_against_the_independent_float_evaluation(uva):
+    """the HIP kernels against the second source directly (not through the restatement): every stage within one level on the
+    committed fixture, and the whole stage end to end inside the stated bound"""
+    from upscale_video_amd import upscale_processing as up
+    g, _ = _golden_nlm()
+    img = g["in"]
+    lab = _stage(uva, 0, img)
+    for K in (3, 10):
+        assert _lvl(lab, g[f"K{K}_float_lab8"]).max() <= 1
+        L = _stage(uva, 2, np.ascontiguousarray(lab[..., 0]), float(K))
+        ab = _stage(uva, 3, np.ascontiguousarray(lab[..., 1:]), float(K))
+        assert _lvl(L, g[f"K{K}_float_nlm_L_on_integer_lab"]).max() <= 1
+        assert _lvl(ab, g[f"K{K}_float_nlm_ab_on_integer_lab"]).max() <= 1
+        e2e = _lvl(up.denoise_u8(img, K, device=0), g[f"K{K}_float_u8"])
+        assert e2e.max() <= 5 and e2e.mean() < 0.8, (K, e2e.max(), e2e.mean())

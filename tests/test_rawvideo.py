@@ -1,6 +1,7 @@
 """rawvideo streamer (upscale_video_amd/rawvideo.py): host logic on CPU with a stand-in net, the real
 engine under -m gpu."""
 import io
+import os
 
 import numpy as np
 import pytest
@@ -245,3 +246,87 @@ def test_segments_to_and_from_one_file_per_lane(tmp_path):
     assert open(dst, "rb").read() == whole.getvalue()[:5 * fb * 4]
     with pytest.raises(ValueError):
         rawvideo.stream_segments(ins[:2], dst, h, w, mk(), 2, alloc=alloc)
+
+
+@pytest.mark.parametrize("nlanes,nframes,h,w", [(4, 13, 5, 7), (8, 37, 6, 10), (3, 3, 33, 41), (2, 1, 4, 4)])
+def test_one_output_file_through_mappings_equals_seek_and_write(tmp_path, nlanes, nframes, h, w):
+    """N workers into ONE output file without taking its inode lock in turn -- every worker copies into a
+    shared mapping of its own byte range (MappedSegment).  Frame sizes that are no multiple of a page (segment offsets in the
+    middle of a page, two workers' ranges sharing one): the bytes of the seek + write route and of the one-writer route."""
+    import io
+    frames = _frames(nframes, h, w)
+    src = tmp_path / "in.bgr24"
+    src.write_bytes(b"".join(f.tobytes() for f in frames))
+    mk = lambda: [[(FakeNet(1), 0), (FakeNet(2), 32)] for _ in range(nlanes)]   # noqa: E731
+    alloc = lambda shape: np.zeros(shape, np.uint8)                             # noqa: E731
+    a, b = str(tmp_path / "mapped.bgr24"), str(tmp_path / "written.bgr24")
+    assert rawvideo.stream_segments(str(src), a, h, w, mk(), 2, alloc=alloc, mapped=True) == nframes
+    assert rawvideo.stream_segments(str(src), b, h, w, mk(), 2, alloc=alloc, mapped=False) == nframes
+    whole = io.BytesIO()
+    rawvideo.stream(io.BytesIO(src.read_bytes()), whole, h, w, mk(), alloc=alloc)
+    assert open(a, "rb").read() == open(b, "rb").read() == whole.getvalue()
+    assert os.path.getsize(a) == nframes * h * w * 3 * 4
+
+
+def test_mapped_segment_refuses_to_write_past_its_range(tmp_path):
+    p = tmp_path / "f.bin"
+    p.write_bytes(b"\0" * 10000)
+    seg = rawvideo.MappedSegment(open(p, "r+b"), 4097, 100)
+    seg.write(memoryview(bytes(range(100))))
+    with pytest.raises(ValueError, match="past the end"):
+        seg.write(memoryview(b"x"))
+    seg.close()
+    data = p.read_bytes()
+    assert data[4097:4197] == bytes(range(100)) and data[:4097] == b"\0" * 4097 and data[4197:] == b"\0" * (10000 - 4197)
+
+
+class _FailingNet(FakeNet):
+    def collect_u8(self, t):
+        raise RuntimeError("device lost")
+
+
+def test_a_failed_worker_takes_the_output_with_it(tmp_path):
+    """a worker that fails used to leave a full-size output of zeros and holes under the name of a result"""
+    h, w = 6, 10
+    src = tmp_path / "in.bgr24"
+    src.write_bytes(b"".join(f.tobytes() for f in _frames(8, h, w)))
+    lanes = [[(FakeNet(2), 0)], [(_FailingNet(2), 0)]]
+    alloc = lambda shape: np.zeros(shape, np.uint8)                             # noqa: E731
+    dst = str(tmp_path / "out.bgr24")
+    with pytest.raises(RuntimeError, match="device lost"):
+        rawvideo.stream_segments(str(src), dst, h, w, lanes, 2, alloc=alloc)
+    assert not os.path.exists(dst)
+    outs = [str(tmp_path / "o0"), str(tmp_path / "o1")]
+    with pytest.raises(RuntimeError, match="device lost"):
+        rawvideo.stream_segments(str(src), outs, h, w, [[(FakeNet(2), 0)], [(_FailingNet(2), 0)]], 2, alloc=alloc)
+    assert not any(os.path.exists(o) for o in outs)
+
+
+def test_input_and_output_must_differ_and_commas_are_lists_only_for_worker_lists(tmp_path, capsys):
+    """`-i X -o X` destroyed the input (the output is sized before anything is read); a path with a comma in it
+    stopped working when -i / -o became lists; a list with `-s 1` (no network pass) got the message '0 entries'"""
+    h, w = 4, 6
+    same = tmp_path / "same.bgr24"
+    same.write_bytes(b"".join(f.tobytes() for f in _frames(2, h, w)))
+    with pytest.raises(SystemExit):
+        rawvideo.main(["-i", str(same), "-o", str(same), "-W", str(w), "-H", str(h), "-s", "1"])
+    assert "input and output at once" in capsys.readouterr().err and same.stat().st_size == 2 * h * w * 3
+    with pytest.raises(ValueError, match="input and output at once"):
+        rawvideo.stream_segments(str(same), str(same), h, w, [[(FakeNet(2), 0)], [(FakeNet(2), 0)]], 2,
+                                 alloc=lambda s: np.zeros(s, np.uint8))
+    assert same.stat().st_size == 2 * h * w * 3
+    # one worker: "a,b" is a file name (copy-through needs no GPU)
+    comma_in = tmp_path / "take,1.bgr24"
+    comma_in.write_bytes(same.read_bytes())
+    comma_out = tmp_path / "out,1.bgr24"
+    assert rawvideo.main(["-i", str(comma_in), "-o", str(comma_out), "-W", str(w), "-H", str(h), "-s", "1"]) == 0
+    assert comma_out.read_bytes() == same.read_bytes()
+    # a worker list without a network pass: the message says what the lists are for
+    with pytest.raises(SystemExit):
+        rawvideo.main(["-i", str(same), "-o", "%s,%s" % (tmp_path / "x", tmp_path / "y"), "-W", str(w), "-H", str(h), "-s", "1", "-g", "0,0"])
+    assert "NETWORK PASS" in capsys.readouterr().err
+
+
+def test_filesystem_type_reads_the_mount_table(tmp_path):
+    assert rawvideo.filesystem_type("/dev/shm") in ("tmpfs", None)
+    assert rawvideo.filesystem_type(str(tmp_path)) is None or isinstance(rawvideo.filesystem_type(str(tmp_path)), str)

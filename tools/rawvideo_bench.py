@@ -24,22 +24,39 @@ for args in (["-s", "2"], ["-s", "2", "-g", "0,0"], ["-s", "2", "-m", "a"], ["-s
     t1 = wall(base + args + ["-i", src, "-o", "/dev/null", "--frames", "1"])
     tn = wall(base + args + ["-i", src, "-o", "/dev/null"])
     print(f"{' '.join(args):20s} file -> /dev/null : {N} frames in {tn:6.2f} s (start-up {t1:5.2f} s) = {(N - 1) / (tn - t1):7.1f} frames/s")
-# file -> FILE (a real output file in /dev/shm: page cache): one worker; several workers through ONE reader and ONE writer
-# (--round-robin), with a segment, reader and writer each into ONE shared output file, and into one output file each
-dst = "/dev/shm/uva_out.bgr24"
-free = os.statvfs("/dev/shm").f_bavail * os.statvfs("/dev/shm").f_frsize
-M = max(8, min(N, int(free * 0.6) // (2160 * 3840 * 3)))
-for args, per_lane in ((["-s", "2", "-g", "0"], False), (["-s", "2", "-g", "0,0", "--round-robin"], False), (["-s", "2", "-g", "0,0"], False),
-                       (["-s", "2", "-g", "0,0"], True), (["-s", "2", "-g", "0,0,0,0", "--round-robin"], False), (["-s", "2", "-g", "0,0,0,0"], False),
-                       (["-s", "2", "-g", "0,0,0,0"], True), (["-s", "2", "-g", "0,0,0,0,0,0,0,0"], True)):
-    k = len(args[3].split(","))
-    outs = [dst + ".%d" % i for i in range(k)] if per_lane else [dst]
-    t1 = wall(base + args + ["-i", src, "-o", ",".join(outs), "--frames", str(k)])
-    tn = wall(base + args + ["-i", src, "-o", ",".join(outs), "--frames", str(M)])
-    label = " ".join(args) + (" -o one file per worker" if per_lane else "")
-    print(f"{label:52s} file -> file : {M} frames in {tn:6.2f} s (start-up {t1:5.2f} s) = {(M - k) / (tn - t1):7.1f} frames/s")
-    for o in outs:
-        os.remove(o)
+# file -> FILE: one worker; several workers through ONE reader and ONE writer (--round-robin); a segment, reader and writer
+# each into ONE shared output file -- through shared mappings (the default since round 5) and through seek + write
+# (UVA_RAW_MMAP=0: the writers take the file's inode lock in turn) --; one output file per worker.  On /dev/shm (tmpfs: page
+# cache and nothing else) and on a directory of a REAL file system (UVA_BENCH_DIR, default: the repository's gpurun_out/).
+from upscale_video_amd.rawvideo import filesystem_type
+real_dir = os.environ.get("UVA_BENCH_DIR") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+os.makedirs(real_dir, exist_ok=True)
+for where in ("/dev/shm", real_dir):
+    dst = os.path.join(where, "uva_out.bgr24")
+    st = os.statvfs(where)
+    free = st.f_bavail * st.f_frsize
+    M = max(8, min(N, int(free * 0.5) // (2160 * 3840 * 3), 400 if where == "/dev/shm" else 160))
+    print(f"--- output files in {where} ({filesystem_type(where)}, {free / 1e9:.0f} GB free), {M} frames")
+    for args, per_lane, env in ((["-s", "2", "-g", "0"], False, {}),
+                                (["-s", "2", "-g", "0,0", "--round-robin"], False, {}),
+                                (["-s", "2", "-g", "0,0"], False, {}), (["-s", "2", "-g", "0,0"], False, {"UVA_RAW_MMAP": "0"}),
+                                (["-s", "2", "-g", "0,0"], True, {}),
+                                (["-s", "2", "-g", "0,0,0,0"], False, {}), (["-s", "2", "-g", "0,0,0,0"], False, {"UVA_RAW_MMAP": "0"}),
+                                (["-s", "2", "-g", "0,0,0,0"], True, {}),
+                                (["-s", "2", "-g", "0,0,0,0,0,0,0,0"], False, {}), (["-s", "2", "-g", "0,0,0,0,0,0,0,0"], True, {})):
+        k = len(args[3].split(","))
+        outs = [dst + ".%d" % i for i in range(k)] if per_lane else [dst]
+        os.environ.update(env)
+        try:
+            t1 = wall(base + args + ["-i", src, "-o", ",".join(outs), "--frames", str(k)])
+            tn = wall(base + args + ["-i", src, "-o", ",".join(outs), "--frames", str(M)])
+        finally:
+            for key in env:
+                os.environ.pop(key, None)
+        label = " ".join(args) + (" -o one file per worker" if per_lane else "") + (" seek+write (UVA_RAW_MMAP=0)" if env else "")
+        print(f"{label:64s} file -> file : {M} frames in {tn:6.2f} s (start-up {t1:5.2f} s) = {(M - k) / (tn - t1):7.1f} frames/s", flush=True)
+        for o in outs:
+            os.remove(o)
 t1 = wall(base + ["-s", "2", "-i", src, "-o", "/dev/null", "--frames", "1"])
 tn = wall(f"cat {src} | {' '.join(base)} -s 2 2>/dev/null | cat > /dev/null", shell=True)
 print(f"-s 2         pipe -> pipe      : {N} frames in {tn:6.2f} s = {(N - 1) / (tn - t1):7.1f} frames/s")

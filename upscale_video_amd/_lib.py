@@ -6,13 +6,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UVA_LIB_PATH") or os.path.join(_HERE, "libuva.so")   # override: A/B builds
 
 # every symbol include/uva.h declares
-ABI_VERSION = 13  # include/uva.h UVA_ABI_VERSION
+ABI_VERSION = 14  # include/uva.h UVA_ABI_VERSION
 
 SYMBOLS = [
     "uva_get_gpu_count", "uva_get_default_gpu_index", "uva_get_gpu_info", "uva_get_gpu_pci_bus_id",
     "uva_debug_trunk2_schedule", "uva_debug_trunkw_schedule", "uva_debug_sub10_rows", "uva_net_submit_u8_png", "uva_png_workspace_bytes",
     "uva_png_assemble", "uva_png_deflate_u8", "uva_debug_png_deflate_host", "uva_png_decode_bgr", "uva_debug_zlib_decompress", "uva_net_debug_generic_plan", "uva_debug_generic_segments", "uva_debug_generic_segments_planes", "uva_debug_generic_batches", "uva_denoise_u8", "uva_denoise_u8_device", "uva_denoise_synchronize", "uva_debug_denoise_stage", "uva_destroy_gpu_instance",
-    "uva_net_create", "uva_net_set_device", "uva_net_load_param", "uva_net_load_model",
+    "uva_net_create", "uva_net_set_device", "uva_net_device", "uva_net_load_param", "uva_net_load_model",
     "uva_net_destroy", "uva_net_scale", "uva_net_num_features", "uva_net_num_convs",
     "uva_net_extract_f32", "uva_net_process_u8", "uva_net_process_u8_device", "uva_net_synchronize",
     "uva_net_wait_for", "uva_net_submit_u8", "uva_net_collect_u8", "uva_host_alloc", "uva_host_free",
@@ -96,7 +96,7 @@ def load():
     decl("uva_net_set_device", [c_p, c_i])
     decl("uva_net_load_param", [c_p, ctypes.c_char_p])
     decl("uva_net_load_model", [c_p, ctypes.c_char_p])
-    for n in ("uva_net_scale", "uva_net_num_features", "uva_net_num_convs", "uva_net_synchronize"):
+    for n in ("uva_net_scale", "uva_net_num_features", "uva_net_num_convs", "uva_net_synchronize", "uva_net_device"):
         decl(n, [c_p])
     decl("uva_net_wait_for", [c_p, c_p])
     decl("uva_net_extract_f32", [c_p, c_p, c_i, c_i, c_p])

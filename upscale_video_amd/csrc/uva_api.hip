@@ -1115,6 +1115,17 @@ hipEvent_t take_event(uva_net* n)
     return e;
 }
 
+// take_sync_event() for the length of a scope: the event goes back to its net's pool on EVERY path out (HIP_TRY returns
+// from the middle of a function; a wait has captured the recorded state by then, or nothing was recorded at all)
+struct SyncEventScope {
+    uva_net* n;
+    hipEvent_t e;
+    explicit SyncEventScope(uva_net* net) : n(net), e(take_sync_event(net)) {}
+    ~SyncEventScope() { if (e) n->ev_sync_free.push_back(e); }
+    SyncEventScope(const SyncEventScope&) = delete;
+    SyncEventScope& operator=(const SyncEventScope&) = delete;
+};
+
 // an event that orders one stream behind another (default flags: its release makes the producer's writes visible)
 hipEvent_t take_sync_event(uva_net* n)
 {
@@ -2109,6 +2120,9 @@ int denoise_ctx(int device, size_t px, DenoiseCtx** out)
         HIP_TRY(hipMemcpy(c.d_lab, &host_tables, sizeof(LabTables), hipMemcpyHostToDevice));
     }
     if (c.cap_px < px) {
+        // uva_denoise_u8_device is asynchronous: frames queued on the stream may still use the buffers about to go
+        // (hipFree happens to synchronise the device; said here instead of relied on)
+        if (c.cap_px) HIP_TRY(hipStreamSynchronize(c.stream));
         for (uint8_t** p : {&c.d_in, &c.d_out, &c.d_l, &c.d_l2, &c.d_ab, &c.d_ab2}) {
             if (*p) (void)hipFree(*p);
             *p = nullptr;
@@ -2194,19 +2208,17 @@ int uva_denoise_u8_device(int device, const void* d_in, int h, int w, size_t in_
     if (c->table_h[0] != h_luma || c->table_h[1] != h_color) HIP_TRY(hipStreamSynchronize(c->stream));
     if (denoise_table(*c, 0, h_luma, 1) || denoise_table(*c, 1, h_color, 2)) return 1;
     if (after) {                 // what `after` has been asked to do so far (it wrote d_in, or still reads d_out) comes first
-        hipEvent_t e = take_sync_event(after);
-        if (!e) return 1;
-        HIP_TRY(hipEventRecord(e, after->stream));
-        HIP_TRY(hipStreamWaitEvent(c->stream, e, 0));
-        after->ev_sync_free.push_back(e);
+        SyncEventScope ev(after);
+        if (!ev.e) return 1;
+        HIP_TRY(hipEventRecord(ev.e, after->stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream, ev.e, 0));
     }
     if (denoise_launch(c, (const uint8_t*)d_in, in_stride, (uint8_t*)d_out, out_stride, h, w)) return 1;
     if (before) {                // ... and whatever `before` is asked to do from now on comes after this frame
-        hipEvent_t e = take_sync_event(before);
-        if (!e) return 1;
-        HIP_TRY(hipEventRecord(e, c->stream));
-        HIP_TRY(hipStreamWaitEvent(before->stream, e, 0));
-        before->ev_sync_free.push_back(e);
+        SyncEventScope ev(before);
+        if (!ev.e) return 1;
+        HIP_TRY(hipEventRecord(ev.e, c->stream));
+        HIP_TRY(hipStreamWaitEvent(before->stream, ev.e, 0));
     }
     return 0;
 }
@@ -2365,6 +2377,8 @@ int uva_net_load_model(uva_net* n, const char* path)
     return 0;
 }
 
+int uva_net_device(const uva_net* n) { return n ? n->device : -1; }
+
 int uva_net_scale(const uva_net* n)
 {
     if (!n) return 0;
@@ -2424,11 +2438,10 @@ int uva_net_wait_for(uva_net* n, uva_net* producer)
     if (n == producer || !producer->dev_ready) return 0;
     if (ensure_device(n)) return 1;
     if (producer->device != n->device) return fail("uva_net_wait_for: nets are on different devices");
-    hipEvent_t e = take_sync_event(n);
-    if (!e) return 1;
-    HIP_TRY(hipEventRecord(e, producer->stream));
-    HIP_TRY(hipStreamWaitEvent(n->stream, e, 0));
-    n->ev_sync_free.push_back(e);   // safe to recycle: the wait has captured the recorded state
+    SyncEventScope ev(n);           // (recycled at the end of the scope: the wait has captured the recorded state)
+    if (!ev.e) return 1;
+    HIP_TRY(hipEventRecord(ev.e, producer->stream));
+    HIP_TRY(hipStreamWaitEvent(n->stream, ev.e, 0));
     return 0;
 }
 

@@ -148,6 +148,9 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
 #ifndef TW_RAW_F0             // chain epilogue -> raw rows -> k-loop is what a period is made of (tools/trunkw_anatomy.py)
 #define TW_RAW_F0 0
 #endif
+#ifndef TW_PRE_BAR
+#define TW_PRE_BAR 0          // 1: a k-loop's first fragments (window row 0: written a period or more ago) are read in front of the
+#endif                        // barrier that opens its phase, not behind it
 #ifndef TW_RAW_GAP
 #define TW_RAW_GAP 10
 #endif
@@ -329,7 +332,17 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
     // last MFMA: its slices are the caller's, in the next phase.  The order is pinned fragment by fragment
     // (sched_barrier): the read PFF fragments ahead, this fragment's MFMAs, one slice.
     f32x4 acc[4][4];
-    auto kloop = [&](auto ring_tag, int base_pos, auto&& slice, auto&& hook) __attribute__((always_inline)) {
+    // the first PFF fragments of a k-loop (all of window row 0) into `pre`: TW_PRE_BAR reads them in front of the barrier
+    [[maybe_unused]] auto prefetch = [&](auto ring_tag, int base_pos, auto& pre) __attribute__((always_inline)) {
+        constexpr bool BR = decltype(ring_tag)::value;
+        constexpr int ROWB = BR ? TW_BROWB : TW_AROWB;
+        constexpr int PFF = BR ? TW_PFF_B : PFF_A;
+        static_assert(PFF <= 8, "the fragments read ahead of the barrier are window row 0's");
+        const unsigned r0 = vlane_c + (unsigned)((BR ? TW_BRING : TW_ARING) + base_pos * ROWB);
+#pragma unroll
+        for (int f = 0; f < PFF; ++f) pre[f] = *(const half8*)(smem + r0 + (f & 3) * (ROWB / 4) + ((f >> 2) & 1) * (ROWB / 8));
+    };
+    auto kloop = [&](auto ring_tag, int base_pos, auto&& slice, auto&& hook, [[maybe_unused]] const auto& pre) __attribute__((always_inline)) {
         constexpr bool BR = decltype(ring_tag)::value;
         constexpr int INR = BR ? TW_INROWS_B : TW_INROWS_A;
         constexpr int ROWB = BR ? TW_BROWB : TW_AROWB, NROWS = BR ? TW_BROWS : TW_AROWS;
@@ -351,7 +364,13 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
         half8 bq[RQ];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int f = 0; f < PFF; ++f) bq[f] = read_f(f);
+        for (int f = 0; f < PFF; ++f) {
+#if TW_PRE_BAR
+            bq[f] = pre[f];
+#else
+            bq[f] = read_f(f);
+#endif
+        }
         __builtin_amdgcn_sched_barrier(0);
         static_for<NFRAG>([&](auto fc) __attribute__((always_inline)) {
             constexpr int f = decltype(fc)::value;
@@ -438,6 +457,10 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
         const unsigned w64 = (unsigned)(TW_BRING + (wave >> 1) * (TW_BROWB / 8) + p * 64 + ((oo ^ ((p >> 1) & 3)) << 4) + 8 * (cg & 1));
         const unsigned wrow = p < 15 ? (unsigned)TW_BROWB : 0u;      // (pair 15: every row and both units to the same spare place)
         const unsigned wj = p < 15 ? (unsigned)(TW_BROWB / 4) : 0u;
+        half8 pre[PFF_A];
+#if TW_PRE_BAR
+        prefetch(std::false_type{}, 0, pre);
+#endif
         for (int it = 0; it < niter; ++it) {
             TW_STAMP(0);
             issue_rows(e_dma, it & 1);             // raw rows of step it + 2 (slot it & 1: transformed one phase ago)
@@ -466,9 +489,13 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
                     st.q[2] = pk_add_f16(st.y0, st.t[0]); st.q[3] = pk_add_f16(st.y1, st.t[1]);      // V1 = d1 + d2
                     st.q[4] = pk_sub_f16(st.t[0], st.y0); st.q[5] = pk_sub_f16(st.t[1], st.y1);      // V2 = d2 - d1
                     st.q[6] = pk_sub_f16(st.y0, st.t[2]); st.q[7] = pk_sub_f16(st.y1, st.t[3]);      // V3 = d1 - d3
-#if defined(TW_EXP_2D) && TW_EXP_2D >= 2   // ... + the VALU a y-transform of these values would add: 16 packed adds per row (WRONG results)
+#if defined(TW_EXP_2D) && TW_EXP_2D >= 2   // ... + the VALU a y-transform of these values would add: 16 packed adds per row, four independent
+                    {                      // chains whose results go nowhere (the frame keeps the bytes of TW_EXP_2D=1: same operand data, same power)
+                        unsigned sk[4] = {st.q[0], st.q[1], st.q[2], st.q[3]};
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) st.q[e & 7] = pk_add_f16(st.q[e & 7], st.q[(e + 3) & 7]);
+                        for (int e = 0; e < 16; ++e) sk[e & 3] = pk_add_f16(sk[e & 3], st.q[4 + ((e >> 2) & 3)]);
+                        asm volatile("" :: "v"(sk[0]), "v"(sk[1]), "v"(sk[2]), "v"(sk[3]));
+                    }
 #endif
                 } else if constexpr (k == 6) {
 #ifndef TW_W128
@@ -481,6 +508,12 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
                         char* const w0 = smem + w64 + (unsigned)pos * TW_BROWB;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) *(uint2*)(w0 + j * (TW_BROWB / 4)) = make_uint2(st.q[2 * j], st.q[2 * j + 1]);
+#if defined(TW_EXP_2D) && TW_EXP_2D >= 3   // ... + the ring traffic: a 2-D transform writes twice the rows (the same bytes again: harmless)
+                        char* w1 = w0;
+                        asm volatile("" : "+v"(w1) :: "memory");       // (the same place, which hipcc must not know)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) *(uint2*)(w1 + j * (TW_BROWB / 4)) = make_uint2(st.q[2 * j], st.q[2 * j + 1]);
+#endif
                     }
                 } else if constexpr (k == 7) {
                 } else if constexpr (k == 8) {
@@ -516,10 +549,10 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
                 // steps that touch their plane's edge (uniform, few) mask what lies outside
                 auto no_hook = [](auto) __attribute__((always_inline)) {};
 #if TW_INROWS_A > 0
-                if (edge) kloop(std::false_type{}, a6, [&](auto nc, auto kc) __attribute__((always_inline)) { slice(st2[0], std::true_type{}, nc, kc); }, no_hook);
+                if (edge) kloop(std::false_type{}, a6, [&](auto nc, auto kc) __attribute__((always_inline)) { slice(st2[0], std::true_type{}, nc, kc); }, no_hook, pre);
                 else
 #endif
-                kloop(std::false_type{}, a6, [&](auto nc, auto kc) __attribute__((always_inline)) { slice(st2[0], std::false_type{}, nc, kc); }, no_hook);
+                kloop(std::false_type{}, a6, [&](auto nc, auto kc) __attribute__((always_inline)) { slice(st2[0], std::false_type{}, nc, kc); }, no_hook, pre);
                 __builtin_amdgcn_s_setprio(TW_PRIO_EA);
             }
             e_dma = load_a(it + 3 <= nsteps + TW_PAD_STEPS - 1 ? it + 3 : nsteps + TW_PAD_STEPS - 1);
@@ -551,8 +584,11 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
 #endif
             e_own = load_a(it + 1 < nsteps ? it + 1 : nsteps - 1);
             TW_STAMP(3);
-            group_barrier();
             a6 = a6 + 4 >= TW_AROWS ? a6 + 4 - TW_AROWS : a6 + 4;
+#if TW_PRE_BAR
+            prefetch(std::false_type{}, a6, pre);  // the next step's window row 0 is this step's row 4: transformed a period ago
+#endif
+            group_barrier();
             b10 = b10 + 4 >= TW_BROWS ? b10 + 4 - TW_BROWS : b10 + 4;
         }
     } else {
@@ -588,9 +624,13 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
                     const auto x = __builtin_amdgcn_permlane16_swap(st.x0, st.y0, false, false);
                     const auto y = __builtin_amdgcn_permlane16_swap(st.x1, st.y1, false, false);
                     st.q[0] = x[0]; st.q[1] = y[0]; st.q[2] = x[1]; st.q[3] = y[1];
-#if defined(TW_EXP_2D) && TW_EXP_2D >= 2   // ... + the second output transform's adds (WRONG results)
+#if defined(TW_EXP_2D) && TW_EXP_2D >= 2   // ... + the second output transform's adds (results discarded, see above)
+                    {
+                        unsigned sk[4] = {st.x0, st.x1, st.y0, st.y1};
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) st.q[e & 3] = pk_add_f16(st.q[e & 3], st.q[(e + 1) & 3]);
+                        for (int e = 0; e < 16; ++e) sk[e & 3] = pk_add_f16(sk[e & 3], st.q[(e >> 2) & 3]);
+                        asm volatile("" :: "v"(sk[0]), "v"(sk[1]), "v"(sk[2]), "v"(sk[3]));
+                    }
 #endif
                 } else if constexpr (k == 5) {
                     char* dst = (n >= v0 && n < vy && colok) ? obase + (size_t)n * pitch : sink;
@@ -602,8 +642,8 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
             TW_STAMP(0);
             if (it >= 2 && ((__builtin_amdgcn_readfirstlane(e_3.y) >> 24) & 1u)) {      // row 3 of step it - 2
                 auto sl3 = make_slice(e_3);
-                static_assert(TW_INROWS_B == 0 || TW_INROWS_B == 2, "rows are finished in pairs");
-                static_for<(4 - TW_INROWS_B) / 2>([&](auto rc) __attribute__((always_inline)) {
+                static_assert(TW_INROWS_B >= 0 && TW_INROWS_B <= 3, "rows 0 .. TW_INROWS_B - 1 ride in the k-loop");
+                static_for<(4 - TW_INROWS_B) / 2>([&](auto rc) __attribute__((always_inline)) {      // the rest in pairs, slice by slice
                     static_for<6>([&](auto kc) __attribute__((always_inline)) {
                         sl3(st2[0], std::integral_constant<int, TW_INROWS_B + 2 * decltype(rc)::value>{}, kc);
                         sl3(st2[1], std::integral_constant<int, TW_INROWS_B + 2 * decltype(rc)::value + 1>{}, kc);
@@ -612,9 +652,17 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
 #endif
                     });
                 });
+                if constexpr ((4 - TW_INROWS_B) % 2 == 1)                                             // ... and the odd one out
+                    static_for<6>([&](auto kc) __attribute__((always_inline)) { sl3(st2[0], std::integral_constant<int, 3>{}, kc); });
             }
             e_k = load_b(it >= 1 ? it - 1 : 0);
             const unsigned kact = (it >= 1 && it <= nsteps) ? (__builtin_amdgcn_readfirstlane(e_k.y) >> 24) & 1u : 0u;
+            int bp = b10 - 4 - 2;                  // block it - 1 begins at (4 (it - 1)) mod 10; the window starts two rows above
+            bp = bp < 0 ? bp + TW_BROWS : bp;
+            half8 pre[TW_PFF_B];
+#if TW_PRE_BAR
+            prefetch(std::true_type{}, bp, pre);   // window row 0 = the third row of block it - 2: written three phases ago
+#endif
             TW_STAMP(1);
             group_barrier();
             TW_STAMP(2);
@@ -650,8 +698,6 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
             TW_STAMP(4);
             if (kact) {
                 __builtin_amdgcn_s_setprio(TW_PRIO_KB);
-                int bp = b10 - 4 - 2;              // block it - 1 begins at (4 (it - 1)) mod 10; the window starts two rows above
-                bp = bp < 0 ? bp + TW_BROWS : bp;
                 auto slk = make_slice(e_k);
 #if TW_RAW_INK
                 // The next step's raw row `wave` -> A-ring, cut into pieces that ride in this k-loop's instruction stream: four
@@ -680,7 +726,7 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
 #else
                 auto raw_hook = [](auto) __attribute__((always_inline)) {};
 #endif
-                kloop(std::true_type{}, bp, [&](auto nc, auto kc) __attribute__((always_inline)) { slk(st2[0], nc, kc); }, raw_hook);
+                kloop(std::true_type{}, bp, [&](auto nc, auto kc) __attribute__((always_inline)) { slk(st2[0], nc, kc); }, raw_hook, pre);
                 __builtin_amdgcn_s_setprio(TW_PRIO_EB);
             }
             e_3 = e_k;

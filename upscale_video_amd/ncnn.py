@@ -215,11 +215,13 @@ class Net:
         if h:
             self._L.uva_net_destroy(h)
 
-    device_index = 0
+    @property
+    def device_index(self):
+        """the HIP ordinal the net is bound to, as the library holds it (include/uva.h uva_net_device)"""
+        return int(self._L.uva_net_device(self._h))
 
     def set_vulkan_device(self, device_index):
         _lib.check(self._L.uva_net_set_device(self._h, int(device_index)))
-        self.device_index = int(device_index)
 
     blob_names = ("input", "output")     # of the loaded graph (load_param)
 

@@ -19,9 +19,12 @@ order: denoise, anime pass, upscale; upscale/upscale_processing.py:880-920),
 -g/--gpu a list of HIP ordinals, one worker per entry (duplicates allowed).  Pipes: one reader deals the frames
 out round-robin, one writer puts the results out in frame order.  File to file: one contiguous segment of frames per
 entry, each with its own reader, chain of nets and writer on its own file handles (stream_segments) -- no shared serial
-copy, so the route scales with the GPUs; `-o x,y,...` (and `-i a,b,...`) give every entry a file of its own.
+copy, so the route scales with the GPUs.  Into ONE output file the writers copy through shared MAPPINGS of their own byte
+ranges (MappedSegment): write() / pwrite() calls on one file take its inode lock in turn whatever their offsets, page faults
+on different pages do not.  `-o x,y,...` (and `-i a,b,...`, with more than one -g entry) give every entry a file of its own.
 """
 import argparse
+import mmap
 import os
 import sys
 import threading
@@ -232,22 +235,93 @@ def stream(fin, fout, h, w, nets_tiles, alloc=None, max_frames=None):
     return written
 
 
-def stream_segments(in_path, out_path, h, w, lanes_spec, scale_total, max_frames=None, alloc=None, opener=open):
+def filesystem_type(path):
+    """fstype of the mount `path` lives on (/proc/self/mountinfo, longest mount point that is a prefix); None if unknown"""
+    try:
+        real = os.path.realpath(path)
+        best, kind = "", None
+        for line in open("/proc/self/mountinfo"):
+            left, _, right = line.partition(" - ")
+            mp = left.split()[4].replace("\\040", " ")
+            if (real == mp or real.startswith(mp.rstrip("/") + "/")) and len(mp) >= len(best):
+                best, kind = mp, right.split()[0]
+        return kind
+    except (OSError, IndexError):
+        return None
+
+
+class MappedSegment:
+    """The writer's end of ONE worker's byte range of a shared output file: a shared mapping of just that range, filled frame by
+    frame with plain memory copies (numpy releases the interpreter lock for them).  Why not write(): every buffered write() /
+    pwrite() on a file holds its inode lock for the whole copy -- ext4, xfs and tmpfs alike -- so N writers into ONE file
+    proceed one at a time however disjoint their offsets (measured: four workers SLOWER than one,
+    profiles/r04_final_rawvideo_bench.txt); stores through a mapping fault their pages in independently.  The pages of a
+    frame are asked for in one call (MADV_POPULATE_WRITE, Linux 5.14+) instead of 6 075 faults where the kernel knows it."""
+    _POPULATE_WRITE = getattr(mmap, "MADV_POPULATE_WRITE", 23)
+
+    def __init__(self, f, offset, nbytes):
+        self._f = f
+        gran = mmap.ALLOCATIONGRANULARITY
+        base = offset - offset % gran
+        self._pos = offset - base
+        self._mm = mmap.mmap(f.fileno(), self._pos + nbytes, access=mmap.ACCESS_WRITE, offset=base)
+        self._arr = np.frombuffer(self._mm, np.uint8)
+        self._populate = hasattr(self._mm, "madvise")
+
+    def write(self, view):
+        src = np.frombuffer(view, np.uint8)
+        n, p = src.size, self._pos
+        if p + n > self._arr.size:
+            raise ValueError("write past the end of the segment")
+        if self._populate:
+            a = p - p % mmap.PAGESIZE
+            try:
+                self._mm.madvise(self._POPULATE_WRITE, a, p + n - a)
+            except (OSError, ValueError):
+                self._populate = False          # an older kernel: plain page faults do the same, one page at a time
+        np.copyto(self._arr[p:p + n], src)
+        self._pos = p + n
+        return n
+
+    def flush(self):
+        pass                                    # (the page cache has the bytes; durability is the caller's fsync, as with write())
+
+    def close(self):
+        self._arr = None
+        self._mm.close()
+        self._f.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def stream_segments(in_path, out_path, h, w, lanes_spec, scale_total, max_frames=None, alloc=None, opener=open, mapped=None):
     """The same frames -> the same bytes as stream(), for regular FILES, with NO shared serial copy: one contiguous segment of
     frames per `-g` entry (the reference's batches, upscale/upscale_processing.py:923-948, are such segments), and every entry
     runs its own stream() -- its own reader, its own pipelined chain of nets, its own writer thread -- on its own file handles.
       in_path   one file: cut into len(lanes_spec) segments, each read at its offset;  a list: one input file per entry
-      out_path  one file: every entry writes at the offset its results belong to (the file is sized first);  a list: one
-                output file per entry -- separate inodes, what a file system wants of concurrent writers (buffered writes
-                to ONE file take its inode lock in turn)
+      out_path  one file: sized first (space checked: statvfs; blocks reserved with posix_fallocate where that is cheap, i.e.
+                not on tmpfs, whose fallocate touches every page), then every entry copies its results into a shared mapping
+                of its own byte range (MappedSegment; `mapped=False` / UVA_RAW_MMAP=0: seek + write on its own handle, which
+                serialise on the file's inode lock);  a list: one output file per entry
     One reader and one writer thread copy ~10 GB/s each, two or three GPUs' worth of 1080p -> 4K frames; N independent pairs
-    scale with the entries.  Returns the number of frames written."""
+    scale with the entries.  A worker that fails takes the output with it: the file(s) this call created are removed (a
+    full-size file of zeros and holes is worse than none).  Returns the number of frames written."""
     fb_in, fb_out = h * w * 3, h * scale_total * w * scale_total * 3
     nl = len(lanes_spec)
     ins = list(in_path) if isinstance(in_path, (list, tuple)) else None
     outs = list(out_path) if isinstance(out_path, (list, tuple)) else None
     if (ins is not None and len(ins) != nl) or (outs is not None and len(outs) != nl):
         raise ValueError("one input / output file per -g entry: %d entries" % nl)
+    if mapped is None:
+        mapped = os.environ.get("UVA_RAW_MMAP", "1") != "0"
+    for i in (ins if ins is not None else [in_path]):
+        for o in (outs if outs is not None else [out_path]):
+            if os.path.exists(o) and os.path.samefile(i, o):
+                raise ValueError("%s is input and output at once: the output is sized (truncated) before anything is read" % o)
 
     def frames_of(path):
         size = os.path.getsize(path)
@@ -270,9 +344,22 @@ def stream_segments(in_path, out_path, h, w, lanes_spec, scale_total, max_frames
         in_first = [0] * nl
         total = sum(counts)
     out_first = [0] * nl if outs is not None else [sum(counts[:k]) for k in range(nl)]
+    created = [o for o in (outs if outs is not None else [out_path]) if not os.path.exists(o)]
     if outs is None:
         with opener(out_path, "wb") as f:       # the output exists at its full size before anybody writes into it
             f.truncate(total * fb_out)
+            if mapped and total:
+                # stores into a hole of a full file system end in SIGBUS, not in ENOSPC: make sure of the space first
+                st = os.statvfs(out_path)
+                if st.f_bavail * st.f_frsize < total * fb_out:
+                    f.truncate(0)
+                    raise OSError(28, "%s: %d bytes of results do not fit the file system (%d free)"
+                                  % (out_path, total * fb_out, st.f_bavail * st.f_frsize))
+                if filesystem_type(out_path) not in ("tmpfs", "ramfs", None):
+                    try:
+                        os.posix_fallocate(f.fileno(), 0, total * fb_out)
+                    except OSError:
+                        pass                     # (a file system without fallocate: the check above stands)
     done, errs = [0] * nl, []
 
     def work(k):
@@ -281,11 +368,15 @@ def stream_segments(in_path, out_path, h, w, lanes_spec, scale_total, max_frames
                 if outs is not None:
                     opener(outs[k], "wb").close()
                 return
-            with opener(in_path if ins is None else ins[k], "rb") as fin, \
-                    opener(out_path if outs is None else outs[k], "r+b" if outs is None else "wb") as fout:
+            with opener(in_path if ins is None else ins[k], "rb") as fin:
                 fin.seek(in_first[k] * fb_in)
-                fout.seek(out_first[k] * fb_out)
-                done[k] = stream(fin, fout, h, w, lanes_spec[k], alloc=alloc, max_frames=counts[k])
+                if outs is None and mapped:
+                    with MappedSegment(opener(out_path, "r+b"), out_first[k] * fb_out, counts[k] * fb_out) as fout:
+                        done[k] = stream(fin, fout, h, w, lanes_spec[k], alloc=alloc, max_frames=counts[k])
+                else:
+                    with opener(out_path if outs is None else outs[k], "r+b" if outs is None else "wb") as fout:
+                        fout.seek(out_first[k] * fb_out)
+                        done[k] = stream(fin, fout, h, w, lanes_spec[k], alloc=alloc, max_frames=counts[k])
         except Exception as e:  # noqa: BLE001
             errs.append(e)
     threads = [threading.Thread(target=work, args=(k,), daemon=True) for k in range(nl)]
@@ -294,6 +385,11 @@ def stream_segments(in_path, out_path, h, w, lanes_spec, scale_total, max_frames
     for t in threads:
         t.join()
     if errs:
+        for o in created:
+            try:
+                os.remove(o)
+            except OSError:
+                pass
         raise errs[0]
     return sum(done)
 
@@ -385,11 +481,24 @@ def main(argv=None):
             chain.append((load_net(final_stem, gpu, a.model_path), a.tile))
         if chain:
             nets.append(chain)
-    # file -> file with several workers: one contiguous segment of frames per worker, each with its own reader and writer
-    ins, outs = a.input.split(","), a.output.split(",")
+    # file -> file with several workers: one contiguous segment of frames per worker, each with its own reader and writer.
+    # "a,b,..." is a LIST only where a list means something -- more than one -g entry -- and only if no file of exactly that
+    # name exists (a path may contain a comma)
+    def as_list(arg):
+        if len(gpus) > 1 and "," in arg and not os.path.exists(arg):
+            return arg.split(",")
+        return [arg]
+    ins, outs = as_list(a.input), as_list(a.output)
     if len(ins) > 1 or len(outs) > 1:
+        if not nets:
+            ap.error("-i / -o lists give every -g entry's NETWORK PASS a file of its own; `-s 1` without -m a / n=K only copies "
+                     "frames through (upscale_processing.py:924-929): one input, one output")
         if (len(ins) > 1 and len(ins) != len(nets)) or (len(outs) > 1 and len(outs) != len(nets)) or "-" in ins + outs:
             ap.error("-i / -o lists: one regular file per -g entry (%d entries)" % len(nets))
+    for i in ins:
+        for o in outs:
+            if i != "-" and o != "-" and os.path.exists(i) and os.path.exists(o) and os.path.samefile(i, o):
+                ap.error("%s is input and output at once" % o)
     regular = all(os.path.isfile(f) for f in ins) and all(not os.path.exists(f) or os.path.isfile(f) for f in outs)
     if nets and (len(ins) > 1 or len(outs) > 1 or (len(nets) > 1 and not a.round_robin and a.input != "-" and a.output != "-" and regular)):
         if not regular:
@@ -403,19 +512,24 @@ def main(argv=None):
         ncnn.destroy_gpu_instance()
         return 0
     fin = sys.stdin.buffer if a.input == "-" else open(a.input, "rb")
+    created = a.output != "-" and not os.path.exists(a.output)
     fout = sys.stdout.buffer if a.output == "-" else open(a.output, "wb")
     for f in (fin, fout):
         grow_pipe(f)
+    ok = False
     try:
         if nets:
             n = stream(fin, fout, a.height, a.width, nets, max_frames=a.frames)
         else:
             n = copy_through(fin, fout, a.height, a.width, a.frames)
+        ok = True
     finally:
         if fin is not sys.stdin.buffer:
             fin.close()
         if fout is not sys.stdout.buffer:
             fout.close()
+            if not ok and created and os.path.isfile(a.output):
+                os.remove(a.output)                # half a stream under the name of a whole one helps nobody
     print("%d frames" % n, file=sys.stderr)
     ncnn.destroy_gpu_instance()
     return 0
