@@ -605,8 +605,11 @@ def run(args, comm, device):
                  ("trunk_kernel" if nf == 64 else "conv3x3_kernel")
         trunk_flops_per_launch = layers_per_launch * 2 * 9 * nf * nf * h * w        # algorithmic: un-tiled frame
         whole_net = nf == 24 and layers_per_launch > nconv - 2.5    # sub10_kernel: all ten convolutions of the 1x net in one launch
+        split5 = nf == 24 and 3.5 < layers_per_launch < 4.5         # sub5_kernel (UVA_SUB5=1): the same net as two launches of five layers
         if whole_net:
             trunk_flops_per_launch = conv_flops_per_px(nf, nconv, s) * h * w
+        if split5:
+            trunk_flops_per_launch = conv_flops_per_px(nf, nconv, s) * h * w / 2.0     # (the frame's convolutions over its two launches)
         avg_ms = trunk_ms / max(1, n_launch)
         achieved = trunk_flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         frame_flops = conv_flops_per_px(nf, nconv, s) * h * w
@@ -639,6 +642,7 @@ def run(args, comm, device):
             },
             "roofline": {
                 "kernel": ("sub10_kernel (the whole 1x net: 3->24, 8 x 24->24, 24->3, + input, one launch per frame)" if whole_net else
+                           "sub5_kernel (the 1x net as two launches of five layers, two pipelines per workgroup; per launch: half the net's FLOPs)" if split5 else
                            (f"{kernel}<{nf}>" if nf == 64 else ("pair24_kernel" if fused else f"conv3x3_kernel<{nf},0,1>")) +
                            (f" ({int(round(layers_per_launch))} trunk layers {nf}->{nf} + PReLU per launch)")),
                 "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",

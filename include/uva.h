@@ -38,7 +38,7 @@ extern "C" {
                                11: + uva_debug_generic_batches;
                                12: + uva_debug_trunkw_schedule (trunkw_kernel: fused trunk pairs as Winograd F(2,3));
                                13: + uva_denoise_u8_device, uva_denoise_synchronize;
-                               14: + uva_net_device */
+                               14: + uva_net_device, uva_debug_sub5_rows (sub5_kernel: the 1x net as two launches of five layers) */
 
 typedef struct uva_net uva_net;
 
@@ -266,6 +266,11 @@ int uva_debug_generic_batches(int h, int w, int tile_size, int border, long long
  * writes columns x0+10 .. x0+69 of it when emit is set. */
 int uva_debug_sub10_rows(int h, int w, int grid, uint32_t* rows_words, size_t capacity_words, size_t* needed_words,
                          int* nrows, int* stride);
+/* The same for sub5_kernel (UVA_SUB5=1: that net as two launches of five layers, two pipelines -- a PAIR of 54-column strips --
+ * per workgroup; csrc/uva_sub5.hip.h).  Entries {row y, column of computed column 0 of the pair's first strip, 1 = written
+ * out, 0}; both launches walk the same lists. */
+int uva_debug_sub5_rows(int h, int w, int grid, uint32_t* rows_words, size_t capacity_words, size_t* needed_words,
+                        int* nrows, int* stride);
 
 const char* uva_last_error(void);
 int uva_abi_version(void);

@@ -8,5 +8,5 @@ C=$R/upscale_video_amd/csrc
 O=$C/_obj${INSTR:+_instr}
 mkdir -p /tmp/uva_var
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function ${INSTR:+-DUVA_INSTRUMENT} "$@" -c $C/uva_wino.hip -o /tmp/uva_var/uva_wino_$NAME.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $O/uva_api.o /tmp/uva_var/uva_wino_$NAME.o $O/uva_model.o $O/uva_generic.o $O/uva_pngread.o -o $R/upscale_video_amd/libuva_$NAME.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $O/uva_api.o /tmp/uva_var/uva_wino_$NAME.o $O/uva_sub5.o $O/uva_model.o $O/uva_generic.o $O/uva_pngread.o -o $R/upscale_video_amd/libuva_$NAME.so
 echo $R/upscale_video_amd/libuva_$NAME.so

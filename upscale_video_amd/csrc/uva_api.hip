@@ -12,6 +12,7 @@
 #include "uva_model.h"
 #include "uva_png.hip.h"
 #include "uva_wino.h"
+#include "uva_sub5.h"
 
 namespace uva {   // uva_pngread.cpp
 int png_read_bgr(const uint8_t* file, size_t len, uint8_t* out, size_t cap, int* h_out, int* w_out, std::string& err);
@@ -72,6 +73,13 @@ struct Workspace {
     int* d_nrows10 = nullptr;
     int max_rows10 = 0, grid10 = 0;
     bool sub10_unfit = false;
+    // sub5_kernel (the 1x net as two launches of five layers, two pipelines per workgroup): row descriptors and the 24-channel
+    // image between the launches
+    uint4* d_rows5 = nullptr;
+    int* d_nrows5 = nullptr;
+    int max_rows5 = 0, grid5 = 0;
+    char* d_mid5 = nullptr;
+    bool sub5_unfit = false;
     // trunk2_kernel (fused layer pair): per-workgroup step lists
     Trunk2Step* d_steps2 = nullptr;
     int* d_nsteps2 = nullptr;
@@ -94,6 +102,12 @@ struct Workspace {
         if (d_nrows10) (void)hipFree(d_nrows10);
         d_rows10 = nullptr;
         d_nrows10 = nullptr;
+        if (d_rows5) (void)hipFree(d_rows5);
+        if (d_nrows5) (void)hipFree(d_nrows5);
+        if (d_mid5) (void)hipFree(d_mid5);
+        d_rows5 = nullptr;
+        d_nrows5 = nullptr;
+        d_mid5 = nullptr;
         d_sched4 = nullptr;
         d_steps2 = nullptr;
         d_nsteps2 = nullptr;
@@ -156,6 +170,7 @@ struct uva_net {
     bool generic_fuse_add = true; // generic graphs: sums that follow a convolution are done in its epilogue (UVA_GENERIC_FUSE_ADD=0: own launch)
     bool generic_lds_conv = true; // generic graphs: 3x3 convolutions through g_conv3_lds (UVA_GENERIC_LDS=0: the plain g_conv<3>)
     bool fuse_all = true;         // 24-feature 1x net: all ten convolutions in one launch (sub10_kernel); UVA_SUB10=0 turns it off
+    bool split5 = false;          // ... as two launches of five layers instead (sub5_kernel, csrc/uva_sub5.hip.h); UVA_SUB5=1
     bool fuse_pairs = true;       // 64-feature nets: trunk layers run two per launch (trunk2_kernel); UVA_TRUNK_FUSION=0 turns it off
     bool carry = true;            // ... and between two launches the negated channels stay negated in HBM (UVA_TW_CARRY=0: every launch
                                   // restores the signs in front of its stores)
@@ -686,6 +701,88 @@ int build_sub10_rows(int h, int w, int grid, std::vector<uint4>& rows, std::vect
     return 0;
 }
 
+// Row descriptors of sub5_kernel (both launches use the same lists): PAIRS of 54-column strips, the sequence (pair, row) dealt
+// out to the workgroups in contiguous ranges; every range (segment) starts 5 rows early and ends 5 rows late -- what five
+// 3x3 layers need --, only its own rows are written out.  x = plane row, y = plane column of computed column 0 of the pair's
+// FIRST strip (the second one's is S5_VALID further right), z = 1: written out.
+int build_sub5_rows(int h, int w, int grid, std::vector<uint4>& rows, std::vector<int>& nrows, int* max_rows)
+{
+    const int np = (w + S5_PAIRW - 1) / S5_PAIRW;
+    const long long total = (long long)np * h;
+    struct Seg { int k, y0, n; };
+    std::vector<std::vector<Seg>> per_wg;
+    int D = (int)std::max<long long>(2 * S5_NL + 4, (total + grid - 1) / grid + 2 * S5_NL);
+    for (;; ++D) {
+        per_wg.assign(1, {});
+        int cap = D;
+        for (int k = 0; k < np; ++k) {
+            int y = 0;
+            while (y < h) {
+                if (cap < 2 * S5_NL + 1) { per_wg.emplace_back(); cap = D; }
+                const int n = std::min(h - y, cap - 2 * S5_NL);
+                per_wg.back().push_back({k, y, n});
+                cap -= n + 2 * S5_NL;
+                y += n;
+            }
+        }
+        if ((int)per_wg.size() <= grid) break;
+    }
+    if (D > S5_MAX_ROWS) return 2;       // the row table does not fit the kernel's LDS copy: the caller takes another path
+    *max_rows = D;
+    rows.assign((size_t)grid * D, make_uint4(0, 0, 0, 0));
+    nrows.assign(grid, 0);
+    const int per_xcd = grid / 8;
+    for (size_t c = 0; c < per_wg.size(); ++c) {
+        const int b = (int)(c % per_xcd) * 8 + (int)(c / per_xcd);
+        uint4* out = rows.data() + (size_t)b * D;
+        int g = 0;
+        for (const Seg& sg : per_wg[c])
+            for (int y = sg.y0 - S5_NL; y < sg.y0 + sg.n + S5_NL; ++y, ++g)
+                out[g] = make_uint4((unsigned)y, (unsigned)(sg.k * S5_PAIRW - S5_NL), (y >= sg.y0 && y < sg.y0 + sg.n) ? 1u : 0u, 0u);
+        nrows[b] = g;
+    }
+    return 0;
+}
+
+// the 24-feature 1x net as two launches of five layers (u8 route, one plane); returns 2 when the frame is too large for it
+int launch_sub5(uva_net* n, Workspace* ws, const void* src, size_t src_stride, void* dst, size_t dst_stride,
+                unsigned long long* dbg = nullptr, int dbg_part = -1)
+{
+    if (ws->sub5_unfit) return 2;
+    if (!ws->d_rows5) {
+        std::vector<uint4> rows;
+        std::vector<int> nrows;
+        ws->grid5 = std::max(8, (n->ncu / 8) * 8);
+        if (build_sub5_rows(ws->h, ws->w, ws->grid5, rows, nrows, &ws->max_rows5)) {
+            ws->sub5_unfit = true;
+            return 2;
+        }
+        HIP_TRY(hipMalloc((void**)&ws->d_mid5, (size_t)ws->h * ws->w * S5_MIDB));
+        HIP_TRY(hipMalloc((void**)&ws->d_rows5, rows.size() * sizeof(uint4)));
+        HIP_TRY(hipMalloc((void**)&ws->d_nrows5, nrows.size() * sizeof(int)));
+        HIP_TRY(hipMemcpyAsync(ws->d_rows5, rows.data(), rows.size() * sizeof(uint4), hipMemcpyHostToDevice, n->stream));
+        HIP_TRY(hipMemcpyAsync(ws->d_nrows5, nrows.data(), nrows.size() * sizeof(int), hipMemcpyHostToDevice, n->stream));
+        HIP_TRY(hipStreamSynchronize(n->stream));
+    }
+    for (int part = 0; part < 2; ++part) {
+        Sub5Args a;
+        std::memset(&a, 0, sizeof a);
+        a.src = (const uint8_t*)src; a.src_stride = src_stride;
+        a.dst = (uint8_t*)dst; a.dst_stride = dst_stride;
+        a.mid = ws->d_mid5;
+        a.h = ws->h; a.w = ws->w;
+        a.rows = ws->d_rows5; a.nrows = ws->d_nrows5; a.max_rows = ws->max_rows5;
+        a.dbg = part == dbg_part ? dbg : nullptr;
+        for (int i = 0; i < S5_NL; ++i) {
+            a.wpk[i] = n->layers[S5_NL * part + i].wpk_s10;
+            a.bias[i] = n->layers[S5_NL * part + i].bias_s10;
+            a.slope[i] = n->layers[S5_NL * part + i].slope;
+        }
+        HIP_TRY(launch_sub5_kernel(n->stream, ws->grid5, a, part));
+    }
+    return 0;
+}
+
 // the whole 24-feature 1x net in one launch (u8 route, one plane); returns 2 when the frame is too large for it
 int launch_sub10(uva_net* n, Workspace* ws, const void* src, size_t src_stride, void* dst, size_t dst_stride,
                  unsigned long long* dbg = nullptr)
@@ -804,6 +901,7 @@ int ensure_device(uva_net* n)
     if (const char* e = std::getenv("UVA_TW_ACT16")) n->act16 = std::atoi(e) != 0;
     if (const char* e = std::getenv("UVA_TW_CARRY")) n->carry = std::atoi(e) != 0;
     if (const char* e = std::getenv("UVA_SUB10")) n->fuse_all = std::atoi(e) != 0;
+    if (const char* e = std::getenv("UVA_SUB5")) n->split5 = std::atoi(e) != 0;
     if (const char* e = std::getenv("UVA_GENERIC_LDS")) n->generic_lds_conv = std::atoi(e) != 0;
     if (const char* e = std::getenv("UVA_GENERIC_FUSE_ADD")) n->generic_fuse_add = std::atoi(e) != 0;
     HIP_TRY(hipMalloc((void**)&n->d_sink, 64 * 128 + 256));
@@ -1195,12 +1293,14 @@ int run_graph(uva_net* n, Workspace* ws, bool f32, const void* src, size_t src_s
             HIP_TRY(hipEventRecord(ev1.e[0], n->stream));
             HIP_TRY(hipEventRecord(ev1.e[1], n->stream));
         }
-        const int rc = launch_sub10(n, ws, src, src_stride, dst, dst_stride);
+        int rc = 2, launches = 2;
+        if (n->split5 && !ws->sub5_unfit) rc = launch_sub5(n, ws, src, src_stride, dst, dst_stride);
+        if (rc == 2) { rc = launch_sub10(n, ws, src, src_stride, dst, dst_stride); launches = 1; }
         if (rc == 1) return 1;
         if (prof1) {
             HIP_TRY(hipEventRecord(ev1.e[2], n->stream));
             HIP_TRY(hipEventRecord(ev1.e[3], n->stream));
-            ev1.ntrunk = 1;
+            ev1.ntrunk = launches;
             if (rc == 0) n->ev_pending.push_back(ev1);
             else for (auto e : ev1.e) n->ev_free.push_back(e);
         }
@@ -3097,6 +3197,23 @@ int uva_debug_sub10_rows(int h, int w, int grid, uint32_t* rows_words, size_t ca
     int max_rows = 0;
     const int rc = build_sub10_rows(h, w, grid, rows, nr, &max_rows);
     if (rc == 2) return fail("frame too large for the fused 1x kernel's row table");
+    if (rc) return 1;
+    if (needed_words) *needed_words = rows.size() * 4;
+    if (stride) *stride = max_rows;
+    if (!rows_words || capacity_words < rows.size() * 4) return fail("rows buffer too small");
+    std::memcpy(rows_words, rows.data(), rows.size() * sizeof(uint4));
+    if (nrows) std::copy(nr.begin(), nr.end(), nrows);
+    return 0;
+}
+
+int uva_debug_sub5_rows(int h, int w, int grid, uint32_t* rows_words, size_t capacity_words, size_t* needed_words, int* nrows, int* stride)
+{
+    if (h <= 0 || w <= 0 || grid <= 0 || grid % 8) return fail("bad argument");
+    std::vector<uint4> rows;
+    std::vector<int> nr;
+    int max_rows = 0;
+    const int rc = build_sub5_rows(h, w, grid, rows, nr, &max_rows);
+    if (rc == 2) return fail("frame too large for sub5_kernel's row table");
     if (rc) return 1;
     if (needed_words) *needed_words = rows.size() * 4;
     if (stride) *stride = max_rows;

@@ -143,14 +143,22 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
 #define TW_INROWS_B TW_INROWS
 #endif
 #ifndef TW_RAW_INK
-#define TW_RAW_INK 0          // 1: the consumers transform the next step's raw rows INSIDE their k-loop (reads at fragment TW_RAW_F0, the
-#endif                        // four V rows of a channel half TW_RAW_GAP fragments later, one every TW_RAW_STRIDE fragments): their serial
-#ifndef TW_RAW_F0             // chain epilogue -> raw rows -> k-loop is what a period is made of (tools/trunkw_anatomy.py)
-#define TW_RAW_F0 0
+#define TW_RAW_INK 1          // 1 (default since round 5): the consumers transform the next step's raw rows INSIDE their k-loop -- reads at
+#endif                        // fragment TW_RAW_F0, the four V rows of a channel half TW_RAW_GAP fragments later, one every TW_RAW_STRIDE
+#ifndef TW_RAW_F0             // fragments, then the other half.  Their serial chain epilogue -> raw rows -> k-loop was what a period was
+#define TW_RAW_F0 0           // made of, and the transform is two LDS round trips that nothing overlapped: +3.6-3.8 % frames/s on two boxes
+#endif                        // (profiles/r05_ab_results.txt block 1; GAP 10 / STRIDE 2: +2.2 %, 17 / 2: the same as 14 / 3).  0: round 4's
+#ifndef TW_RAW_GAP            // stand-alone transform in front of the k-loop.
+#define TW_RAW_GAP 14
+#endif
+#ifndef TW_RAW_STRIDE
+#define TW_RAW_STRIDE 3
 #endif
 #ifndef TW_PRE_BAR
-#define TW_PRE_BAR 0          // 1: a k-loop's first fragments (window row 0: written a period or more ago) are read in front of the
-#endif                        // barrier that opens its phase, not behind it
+#define TW_PRE_BAR 0          // a k-loop's first fragments (window row 0: written a period or more ago) are read in front of the barrier that
+#endif                        // opens its phase, not behind it.  Bit 0: the producers' (they wait at that barrier anyway); bit 1: the consumers',
+                              // who then pass the barrier WITHOUT waiting for the reads (they wrote nothing to LDS in that phase).  3 with a
+                              // waiting barrier measured 2.3 % slower (block 3 of the same file): the consumers arrive last, and later still.
 #ifndef TW_RAW_GAP
 #define TW_RAW_GAP 10
 #endif
@@ -365,11 +373,8 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int f = 0; f < PFF; ++f) {
-#if TW_PRE_BAR
-            bq[f] = pre[f];
-#else
-            bq[f] = read_f(f);
-#endif
+            if constexpr ((TW_PRE_BAR >> (BR ? 1 : 0)) & 1) bq[f] = pre[f];
+            else bq[f] = read_f(f);
         }
         __builtin_amdgcn_sched_barrier(0);
         static_for<NFRAG>([&](auto fc) __attribute__((always_inline)) {
@@ -458,7 +463,7 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
         const unsigned wrow = p < 15 ? (unsigned)TW_BROWB : 0u;      // (pair 15: every row and both units to the same spare place)
         const unsigned wj = p < 15 ? (unsigned)(TW_BROWB / 4) : 0u;
         half8 pre[PFF_A];
-#if TW_PRE_BAR
+#if TW_PRE_BAR & 1
         prefetch(std::false_type{}, 0, pre);
 #endif
         for (int it = 0; it < niter; ++it) {
@@ -585,7 +590,7 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
             e_own = load_a(it + 1 < nsteps ? it + 1 : nsteps - 1);
             TW_STAMP(3);
             a6 = a6 + 4 >= TW_AROWS ? a6 + 4 - TW_AROWS : a6 + 4;
-#if TW_PRE_BAR
+#if TW_PRE_BAR & 1
             prefetch(std::false_type{}, a6, pre);  // the next step's window row 0 is this step's row 4: transformed a period ago
 #endif
             group_barrier();
@@ -660,11 +665,13 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
             int bp = b10 - 4 - 2;                  // block it - 1 begins at (4 (it - 1)) mod 10; the window starts two rows above
             bp = bp < 0 ? bp + TW_BROWS : bp;
             half8 pre[TW_PFF_B];
-#if TW_PRE_BAR
-            prefetch(std::true_type{}, bp, pre);   // window row 0 = the third row of block it - 2: written three phases ago
-#endif
             TW_STAMP(1);
+#if TW_PRE_BAR & 2
+            prefetch(std::true_type{}, bp, pre);   // window row 0 = the third row of block it - 2: written three phases ago
+            asm volatile("s_barrier" ::: "memory");        // (kact above has waited for the step entry; nothing of this phase went to LDS)
+#else
             group_barrier();
+#endif
             TW_STAMP(2);
             // The raw rows of step it + 1 (landed: the producers waited for them in front of barrier 1) -> A-ring.  FIRST: the
             // producers' epilogue runs beside it at full speed (beside a k-loop it gets one instruction through per MFMA), and
