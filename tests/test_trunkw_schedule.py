@@ -62,6 +62,7 @@ def test_walking_the_lists_like_the_kernel(uva, h, w, tile, border, six, monkeyp
         assert bool(((steps[:, 0, 1] >> 25) & 1).any()) == bool(six)
     grid, stride, _ = steps.shape
     cover = [np.zeros((int(p[0]), int(p[1])), np.int32) for p in planes]
+    folded_planes = set()
     for b in range(grid):
         n = int(nsteps[b])
         assert 0 <= n <= stride - PAD
@@ -76,12 +77,27 @@ def test_walking_the_lists_like_the_kernel(uva, h, w, tile, border, six, monkeyp
                     assert a_off == (int(steps[b, n - 1, 0]) | ((int(steps[b, n - 1, 1]) & 0xff) << 32))
                 continue
             assert a_act == 1
-            pi = int(a[3])
+            fold = (int(a[1]) >> 27) & 1
+            pi2 = -1
+            if fold:
+                # a FOLDED step (round 5): the narrow last strips of two planes of one size in one walk; .w = the byte distance of
+                # the second plane's pixels - 2048, the first plane's index in the top byte of .z
+                pi = int(a[2]) >> 24
+                delta = int(np.uint32(a[3])) + 2048
+                assert delta % 128 == 0
+                match = [j for j in range(len(planes)) if int(planes[j, 3]) == int(planes[pi, 3]) + delta // 128]
+                assert len(match) == 1 and match[0] > pi
+                pi2 = match[0]
+                assert tuple(planes[pi2, :3]) == tuple(planes[pi, :3]), "folded planes have one size"
+                assert int(planes[pi, 1]) - (c_ := locate(a_off, planes, guard, pi)[1] + 1) <= 14
+                folded_planes.add((pi, pi2))
+            else:
+                pi = int(a[3])
             row, col = locate(a_off, planes, guard, pi)
             # first new input row = pixel (yA + 1, x0 - 2) = array position (yA + 2, x0 - 1)
             yA, x0 = row - 2, col + 1
             ph, pw, pitch = int(planes[pi, 0]), int(planes[pi, 1]), int(planes[pi, 2])
-            assert x0 % SW == 0 and 0 <= x0 < pw and int(a[2]) == pitch * 128
+            assert x0 % SW == 0 and 0 <= x0 < pw and (int(a[2]) & 0xffffff) == pitch * 128 and (fold or int(a[2]) >> 24 == 0)
             # the raw rows stay inside the 8-row guard around the plane arrays
             assert yA + 2 >= -8
             rmask, c_lo, c_hi = (int(a[1]) >> 8) & 15, (int(a[1]) >> 12) & 63, (int(a[1]) >> 18) & 63
@@ -89,8 +105,8 @@ def test_walking_the_lists_like_the_kernel(uva, h, w, tile, border, six, monkeyp
                 assert ((rmask >> r) & 1) == (0 <= yA + r < ph)
             assert c_lo == (1 if x0 == 0 else 0) and c_hi == min(32, pw - x0 + 1)
             six = (int(a[1]) >> 25) & 1          # only a workgroup's first step may ask for all six input rows
-            assert six == 0 or g == 0
-            dec.append((pi, yA, x0, bb, six))
+            assert six == 0 or (g == 0 and not fold)
+            dec.append((pi, yA, x0, bb, six, pi2))
         # ---- the kernel's walk: iteration `it`, phase X: A k-loop(it); phase Y: A epilogue(it) -> B-ring, raw rows of
         # step it + 1 -> A-ring, B k-loop(it - 1); B's stores of step it - 1 follow in iteration it + 1
         aring = [None] * AROWS          # (plane, x0, input row)
@@ -98,7 +114,7 @@ def test_walking_the_lists_like_the_kernel(uva, h, w, tile, border, six, monkeyp
         a6 = b10 = 0
 
         def put_rows(g, pos0):
-            pi, yA, x0, _, _ = dec[g]
+            pi, yA, x0, _, _, _ = dec[g]
             for wv in range(4):
                 aring[(pos0 + wv) % AROWS] = (pi, x0, yA + 1 + wv)
         if n:
@@ -107,7 +123,7 @@ def test_walking_the_lists_like_the_kernel(uva, h, w, tile, border, six, monkeyp
                 aring[0], aring[1] = (dec[0][0], dec[0][2], dec[0][1] - 1), (dec[0][0], dec[0][2], dec[0][1])
         for it in range(n + 1):
             if it < n:
-                pi, yA, x0, _, _ = dec[it]
+                pi, yA, x0, _, _, _ = dec[it]
                 ph = int(planes[pi, 0])
                 rows6 = [aring[(a6 + r) % AROWS] for r in range(6)]
                 for nn in range(4):
@@ -118,12 +134,17 @@ def test_walking_the_lists_like_the_kernel(uva, h, w, tile, border, six, monkeyp
                 if it + 1 < n:
                     put_rows(it + 1, (a6 + 4 + 2) % AROWS)
             if 1 <= it <= n:
-                pi, yA, x0, bb, _ = dec[it - 1]
+                pi, yA, x0, bb, _, pi2 = dec[it - 1]
                 if (int(bb[1]) >> 24) & 1:
                     ph, pw = int(planes[pi, 0]), int(planes[pi, 1])
                     b_off = int(bb[0]) | ((int(bb[1]) & 0xff) << 32)
                     vy, vx, v0 = (int(bb[1]) >> 8) & 7, (int(bb[1]) >> 11) & 63, (int(bb[1]) >> 17) & 7
-                    assert int(bb[3]) == pi and int(bb[2]) == int(planes[pi, 2]) * 128
+                    assert ((int(bb[1]) >> 25) & 1) == (1 if pi2 >= 0 else 0)
+                    if pi2 >= 0:
+                        assert int(np.uint32(bb[3])) + 2048 == (int(planes[pi2, 3]) - int(planes[pi, 3])) * 128 and vx <= 14
+                    else:
+                        assert int(bb[3]) == pi
+                    assert (int(bb[2]) & 0xffffff) == int(planes[pi, 2]) * 128 and int(bb[2]) >> 24 == (pi if pi2 >= 0 else 0)
                     row, col = locate(b_off, planes, guard, pi)
                     yo = row - 1
                     assert col - 1 == x0 and yo == yA - 1 and 0 <= v0 < vy <= 4 and vx == min(SW, pw - x0)
@@ -135,25 +156,45 @@ def test_walking_the_lists_like_the_kernel(uva, h, w, tile, border, six, monkeyp
                             e = win[nn + d]
                             assert e is not None and e[:3] == (pi, x0, yo + nn - 1 + d) and e[3], (b, it, nn, d, e)
                     cover[pi][yo + v0:yo + vy, x0:x0 + vx] += 1
+                    if pi2 >= 0:                         # pairs 8..15 of the same step: the same rows and columns of the second plane
+                        cover[pi2][yo + v0:yo + vy, x0:x0 + vx] += 1
             a6 = (a6 + 4) % AROWS
             b10 = (b10 + 4) % BROWS
     for c in cover:
         assert c.min() == 1 and c.max() == 1
+    if (h, w, tile, border) == (1080, 1920, 960, 10):
+        # the reference tiling at 1080p: planes 970 x 970 (x 2) and 130 x 970 (x 2), last strips of 10 columns: both pairs fold
+        assert folded_planes == {(0, 1), (2, 3)}
     # balance: the longest list is within a few steps of the mean over the workgroups that have work
     busy = int((nsteps > 0).sum())
     assert int(nsteps.max()) <= -(-int(nsteps.sum()) // busy) + 4
 
 
+def test_folded_last_strips_save_their_steps(uva, monkeypatch):
+    """970 columns are 32 strips and a third of one: with the two planes of a size sharing ONE walk of their last strips the
+    reference tiling at 1080p needs 1.5 % fewer steps; UVA_TW_FOLD=0 is round 4's schedule"""
+    monkeypatch.delenv("UVA_TW_SIX", raising=False)
+    monkeypatch.setenv("UVA_TW_FOLD", "0")
+    _, n0, _, _ = schedule(uva, 1080, 1920, 960, 10)
+    monkeypatch.delenv("UVA_TW_FOLD")
+    steps, n1, _, _ = schedule(uva, 1080, 1920, 960, 10)
+    assert int(n0.sum()) == 18597 and int(n0.max()) == 73
+    assert int(n0.sum()) - int(n1.sum()) >= 270 and int(n1.max()) <= 72
+    assert ((steps[:, :, 1] >> 27) & 1).sum() >= 270
+
+
 def test_six_row_starts_only_where_they_shorten_the_longest_list(uva, monkeypatch):
     monkeypatch.delenv("UVA_TW_SIX", raising=False)
+    monkeypatch.setenv("UVA_TW_FOLD", "0")
     steps, nsteps, planes, guard = schedule(uva, 1080, 1920, 960, 10)        # reference tiling: 73 steps either way
     assert int(nsteps.max()) == 73 and not ((steps[:, 0, 1] >> 25) & 1).any()
     steps, nsteps, planes, guard = schedule(uva, 1080, 1920, 0, 0)           # whole frame: 69 -> 68
     assert int(nsteps.max()) == 68 and ((steps[:, 0, 1] >> 25) & 1).any()
 
 
-def test_consecutive_ranges_share_an_xcd(uva):
+def test_consecutive_ranges_share_an_xcd(uva, monkeypatch):
     """block b runs on XCD b % 8: the k-th contiguous range of the sequence goes to block (k % 32) * 8 + k // 32"""
+    monkeypatch.setenv("UVA_TW_FOLD", "0")           # (folded entries carry no plane index: the placement rule is the same)
     steps, nsteps, planes, guard = schedule(uva, 1080, 1920, 960, 10)
     keys = []
     for b in range(0, 256, 8):

@@ -540,7 +540,32 @@ int build_trunkw_schedule(const std::vector<PlaneDesc>& planes, int grid, size_t
     const char* const sx = std::getenv("UVA_TW_SIX");
     const int six_mode = sx ? (std::atoi(sx) != 0 ? 1 : 0) : -1;
     const bool top_ok = false;
-    struct Seg { int plane, x0, r0, rows, k; bool full, zero; };
+    // FOLDED last strips (round 5).  A strip costs its 16 MFMA pair columns whatever its width, and 970 columns (the reference
+    // tiling's planes at 1080p) are 32 strips and a THIRD of one: 2 % of a launch's steps compute nothing.  Where two planes have
+    // the same size and a last strip of at most 14 columns (7 consumer pairs, which need the producers' pairs 0..7), ONE strip
+    // walk does both: lanes with pair index 0..7 work on the first plane, 8..15 on the second -- everything in between (rings,
+    // transforms, k-loops) is pair-wise and does not care; what differs is where the raw rows come from and where the results
+    // go: the second plane's addresses = the first's + a constant (entry .w = that constant - 2048, flags a.y bit 27 / b.y
+    // bit 25; csrc/uva_wino.hip.h).  UVA_TW_FOLD=0: off.
+    const char* const sf = std::getenv("UVA_TW_FOLD");
+    const bool fold_ok = !sf || std::atoi(sf) != 0;
+    std::vector<int> fold_partner(planes.size(), -1);
+    std::vector<char> folded_away(planes.size(), 0);
+    auto last_x0 = [](const PlaneDesc& p) { return ((p.w + TW_SW - 1) / TW_SW - 1) * TW_SW; };
+    if (fold_ok)
+        for (size_t i = 0; i < planes.size(); ++i) {
+            if (fold_partner[i] >= 0 || folded_away[i] || planes[i].w - last_x0(planes[i]) > 14) continue;
+            for (size_t j = i + 1; j < planes.size(); ++j) {
+                if (fold_partner[j] >= 0 || folded_away[j]) continue;
+                const long long delta = ((long long)planes[j].act_off - (long long)planes[i].act_off) * PIXB;
+                if (planes[j].h == planes[i].h && planes[j].w == planes[i].w && planes[j].pitch == planes[i].pitch && delta > 2048 && delta < (1ll << 31)) {
+                    fold_partner[i] = (int)j;
+                    folded_away[j] = 1;
+                    break;
+                }
+            }
+        }
+    struct Seg { int plane, x0, r0, rows, k; bool full, zero; int fold; };
     long long total = 0;
     for (const auto& p : planes) total += (long long)((p.w + TW_SW - 1) / TW_SW) * ((p.h + 3) / 4 + 1);     // (an upper bound: full segments need less)
     auto pack = [&](bool six_ok, std::vector<std::vector<Seg>>& per_wg) {
@@ -552,13 +577,16 @@ int build_trunkw_schedule(const std::vector<PlaneDesc>& planes, int grid, size_t
             for (size_t pi = 0; pi < planes.size(); ++pi) {
                 const PlaneDesc& p = planes[pi];
                 for (int x0 = 0; x0 < p.w; x0 += TW_SW) {
+                    const bool last = x0 + TW_SW >= p.w;
+                    if (last && folded_away[pi]) continue;          // done by its partner's last strip
+                    const int fold = last ? fold_partner[pi] : -1;
                     int y = 0;
                     while (y < p.h) {
                         const bool zero = top_ok && y == 0;
-                        const bool full = zero || (six_ok && per_wg.back().empty());
+                        const bool full = zero || (six_ok && per_wg.back().empty() && fold < 0);     // (the prologue's six-row fetch knows one plane)
                         const int need = full ? (p.h - y + 2 + 3) / 4 : (p.h - y + 3) / 4 + 1;
                         if (need <= cap) {
-                            per_wg.back().push_back({(int)pi, x0, y, p.h - y, need, full, zero});
+                            per_wg.back().push_back({(int)pi, x0, y, p.h - y, need, full, zero, fold});
                             cap -= need;
                             y = p.h;
                         } else if (cap < 3) {             // a segment of fewer than 3 steps is mostly pipeline fill
@@ -566,7 +594,7 @@ int build_trunkw_schedule(const std::vector<PlaneDesc>& planes, int grid, size_t
                             continue;
                         } else {
                             const int rows = full ? 4 * cap - 2 : 4 * (cap - 1);
-                            per_wg.back().push_back({(int)pi, x0, y, rows, cap, full, zero});
+                            per_wg.back().push_back({(int)pi, x0, y, rows, cap, full, zero, fold});
                             y += rows;
                             cap = 0;
                         }
@@ -619,9 +647,14 @@ int build_trunkw_schedule(const std::vector<PlaneDesc>& planes, int grid, size_t
                 for (int r = 0; r < 4; ++r)
                     if (yA + r >= 0 && yA + r < p.h) rmask |= 1u << r;
                 const unsigned c_lo = sg.x0 == 0 ? 1 : 0, c_hi = (unsigned)std::min(32, p.w - sg.x0 + 1);
+                // a folded step: the second plane's pixels lie fold_add + 2048 bytes behind the first's
+                const unsigned fold_add = sg.fold >= 0 ? (unsigned)(((long long)planes[sg.fold].act_off - (long long)p.act_off) * PIXB - 2048) : 0u;
                 out[g].a = make_uint4((unsigned)ao, (unsigned)(ao >> 32) | (rmask << 8) | (c_lo << 12) | (c_hi << 18) | (1u << 24) |
-                                                    ((sg.full && !sg.zero && j == 0) ? 1u << 25 : 0u) | ((sg.zero && j == 0) ? 1u << 26 : 0u),
-                                      (unsigned)(p.pitch * PIXB), (unsigned)sg.plane);
+                                                    ((sg.full && !sg.zero && j == 0) ? 1u << 25 : 0u) | ((sg.zero && j == 0) ? 1u << 26 : 0u) |
+                                                    (sg.fold >= 0 ? 1u << 27 : 0u),
+                                      (unsigned)(p.pitch * PIXB) | (sg.fold >= 0 ? (unsigned)sg.plane << 24 : 0u),   // (folded: .w is taken, the
+                                      sg.fold >= 0 ? fold_add : (unsigned)sg.plane);                                // plane index rides in .z's top byte)
+                if ((unsigned)(p.pitch * PIXB) >> 24) return fail("plane too wide for the step encoding");
                 // the consumer step stores rows yo + [v0, v1) of its four (yo = yA - 1): those inside the segment
                 const int yo = yA - 1;
                 const int v0 = std::max(0, sg.r0 - yo), v1 = std::min(4, sg.r0 + sg.rows - yo);
@@ -630,8 +663,10 @@ int build_trunkw_schedule(const std::vector<PlaneDesc>& planes, int grid, size_t
                                          ((long long)p.act_off + (long long)(yo + 1) * p.pitch + (sg.x0 + 1)) * PIXB;
                     if (bo < 0 || (bo >> 40)) return fail("activation buffer too large for the step encoding");
                     const unsigned vx = (unsigned)std::min(TW_SW, p.w - sg.x0);
-                    out[g].b = make_uint4((unsigned)bo, (unsigned)(bo >> 32) | ((unsigned)v1 << 8) | (vx << 11) | ((unsigned)v0 << 17) | (1u << 24),
-                                          (unsigned)(p.pitch * PIXB), (unsigned)sg.plane);
+                    out[g].b = make_uint4((unsigned)bo, (unsigned)(bo >> 32) | ((unsigned)v1 << 8) | (vx << 11) | ((unsigned)v0 << 17) | (1u << 24) |
+                                                        (sg.fold >= 0 ? 1u << 25 : 0u),
+                                          (unsigned)(p.pitch * PIXB) | (sg.fold >= 0 ? (unsigned)sg.plane << 24 : 0u),
+                                          sg.fold >= 0 ? fold_add : (unsigned)sg.plane);
                 }
             }
         }
@@ -2981,6 +3016,29 @@ int uva_net_debug_trunk_stamps(uva_net* n, unsigned long long* out, int max_tile
         (void)hipFree(d);
         if (tiles) *tiles = ws->max_rows10 + S10_DRAIN;
         return rc7 ? (rc7 == 2 ? fail("frame too large for sub10_kernel") : 1) : 0;
+    }
+    if (ablate == 9 || ablate == 10) {
+        // sub5_kernel, part 0 / part 1 (the 1x net as two launches of five layers): out[(step*12 + wave)*4 + {0 step start, 1 MFMAs
+        // done (front wave), 2 at the barrier}] of workgroup 0; *tiles = steps; kernel_ms = both launches
+        if (n->last.f32 || !n->last.dst || ws->planes.size() != 1) { (void)hipFree(d); return fail("sub5 stamps need a previous whole-frame uva_net_process_u8 call"); }
+        int rc9 = launch_sub5(n, ws, n->last.src, n->last.src_stride, n->last.dst, n->last.dst_stride);
+        if (rc9 == 0 && (size_t)(ws->max_rows5 + 16) * 4 * 12 > (size_t)max_tiles * 8) { (void)hipFree(d); return fail("max_tiles too small"); }
+        HIP_TRY(hipEventRecord(e0, n->stream));
+        for (int r = 0; r < 50 && !rc9; ++r) rc9 = launch_sub5(n, ws, n->last.src, n->last.src_stride, n->last.dst, n->last.dst_stride);
+        HIP_TRY(hipEventRecord(e1, n->stream));
+        if (!rc9) rc9 = launch_sub5(n, ws, n->last.src, n->last.src_stride, n->last.dst, n->last.dst_stride, d, ablate - 9);
+        if (!rc9) {
+            HIP_TRY(hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, n->stream));
+            HIP_TRY(hipStreamSynchronize(n->stream));
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+            if (kernel_ms) *kernel_ms = ms / 50;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        (void)hipFree(d);
+        if (tiles) *tiles = ws->max_rows5 + 14;
+        return rc9 ? (rc9 == 2 ? fail("frame too large for sub5_kernel") : 1) : 0;
     }
     if (ablate == 6) {
         // pair24_kernel (two 24-feature trunk layers): out[8*it + {0 top, 1 tile landed, 2 stage A done, 3 intermediate

@@ -41,6 +41,9 @@
 #ifndef UVA_SW_DBG
 #define UVA_SW_DBG 0
 #endif
+#ifndef UVA_SW_DBG_X
+#define UVA_SW_DBG_X 0     // CEILING EXPERIMENT (wrong results), with UVA_RA_DBG=1: g_conv3_sw<6,..> fetches the channels behind the first 64
+#endif                     // (x1..x4 of a dense block) from ONE fixed array row, i.e. from L2: together "x1..x4 never cross HBM"
 #ifndef UVA_RA_DBG
 #define UVA_RA_DBG 0       // timing experiments only (results are wrong): 1 no HBM stores, 2 no epilogue, 4 no x DMA, 8 no hand-over
 #endif
@@ -160,6 +163,16 @@ __global__ __launch_bounds__(256, 1) void g_conv3_sw(GSwArgs a)
         const int ayo = min(y0 + rr, ph + 1), ay = UP ? (ayo + 1) >> 1 : ayo;
         const char* const src = (const char*)(pin + (size_t)ay * in_pitch + (size_t)(UP ? c0 >> 1 : c0) * a.in_stride);
         const unsigned dst = ring_lds + (unsigned)(rr % SW_SLOTS) * ROWB + wave * 1024;
+        if constexpr (UVA_SW_DBG_X != 0 && KC == 6) {
+            const char* const src2 = (const char*)(pin + (size_t)1 * in_pitch + (size_t)c0 * a.in_stride);      // row 1 whatever the block
+#pragma unroll
+            for (int k = 0; k < NPW; ++k)
+                if (wave + 4 * k < NP) {
+                    const int idx = min((wave + 4 * k) * 64 + lane, KC * RC * 4 - 1);
+                    glds16((idx / (RC * 4) >= 2 ? src2 : src) + voff[k], dst + k * 4096);
+                }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < NPW; ++k)
             if (wave + 4 * k < NP) glds16_s(src, voff[k], dst + k * 4096);

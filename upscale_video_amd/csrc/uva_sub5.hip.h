@@ -12,8 +12,11 @@
 //
 // Organisation: one 12-wave workgroup per CU runs TWO pipelines on two neighbouring 64-column strips (54 valid columns each):
 // waves 0-3 / 4-7 are the four 24->24 layers of pipeline 0 / 1 (a wave IS a layer, its 56 weight registers never move), waves 8, 9
-// the pipelines' LIGHT FRONT wave (part 0: u8 rows in + conv 3->24; part 1: rows of `mid` in), waves 10, 11 their LIGHT BACK
-// wave (part 0: layer 4's rows out to `mid`; part 1: conv 24->3 + residual -> u8 out).  Waves w, w+4, w+8 share a SIMD: two
+// the pipelines' LIGHT FRONT wave, waves 10, 11 their LIGHT BACK wave.  The launch's light LAYER (part 0: conv 3->24, part 1:
+// conv 24->3 + residual -> u8) is split between the two by fragments -- front: fragments 0, 1; back: 2, 3 -- and each also
+// moves rows: part 0's front wave brings the u8 rows in, its back wave takes layer 4's rows out to `mid`; part 1's front wave
+// brings the rows of `mid` in.  (First version: the whole light layer on one wave, the other one only moving rows -- the
+// light waves set the row period, as in sub10_kernel, profiles/r05_ab_results.txt.)  Waves w, w+4, w+8 share a SIMD: two
 // trunk layers and one light wave on every SIMD, as in sub10_kernel.  Rows stream top to bottom through 4-row rings in LDS
 // (one ring per layer output, 48 B per pixel, sub10_kernel's layout and conflict-free read recipe), one workgroup barrier per
 // row; layer s runs two rows behind layer s-1.  Segments start 5 rows early and end 5 rows late (host: build_sub5_rows).
@@ -87,11 +90,13 @@ __device__ __forceinline__ void store_px(const f32x4 x0, const f32x4 x1, const P
 __device__ __forceinline__ int pix_of(int p) { return p < 4 ? 2 * p : p >= 12 ? 2 * (p - 8) : 2 * (p - 4) + 1; }
 __host__ __device__ constexpr int dy_of(int ks, int o) { return ((SUB16_OCTET[ks][o] > 26 ? 26 : SUB16_OCTET[ks][o]) / 3) / 3; }
 
-// ---- part 0, light front wave: u8 rows in, conv 3 -> 24 (+ bias, PReLU) on all four fragments ------------------------------
+// ---- part 0, the two light waves of a pipeline: conv 3 -> 24 (+ bias, PReLU) on fragments [F0, F1);
+//      FRONT (F0 == 0): also the u8 rows in;  BACK: also layer 4's finished rows (ring 4) out to `mid` ---------------------------------
+template <int F0, int F1, bool FRONT>
 __device__ __forceinline__ void head(const Sub5Args& a, const Lds L, const int wave, const int lane, const int xoff, const int nrows,
                                      const int nsteps)
 {
-    constexpr int NF = 4;
+    constexpr int NF = F1 - F0;
     const int p = lane & 15, o = lane >> 4;
     [[maybe_unused]] const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && lane == 0;
     char* const uring = L.pipe + NRINGS * RINGB;
@@ -113,8 +118,8 @@ __device__ __forceinline__ void head(const Sub5Args& a, const Lds L, const int w
     const f32x2 hb1 = *(const f32x2*)(L.prm + 16 + 2 * o);
     const float norm = (float)(1 / 255.0);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    // the u8 row of descriptor r: ring column `lane` (and, lanes 0 and 1, ring column 64 + lane), packed B | G<<8 | R<<16; outside the
-    // plane: 0.  Fetched one step before it is needed: HBM latency has a whole step to pass.
+    // FRONT: the u8 row of descriptor r: ring column `lane` (and, lanes 0 and 1, ring column 64 + lane), packed B | G<<8 | R<<16;
+    // outside the plane: 0.  Fetched one step before it is needed: HBM latency has a whole step to pass.
     auto fetch_row = [&](int r, unsigned (&px)[2]) {
         px[0] = px[1] = 0;
         if (r < nrows) {
@@ -132,65 +137,86 @@ __device__ __forceinline__ void head(const Sub5Args& a, const Lds L, const int w
             }
         }
     };
-    auto step = [&](const int t, const unsigned (&upx)[2], unsigned (&upx_next)[2]) {
-        S5_STAMP(0);
-        fetch_row(t + 1, upx_next);
-        const int d = t - 2;
-        if (d >= 0 && d < nrows) {
-            const int2 e = L.rows[d];
-            const int ye = __builtin_amdgcn_readfirstlane(e.x), x0c = __builtin_amdgcn_readfirstlane(e.y) + xoff;
-            const int y = ye >> 1;
-            const bool row_in = y >= 0 && y < a.h;
-            unsigned rb[3];
+    // BACK: layer 4's row of descriptor d -> `mid`, the strip's 54 valid columns, 16 bytes per lane and unit
+    auto store_row = [&](const int d) {
+        constexpr int UNITS = S5_VALID * 3;
+        if (d < 0 || d >= nrows) return;
+        const int2 e = L.rows[d];
+        const int ye = __builtin_amdgcn_readfirstlane(e.x), x0c = __builtin_amdgcn_readfirstlane(e.y) + xoff;
+        const int y = ye >> 1;
+        if (!(ye & 1) || y < 0 || y >= a.h) return;
+        const char* const src = L.pipe + 4 * RINGB + (d & 3) * ROWB + (1 + S5_NL) * PIXB;
+        char* const dst = a.mid + ((size_t)y * a.w + (x0c + S5_NL)) * PIXB;
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy) rb[dy] = (unsigned)(uring - L.pipe) + ((d + dy - 1) & 3) * UROWB;
-            f32x4 acc[NF][2];
+        for (int k = 0; k < (UNITS + 63) / 64; ++k) {
+            const int u = lane + 64 * k;
+            if (u < UNITS && x0c + S5_NL + u / 3 < a.w) *(uint4*)(dst + u * 16) = *(const uint4*)(src + u * 16);
+        }
+    };
+    auto conv_row = [&](const int d) {
+        if (d < 0 || d >= nrows) return;
+        const int2 e = L.rows[d];
+        const int ye = __builtin_amdgcn_readfirstlane(e.x), x0c = __builtin_amdgcn_readfirstlane(e.y) + xoff;
+        const int y = ye >> 1;
+        const bool row_in = y >= 0 && y < a.h;
+        unsigned rb[3];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) rb[dy] = (unsigned)(uring - L.pipe) + ((d + dy - 1) & 3) * UROWB;
+        f32x4 acc[NF][2];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            acc[f][0] = zero4; acc[f][1] = zero4;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int ra = sel_lo[ks] >> 16, rh = sel_hi[ks] >> 16;
+                const uint2 lo = *(const uint2*)(L.pipe + (ra == 0 ? rb[0] : ra == 1 ? rb[1] : rb[2]) + (sel_lo[ks] & 0xffff) + (F0 + f) * 16 * 8);
+                const uint2 hi = *(const uint2*)(L.pipe + (rh == 0 ? rb[0] : rh == 1 ? rb[1] : rb[2]) + (sel_hi[ks] & 0xffff) + (F0 + f) * 16 * 8);
+                const half8 b = __builtin_bit_cast(half8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                acc[f][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wgt[ks][0], b, acc[f][0], 0, 0, 0);
+                acc[f][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wgt[ks][1], b, acc[f][1], 0, 0, 0);
+            }
+        }
+        char* const px0 = L.pipe + (d & 3) * ROWB + (p + 1 + 16 * F0) * PIXB + 8 * o;
+        char* const px1 = L.pipe + (d & 3) * ROWB + (p + 1 + 16 * F0) * PIXB + 32 + 4 * o;
+        auto epi = [&](auto masked) {
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
-                acc[f][0] = zero4; acc[f][1] = zero4;
+                const int X = x0c + 16 * (F0 + f) + p;
+                const f32x4 x0 = __builtin_elementwise_fma(acc[f][0], f32x4{norm, norm, norm, norm}, hb0);
+                const f32x2 x1h = __builtin_elementwise_fma(f32x2{acc[f][1][0], acc[f][1][1]}, f32x2{norm, norm}, hb1);
+                const f32x4 x1 = {x1h[0], x1h[1], 0.f, 0.f};
+                store_px<decltype(masked)::value>(x0, x1, q, px0 + f * 16 * PIXB, px1 + f * 16 * PIXB, row_in && X >= 0 && X < a.w);
+            }
+        };
+        if (row_in && x0c >= 0 && x0c + S5_WC <= a.w) epi(std::false_type{});
+        else epi(std::true_type{});
+    };
+    auto step = [&](const int t, const unsigned (&upx)[2], unsigned (&upx_next)[2]) {
+        S5_STAMP(0);
+        if constexpr (FRONT) fetch_row(t + 1, upx_next);
+        conv_row(t - 2);
+        S5_STAMP(1);
+        if constexpr (FRONT) {
+            if (t < nrows) {
+                // the fetched u8 pixels -> [B, G, R, 0] fp16 in ring row t (outside the plane: zeros, already in upx)
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const int ra = sel_lo[ks] >> 16, rh = sel_hi[ks] >> 16;
-                    const uint2 lo = *(const uint2*)(L.pipe + (ra == 0 ? rb[0] : ra == 1 ? rb[1] : rb[2]) + (sel_lo[ks] & 0xffff) + f * 16 * 8);
-                    const uint2 hi = *(const uint2*)(L.pipe + (rh == 0 ? rb[0] : rh == 1 ? rb[1] : rb[2]) + (sel_hi[ks] & 0xffff) + f * 16 * 8);
-                    const half8 b = __builtin_bit_cast(half8, make_uint4(lo.x, lo.y, hi.x, hi.y));
-                    acc[f][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wgt[ks][0], b, acc[f][0], 0, 0, 0);
-                    acc[f][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wgt[ks][1], b, acc[f][1], 0, 0, 0);
+                for (int k = 0; k < 2; ++k) {
+                    const int qq = lane + 64 * k;
+                    if (qq < ROWPX) {
+                        const half2v bg = {(_Float16)(float)(upx[k] & 0xff), (_Float16)(float)((upx[k] >> 8) & 0xff)};
+                        const half2v r0 = {(_Float16)(float)((upx[k] >> 16) & 0xff), (_Float16)0.f};
+                        *(uint2*)(uring + (t & 3) * UROWB + qq * 8) = make_uint2(__builtin_bit_cast(unsigned, bg), __builtin_bit_cast(unsigned, r0));
+                    }
                 }
             }
-            S5_STAMP(1);
-            char* const px0 = L.pipe + (d & 3) * ROWB + (p + 1) * PIXB + 8 * o;
-            char* const px1 = L.pipe + (d & 3) * ROWB + (p + 1) * PIXB + 32 + 4 * o;
-            auto epi = [&](auto masked) {
-#pragma unroll
-                for (int f = 0; f < NF; ++f) {
-                    const int X = x0c + 16 * f + p;
-                    const f32x4 x0 = __builtin_elementwise_fma(acc[f][0], f32x4{norm, norm, norm, norm}, hb0);
-                    const f32x2 x1h = __builtin_elementwise_fma(f32x2{acc[f][1][0], acc[f][1][1]}, f32x2{norm, norm}, hb1);
-                    const f32x4 x1 = {x1h[0], x1h[1], 0.f, 0.f};
-                    store_px<decltype(masked)::value>(x0, x1, q, px0 + f * 16 * PIXB, px1 + f * 16 * PIXB, row_in && X >= 0 && X < a.w);
-                }
-            };
-            if (row_in && x0c >= 0 && x0c + S5_WC <= a.w) epi(std::false_type{});
-            else epi(std::true_type{});
-        }
-        if (t < nrows) {
-            // the fetched u8 pixels -> [B, G, R, 0] fp16 in ring row t (outside the plane: zeros, already in upx)
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int qq = lane + 64 * k;
-                if (qq < ROWPX) {
-                    const half2v bg = {(_Float16)(float)(upx[k] & 0xff), (_Float16)(float)((upx[k] >> 8) & 0xff)};
-                    const half2v r0 = {(_Float16)(float)((upx[k] >> 16) & 0xff), (_Float16)0.f};
-                    *(uint2*)(uring + (t & 3) * UROWB + qq * 8) = make_uint2(__builtin_bit_cast(unsigned, bg), __builtin_bit_cast(unsigned, r0));
-                }
-            }
+        } else {
+            store_row(t - (2 * 4 + 2 + 1));      // one step behind layer 4 (no row below is needed)
         }
         S5_STAMP(2);
         barrier();
     };
-    unsigned pxa[2], pxb[2];
-    fetch_row(0, pxa);
+    unsigned pxa[2] = {0, 0}, pxb[2] = {0, 0};
+    if constexpr (FRONT) fetch_row(0, pxa);
     for (int t = 0; t < nsteps; t += 2) {      // two steps per trip: the row fetched during one step is converted at the end of the next
         step(t, pxa, pxb);
         step(t + 1, pxb, pxa);
@@ -199,17 +225,16 @@ __device__ __forceinline__ void head(const Sub5Args& a, const Lds L, const int w
 
 // ---- one row of one 24-input layer, four fragments (sub10_kernel's sub10_row): LDS reads run seven k-steps ahead of their MFMAs,
 // epilogues follow one fragment behind.  TAIL: conv 24 -> 3 + input pixel -> u8 (the residual bytes come from HBM: r8[]) -------------
-template <bool TAIL, bool MASKED, int KS, int MB>
-__device__ __forceinline__ void row4(const char* __restrict__ rin, char* __restrict__ px0, char* __restrict__ px1, uint8_t* __restrict__ dst,
+template <bool TAIL, bool MASKED, int KS, int MB, int F0, int F1>
+__device__ __forceinline__ void rowf(const char* __restrict__ rin, char* __restrict__ px0, char* __restrict__ px1, uint8_t* __restrict__ dst,
                                      const unsigned (&adr)[KS], const half8 (&wgt)[KS][MB], const f32x4 (&binit)[2], const Prm& q,
                                      const unsigned (&r8)[4], const int x0c, const int w, const bool row_in, const bool emit, const int pix,
                                      const int o)
 {
-    constexpr int F1 = 4;
     const float norm = (float)(1 / 255.0);
     half8 bq[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) bq[ks] = *(const half8*)(rin + adr[ks]);
+    for (int ks = 0; ks < KS; ++ks) bq[ks] = *(const half8*)(rin + adr[ks] + F0 * 16 * PIXB);
     __builtin_amdgcn_sched_group_barrier(0x100, KS, 0);
     auto mma = [&](const int f, f32x4 (&acc)[MB]) {
 #pragma unroll
@@ -243,19 +268,28 @@ __device__ __forceinline__ void row4(const char* __restrict__ rin, char* __restr
         }
     };
     f32x4 a0[MB], a1[MB];
-    mma(0, a0);
-    mma(1, a1);
-    epi(0, a0);
-    mma(2, a0);
-    epi(1, a1);
-    mma(3, a1);
-    epi(2, a0);
-    epi(3, a1);
+    if constexpr (F1 - F0 == 4) {
+        mma(F0, a0);
+        mma(F0 + 1, a1);
+        epi(F0, a0);
+        mma(F0 + 2, a0);
+        epi(F0 + 1, a1);
+        mma(F0 + 3, a1);
+        epi(F0 + 2, a0);
+        epi(F0 + 3, a1);
+    } else {
+        static_assert(F1 - F0 == 2, "four fragments (a trunk layer) or two (half of the last layer)");
+        mma(F0, a0);
+        mma(F0 + 1, a1);
+        epi(F0, a0);
+        epi(F0 + 1, a1);
+    }
 }
 
 // ---- eight waves: conv 24 -> 24 (+ bias, PReLU), stage 1..4 of a pipeline: ring stage-1 -> ring stage;
 //      part 1's light back wave (TAIL): ring 4 -> u8 frame -----------------------------------------------------------------------------
-template <bool TAIL>
+//      TAIL waves take fragments [F0, F1) of the last layer; LOAD (part 1's front wave): also the rows of `mid` in -> ring 0 --------------
+template <bool TAIL, int F0, int F1, bool LOAD>
 __device__ __forceinline__ void body(const Sub5Args& a, const Lds L, const int wave, const int stage, const int li, const int lag,
                                      const int lane, const int xoff, const int nrows, const int nsteps)
 {
@@ -281,9 +315,41 @@ __device__ __forceinline__ void body(const Sub5Args& a, const Lds L, const int w
     const f32x4 binit[2] = {*(const f32x4*)(myprm + 4 * o), f32x4{myprm[16 + 2 * o], myprm[17 + 2 * o], 0.f, 0.f}};
     char* const out_ring = L.pipe + stage * RINGB;
 
+    // LOAD: row t of `mid` (all 66 ring columns; outside the plane: zeros) was requested a step ago and goes into ring 0 now; row
+    // t + 1 is requested behind it -- HBM latency has a whole step to pass
+    constexpr int LUNITS = ROWPX * 3, NK = LOAD ? (LUNITS + 63) / 64 : 1;
+    uint4 lv[NK];
+    [[maybe_unused]] auto fetch_mid = [&](int r) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) lv[k] = make_uint4(0, 0, 0, 0);
+        if (r < nrows) {
+            const int2 e = L.rows[r];
+            const int y = e.x >> 1, x0c = e.y + xoff;
+            if (y >= 0 && y < a.h) {
+                const char* const src = a.mid + ((size_t)y * a.w + (x0c - 1)) * PIXB;
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    const int u = lane + 64 * k, X = x0c - 1 + u / 3;
+                    if (u < LUNITS && X >= 0 && X < a.w) lv[k] = *(const uint4*)(src + (ptrdiff_t)u * 16);
+                }
+            }
+        }
+    };
+    if constexpr (LOAD) fetch_mid(0);
     int2 desc = make_int2(0, 0);        // the descriptor of the next step's row, fetched a step ahead
     for (int t = 0; t < nsteps; ++t) {
         S5_STAMP(0);
+        if constexpr (LOAD) {
+            if (t < nrows) {
+                char* const dst = L.pipe + (t & 3) * ROWB;
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    const int u = lane + 64 * k;
+                    if (u < LUNITS) *(uint4*)(dst + u * 16) = lv[k];
+                }
+            }
+            fetch_mid(t + 1);
+        }
         const int d = t - lag;
         if (d >= 0 && d < nrows) {
             const int ye = __builtin_amdgcn_readfirstlane(desc.x), x0c = __builtin_amdgcn_readfirstlane(desc.y) + xoff;
@@ -298,16 +364,16 @@ __device__ __forceinline__ void body(const Sub5Args& a, const Lds L, const int w
                 if ((ye & 1) && row_in && o == 0) {
                     const uint8_t* sp = a.src + (size_t)yy * a.src_stride + (size_t)(x0c + pix) * 3;
 #pragma unroll
-                    for (int f = 0; f < 4; ++f) {
+                    for (int f = F0; f < F1; ++f) {
                         const int X = x0c + 16 * f + pix;
                         if (X >= 0 && X < a.w) r8[f] = (unsigned)sp[f * 48] | ((unsigned)sp[f * 48 + 1] << 8) | ((unsigned)sp[f * 48 + 2] << 16);
                     }
                 }
             }
             if (!TAIL && row_in && x0c >= 0 && x0c + S5_WC <= a.w)
-                row4<TAIL, false, KS, MB>(L.pipe, px + 8 * o, px + 32 + 4 * o, dst, adr, wgt, binit, q, r8, x0c, a.w, row_in, (ye & 1) != 0, pix, o);
+                rowf<TAIL, false, KS, MB, F0, F1>(L.pipe, px + 8 * o, px + 32 + 4 * o, dst, adr, wgt, binit, q, r8, x0c, a.w, row_in, (ye & 1) != 0, pix, o);
             else
-                row4<TAIL, true, KS, MB>(L.pipe, px + 8 * o, px + 32 + 4 * o, dst, adr, wgt, binit, q, r8, x0c, a.w, row_in, (ye & 1) != 0, pix, o);
+                rowf<TAIL, true, KS, MB, F0, F1>(L.pipe, px + 8 * o, px + 32 + 4 * o, dst, adr, wgt, binit, q, r8, x0c, a.w, row_in, (ye & 1) != 0, pix, o);
             // next row: every address one ring row on, wrapping after the fourth (the increments are scalars: they depend on the
             // window row dy an octet comes from only)
             int inc[3];
@@ -323,80 +389,6 @@ __device__ __forceinline__ void body(const Sub5Args& a, const Lds L, const int w
         S5_STAMP(2);
         if (d + 1 >= 0 && d + 1 < nrows) desc = L.rows[d + 1];
         barrier();
-    }
-}
-
-// ---- part 0, light back wave: layer 4's finished rows (ring 4) -> `mid`, the strip's 54 valid columns, 16 bytes per lane ---------------
-__device__ __forceinline__ void store_mid(const Sub5Args& a, const Lds L, const int wave, const int lane, const int xoff, const int nrows,
-                                          const int nsteps)
-{
-    constexpr int LAG = 2 * 4 + 2 + 1;           // one step behind layer 4 (no row below is needed)
-    constexpr int UNITS = S5_VALID * 3;          // 16-byte units of a row's valid pixels
-    [[maybe_unused]] const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && lane == 0;
-    const char* const ring = L.pipe + 4 * RINGB;
-    for (int t = 0; t < nsteps; ++t) {
-        S5_STAMP(0);
-        const int d = t - LAG;
-        if (d >= 0 && d < nrows) {
-            const int2 e = L.rows[d];
-            const int ye = __builtin_amdgcn_readfirstlane(e.x), x0c = __builtin_amdgcn_readfirstlane(e.y) + xoff;
-            const int y = ye >> 1;
-            if ((ye & 1) && y >= 0 && y < a.h) {
-                const char* const src = ring + (d & 3) * ROWB + (1 + S5_NL) * PIXB;
-                char* const dst = a.mid + ((size_t)y * a.w + (x0c + S5_NL)) * PIXB;
-#pragma unroll
-                for (int k = 0; k < (UNITS + 63) / 64; ++k) {
-                    const int u = lane + 64 * k;
-                    if (u < UNITS && x0c + S5_NL + u / 3 < a.w) *(uint4*)(dst + u * 16) = *(const uint4*)(src + u * 16);
-                }
-            }
-        }
-        S5_STAMP(2);
-        barrier();
-    }
-}
-
-// ---- part 1, light front wave: rows of `mid` (all 66 ring columns; outside the plane: zeros) -> ring 0 ---------------------------------
-__device__ __forceinline__ void load_mid(const Sub5Args& a, const Lds L, const int wave, const int lane, const int xoff, const int nrows,
-                                         const int nsteps)
-{
-    constexpr int UNITS = ROWPX * 3, NK = (UNITS + 63) / 64;
-    [[maybe_unused]] const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && lane == 0;
-    auto fetch_row = [&](int r, uint4 (&v)[NK]) {
-#pragma unroll
-        for (int k = 0; k < NK; ++k) v[k] = make_uint4(0, 0, 0, 0);
-        if (r < nrows) {
-            const int2 e = L.rows[r];
-            const int y = e.x >> 1, x0c = e.y + xoff;
-            if (y >= 0 && y < a.h) {
-                const char* const src = a.mid + ((size_t)y * a.w + (x0c - 1)) * PIXB;
-#pragma unroll
-                for (int k = 0; k < NK; ++k) {
-                    const int u = lane + 64 * k, X = x0c - 1 + u / 3;
-                    if (u < UNITS && X >= 0 && X < a.w) v[k] = *(const uint4*)(src + (ptrdiff_t)u * 16);
-                }
-            }
-        }
-    };
-    auto step = [&](const int t, const uint4 (&v)[NK], uint4 (&v_next)[NK]) {
-        S5_STAMP(0);
-        fetch_row(t + 1, v_next);
-        if (t < nrows) {
-            char* const dst = L.pipe + (t & 3) * ROWB;
-#pragma unroll
-            for (int k = 0; k < NK; ++k) {
-                const int u = lane + 64 * k;
-                if (u < UNITS) *(uint4*)(dst + u * 16) = v[k];
-            }
-        }
-        S5_STAMP(2);
-        barrier();
-    };
-    uint4 va[NK], vb[NK];
-    fetch_row(0, va);
-    for (int t = 0; t < nsteps; t += 2) {
-        step(t, va, vb);
-        step(t + 1, vb, va);
     }
 }
 
@@ -437,14 +429,14 @@ __global__ __launch_bounds__(64 * s5::NW, 1) void sub5_kernel(Sub5Args a)
     const int xoff = pipe * S5_VALID;
     if (wave < 8) {
         const int stage = (wave & 3) + 1;
-        if (PART == 0) body<false>(a, L, wave, stage, stage, 2 * stage + 2, lane, xoff, nrows, nsteps);      // layer `stage`, two rows behind the one above
-        else body<false>(a, L, wave, stage, stage - 1, 2 * stage, lane, xoff, nrows, nsteps);                // layer 4 + stage (ring 0 is loaded, not computed)
+        if (PART == 0) body<false, 0, 4, false>(a, L, wave, stage, stage, 2 * stage + 2, lane, xoff, nrows, nsteps);   // layer `stage`, two rows behind the one above
+        else body<false, 0, 4, false>(a, L, wave, stage, stage - 1, 2 * stage, lane, xoff, nrows, nsteps);              // layer 4 + stage (ring 0 is loaded, not computed)
     } else if (wave < 10) {
-        if (PART == 0) head(a, L, wave, lane, xoff, nrows, nsteps);
-        else load_mid(a, L, wave, lane, xoff, nrows, nsteps);
+        if (PART == 0) head<0, 2, true>(a, L, wave, lane, xoff, nrows, nsteps);
+        else body<true, 0, 2, true>(a, L, wave, S5_NL, S5_NL - 1, 2 * S5_NL, lane, xoff, nrows, nsteps);               // conv 24 -> 3 reads ring 4
     } else {
-        if (PART == 0) store_mid(a, L, wave, lane, xoff, nrows, nsteps);
-        else body<true>(a, L, wave, S5_NL, S5_NL - 1, 2 * S5_NL, lane, xoff, nrows, nsteps);                 // conv 24 -> 3 reads ring 4
+        if (PART == 0) head<2, 4, false>(a, L, wave, lane, xoff, nrows, nsteps);
+        else body<true, 2, 4, false>(a, L, wave, S5_NL, S5_NL - 1, 2 * S5_NL, lane, xoff, nrows, nsteps);
     }
 }
 

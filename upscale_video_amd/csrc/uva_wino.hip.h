@@ -73,6 +73,13 @@ static_assert(TW_RAW % 128 == 0 && TW_RAWROWB % 128 == 0, "raw pixel records are
 //      active << 24 | (the workgroup's first step only) all six input rows are to be fetched << 25, z = row pitch in bytes
 //   b: x = byte offset (low 32) of output pixel (yA - 1, x0), y = offset bits 32..39 | v1 << 8 | valid columns << 11 |
 //      v0 << 17 (rows yA-1 + [v0, v1) are stored) | active << 24, z = row pitch in bytes
+//   FOLDED steps (a.y bit 27, b.y bit 25; host: build_trunkw_schedule): the last, narrow (<= 14 columns) strips of TWO planes of one
+//   size in one walk -- pairs 0..7 belong to the first plane, pairs 8..15 to the second, whose pixels lie a constant further on:
+//   .w = that constant - 2048 (raw column 16 + c of the step is the second plane's column c: 16 pixels back, one plane on), the
+//   first plane's index in the top byte of .z (the pitch is its low 24 bits in every entry).  Rings,
+//   transforms and k-loops are pair-wise and unchanged; the DMA source, the producers' column masks (pair & 7) and the consumers'
+//   store addresses are what a folded step does differently.  Pair 7's transformed values mix the two planes and are never used
+//   (a folded strip has at most 7 consumer pairs per plane).
 
 // LDS-DMA piece i of wave `wave`: piece c = 4i + wave covers units [64c, 64c + 64) of a raw slot; unit q is row
 // q / 272, record (q % 272) / 8, slot q % 8 -> (row << 13) | byte offset of that octet inside the source row
@@ -216,16 +223,21 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
     for (int i = 0; i < 3; ++i)
         dma_pc2[i] = tw_piece_const(2 * i, wave, lane) | (2 * i + 1 < 5 ? tw_piece_const(2 * i + 1, wave, lane) << 16 : 0u);
     auto issue_rows = [&](const uint4 e, int slot) __attribute__((always_inline)) {
-        const unsigned lo = __builtin_amdgcn_readfirstlane(e.x), hi = __builtin_amdgcn_readfirstlane(e.y) & 0xffu;
+        const unsigned ey = __builtin_amdgcn_readfirstlane(e.y);
+        const unsigned lo = __builtin_amdgcn_readfirstlane(e.x), hi = ey & 0xffu;
         const char* base = a.in_act + (((unsigned long long)hi << 32) | lo);
-        const int pitch = __builtin_amdgcn_readfirstlane(e.z);
+        const int pitch = __builtin_amdgcn_readfirstlane(e.z) & 0xffffff;
+        // a folded step's raw columns 16.. come from the second plane (uniform branch: one strip in thirty-three)
+        const unsigned fadd = ((ey >> 27) & 1u) ? (unsigned)__builtin_amdgcn_readfirstlane(e.w) : 0u;
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             if (4 * i + wave >= TW_RAW_PIECES) continue;
             const unsigned pc = (dma_pc2[i >> 1] >> (16 * (i & 1))) & 0xffffu;
             // (a 24-bit multiply-add: hipcc's v_mad_u64_u32 for the plain expression takes an UNDEFINED register as the high half of
             // its addend, which in the prologue was one a parameter load was still writing -- a wait in front of the first DMA)
-            glds16_s(base, __umul24(pc >> 13, (unsigned)pitch) + (pc & 0x1fffu), lds0 + TW_RAW + slot * TW_RAWSLOTB + (4 * i + wave) * 1024);
+            unsigned off = __umul24(pc >> 13, (unsigned)pitch) + (pc & 0x1fffu);
+            if (fadd) off += (pc & 0x1800u) ? fadd : 0u;
+            glds16_s(base, off, lds0 + TW_RAW + slot * TW_RAWSLOTB + (4 * i + wave) * 1024);
         }
     };
 
@@ -295,7 +307,7 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
         issue_rows(e_second, 1);
         if (six && wave < 2) {
             const unsigned lo = __builtin_amdgcn_readfirstlane(e_first.x), hi = __builtin_amdgcn_readfirstlane(e_first.y) & 0xffu;
-            const int pitch = __builtin_amdgcn_readfirstlane(e_first.z);
+            const int pitch = __builtin_amdgcn_readfirstlane(e_first.z) & 0xffffff;
             const char* base = a.in_act + (((unsigned long long)hi << 32) | lo) - (size_t)(2 - wave) * pitch;      // rows yA - 1, yA
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
@@ -472,7 +484,8 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
             // what the epilogue of step it needs: the masks of a step at its plane's edge
             const unsigned ey = __builtin_amdgcn_readfirstlane(e_own.y);
             const int rmask = (ey >> 8) & 15, c_lo = (ey >> 12) & 63, c_hi = (ey >> 18) & 63;
-            const bool in0 = 2 * p >= c_lo && 2 * p < c_hi, in1 = 2 * p + 1 >= c_lo && 2 * p + 1 < c_hi;
+            const int pm = ((ey >> 27) & 1u) ? (p & 7) : p;           // a folded step: each half's pairs count from its own plane's column
+            const bool in0 = 2 * pm >= c_lo && 2 * pm < c_hi, in1 = 2 * pm + 1 >= c_lo && 2 * pm + 1 < c_hi;
             const bool edge = rmask != 15 || c_lo != 0 || c_hi != 32;
             auto slice = [&](RowSt& st, auto edge_tag, auto nc, auto kc) __attribute__((always_inline)) {
                 constexpr int n = decltype(nc)::value, k = decltype(kc)::value;
@@ -611,10 +624,12 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
         auto make_slice = [&](const uint4 e) __attribute__((always_inline)) {
             const unsigned ey = __builtin_amdgcn_readfirstlane(e.y), lo = __builtin_amdgcn_readfirstlane(e.x);
             const size_t off = ((unsigned long long)(ey & 0xffu) << 32) | lo;
-            const int pitch = __builtin_amdgcn_readfirstlane(e.z);
+            const int pitch = __builtin_amdgcn_readfirstlane(e.z) & 0xffffff;
             const int vy = (ey >> 8) & 7, vx = (ey >> 11) & 63, v0 = (ey >> 17) & 7;
-            char* const obase = a.out_act + off + olane;
-            const bool colok = col < vx;
+            const bool fold = (ey >> 25) & 1u;                      // pairs 8..15 store into the second plane: 16 columns back, one plane on
+            const unsigned fadd = fold ? (unsigned)__builtin_amdgcn_readfirstlane(e.w) : 0u;
+            char* const obase = a.out_act + off + olane + ((fold && p >= 8) ? fadd : 0u);
+            const bool colok = (fold ? (col & 15) : col) < vx;
             return [&, obase, pitch, vy, v0, colok](RowSt& st, auto nc, auto kc) __attribute__((always_inline)) {
                 constexpr int n = decltype(nc)::value, k = decltype(kc)::value;
                 if constexpr (k == 0) fin_sum(st, n, 0);
