@@ -208,3 +208,22 @@ def test_bench_refuses_a_device_list_of_the_wrong_length():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--devices", "0"], capture_output=True, text=True,
                        env=dict(os.environ, UVA_LIB_PATH=os.path.join(ROOT, "upscale_video_amd", "libuva.so")))
     assert r.returncode != 0 and "--devices" in (r.stderr + r.stdout)
+
+
+@pytest.mark.parametrize("tile", [64, 0])
+def test_bench_parity_windows_are_exact_for_an_exact_result(tile):
+    """bench.py's full-size parity (windows of the timed frame against the oracle on their receptive fields, cut to the window's
+    tile where the reference tiles): with the oracle's own frame standing in for the GPU's the distance must be exactly zero --
+    corners, centre and both sides of the seams, tiled and whole -- and a planted error must be found"""
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import uvoracle
+    uvoracle.build()
+    img = uvoracle.synthetic_frame(150, 200, seed=3)
+    m = uvoracle.load_model("2x")
+    got = m.upscale_image(img, tile_size=tile, border=10) if tile else m.apply_model(img)
+    r = bench.parity_windows("2x", img, got, 2, 18, tile, win=24)
+    assert r["max_abs_lsb"] == 0 and r["differ_share"] == 0.0 and r["windows"] == (9 if tile else 5)
+    bad = got.copy()
+    bad[0, 0, 0] ^= 4
+    assert bench.parity_windows("2x", img, bad, 2, 18, tile, win=24)["max_abs_lsb"] == 4
