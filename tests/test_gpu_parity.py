@@ -171,6 +171,25 @@ def test_sign_carry_between_launches_changes_no_bit(uva, nets, oracle, key, monk
     assert np.array_equal(nets[key]._extract(x), plain._extract(x))
 
 
+@pytest.mark.parametrize("key", ["2x", "4x"])
+def test_folded_last_strips_change_no_bit(uva, nets, oracle, key, monkeypatch):
+    """trunkw_kernel walks the narrow last strips of two planes of one size in ONE pass (pairs 0..7: the first plane, 8..15: the
+    second; csrc/uva_api.hip build_trunkw_schedule).  The arithmetic per pixel is untouched, so the frame must equal, BYTE FOR
+    BYTE, the one a net with UVA_TW_FOLD=0 gives -- the bar that catches what the LSB / dB bars let through (the first version
+    folded strips of 13 and 14 columns, whose last producer pair reads two raw columns of the other plane: one wrong column per
+    plane, inside every tolerance).  Frames of 2T x 2T pixels with tile T give four planes of (T + 10)^2: last strips of 1, 5,
+    11, 12 columns (folded), 13 and 14 (not), and the 1080p reference tiling (10 columns, 970 and 130 rows)."""
+    monkeypatch.setenv("UVA_TW_FOLD", "0")
+    plain = load_net(uva, key)            # (the schedule is built, and the switch read, when a geometry is first seen)
+    frames = [(oracle.synthetic_frame(2 * t, 2 * t, kind="random", seed=900 + t), t) for t in (32, 51, 55, 61, 33, 34)]
+    frames.append((oracle.synthetic_frame(1080, 1920, seed=77), 960))
+    want = [plain.process_u8(img, tile_size=t, border=10) for img, t in frames]
+    monkeypatch.delenv("UVA_TW_FOLD")
+    for (img, t), w in zip(frames, want):
+        got = nets[key].process_u8(img, tile_size=t, border=10)
+        assert np.array_equal(got, w), (key, t, int(np.abs(got.astype(int) - w.astype(int)).max()), float((got != w).mean()))
+
+
 def test_fused_route_equals_float_route(nets, oracle):
     """The fused u8 device call against the reference-shaped float route (from_pixels ->
     normalize -> extract -> *255 -> convertTo) run tile by tile through the same kernels."""

@@ -330,3 +330,36 @@ def test_input_and_output_must_differ_and_commas_are_lists_only_for_worker_lists
 def test_filesystem_type_reads_the_mount_table(tmp_path):
     assert rawvideo.filesystem_type("/dev/shm") in ("tmpfs", None)
     assert rawvideo.filesystem_type(str(tmp_path)) is None or isinstance(rawvideo.filesystem_type(str(tmp_path)), str)
+
+
+@pytest.mark.parametrize("threads", [2, 3, 4])
+def test_positional_writers_give_the_bytes_of_the_single_writer(tmp_path, threads):
+    """--write-threads: a result frame cut into whole-MiB pieces written with os.pwrite by a pool (regular files only); the bytes
+    and the file position behind the stream are those of plain write() calls, also in the middle of a file (a segment's offset)"""
+    import io
+    h, w, nframes = 300, 500, 5                      # 450 000 B in, 1.8 MB out per frame: two pieces with 2-4 writers
+    frames = _frames(nframes, h, w)
+    data = b"".join(f.tobytes() for f in frames)
+    alloc = lambda shape: np.zeros(shape, np.uint8)   # noqa: E731
+    ref = io.BytesIO()
+    rawvideo.stream(io.BytesIO(data), ref, h, w, [(FakeNet(2), 0)], alloc=alloc)
+    p = tmp_path / "out.bgr24"
+    with open(p, "wb") as f:
+        f.write(b"HEAD" * 3)                         # the stream starts at the handle's position, not at 0
+        n = rawvideo.stream(io.BytesIO(data), f, h, w, [(FakeNet(2), 0)], alloc=alloc, write_threads=threads)
+        assert n == nframes and f.tell() == 12 + len(ref.getvalue())
+        f.write(b"TAIL")
+    got = p.read_bytes()
+    assert got[:12] == b"HEAD" * 3 and got[12:-4] == ref.getvalue() and got[-4:] == b"TAIL"
+    # a pipe-like object (no descriptor): the single writer, silently
+    out = io.BytesIO()
+    assert rawvideo.stream(io.BytesIO(data), out, h, w, [(FakeNet(2), 0)], alloc=alloc, write_threads=threads) == nframes
+    assert out.getvalue() == ref.getvalue()
+    # segments with positional writers: the same file as without
+    src = tmp_path / "in.bgr24"
+    src.write_bytes(data)
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    mk = lambda: [[(FakeNet(2), 0)] for _ in range(2)]   # noqa: E731
+    rawvideo.stream_segments(str(src), a, h, w, mk(), 2, alloc=alloc, write_threads=threads)
+    rawvideo.stream_segments(str(src), b, h, w, mk(), 2, alloc=alloc, write_threads=1)
+    assert open(a, "rb").read() == open(b, "rb").read() == ref.getvalue()

@@ -24,9 +24,9 @@ for args in (["-s", "2"], ["-s", "2", "-g", "0,0"], ["-s", "2", "-m", "a"], ["-s
     t1 = wall(base + args + ["-i", src, "-o", "/dev/null", "--frames", "1"])
     tn = wall(base + args + ["-i", src, "-o", "/dev/null"])
     print(f"{' '.join(args):20s} file -> /dev/null : {N} frames in {tn:6.2f} s (start-up {t1:5.2f} s) = {(N - 1) / (tn - t1):7.1f} frames/s")
-# file -> FILE: one worker; several workers through ONE reader and ONE writer (--round-robin); a segment, reader and writer
-# each into ONE shared output file -- through shared mappings (the default since round 5) and through seek + write
-# (UVA_RAW_MMAP=0: the writers take the file's inode lock in turn) --; one output file per worker.  On /dev/shm (tmpfs: page
+# file -> FILE: one worker with one and with four positional writers; several workers through ONE reader and ONE writer
+# (--round-robin); a segment, reader and writers each into ONE shared output file -- by positional writes (the default) and
+# through shared mappings (UVA_RAW_MMAP=1) --; one output file per worker.  On /dev/shm (tmpfs: page
 # cache and nothing else) and on a directory of a REAL file system (UVA_BENCH_DIR, default: the repository's gpurun_out/).
 from upscale_video_amd.rawvideo import filesystem_type
 real_dir = os.environ.get("UVA_BENCH_DIR") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
@@ -37,11 +37,11 @@ for where in ("/dev/shm", real_dir):
     free = st.f_bavail * st.f_frsize
     M = max(8, min(N, int(free * 0.5) // (2160 * 3840 * 3), 400 if where == "/dev/shm" else 160))
     print(f"--- output files in {where} ({filesystem_type(where)}, {free / 1e9:.0f} GB free), {M} frames")
-    for args, per_lane, env in ((["-s", "2", "-g", "0"], False, {}),
+    for args, per_lane, env in ((["-s", "2", "-g", "0", "--write-threads", "1"], False, {}), (["-s", "2", "-g", "0"], False, {}),
                                 (["-s", "2", "-g", "0,0", "--round-robin"], False, {}),
-                                (["-s", "2", "-g", "0,0"], False, {}), (["-s", "2", "-g", "0,0"], False, {"UVA_RAW_MMAP": "0"}),
+                                (["-s", "2", "-g", "0,0"], False, {}), (["-s", "2", "-g", "0,0"], False, {"UVA_RAW_MMAP": "1"}),
                                 (["-s", "2", "-g", "0,0"], True, {}),
-                                (["-s", "2", "-g", "0,0,0,0"], False, {}), (["-s", "2", "-g", "0,0,0,0"], False, {"UVA_RAW_MMAP": "0"}),
+                                (["-s", "2", "-g", "0,0,0,0"], False, {}), (["-s", "2", "-g", "0,0,0,0"], False, {"UVA_RAW_MMAP": "1"}),
                                 (["-s", "2", "-g", "0,0,0,0"], True, {}),
                                 (["-s", "2", "-g", "0,0,0,0,0,0,0,0"], False, {}), (["-s", "2", "-g", "0,0,0,0,0,0,0,0"], True, {})):
         k = len(args[3].split(","))
@@ -53,7 +53,7 @@ for where in ("/dev/shm", real_dir):
         finally:
             for key in env:
                 os.environ.pop(key, None)
-        label = " ".join(args) + (" -o one file per worker" if per_lane else "") + (" seek+write (UVA_RAW_MMAP=0)" if env else "")
+        label = " ".join(args) + (" -o one file per worker" if per_lane else "") + (" through shared mappings (UVA_RAW_MMAP=1)" if env else "")
         print(f"{label:64s} file -> file : {M} frames in {tn:6.2f} s (start-up {t1:5.2f} s) = {(M - k) / (tn - t1):7.1f} frames/s", flush=True)
         for o in outs:
             os.remove(o)

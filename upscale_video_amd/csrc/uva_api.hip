@@ -542,8 +542,12 @@ int build_trunkw_schedule(const std::vector<PlaneDesc>& planes, int grid, size_t
     const bool top_ok = false;
     // FOLDED last strips (round 5).  A strip costs its 16 MFMA pair columns whatever its width, and 970 columns (the reference
     // tiling's planes at 1080p) are 32 strips and a THIRD of one: 2 % of a launch's steps compute nothing.  Where two planes have
-    // the same size and a last strip of at most 14 columns (7 consumer pairs, which need the producers' pairs 0..7), ONE strip
-    // walk does both: lanes with pair index 0..7 work on the first plane, 8..15 on the second -- everything in between (rings,
+    // the same size and a last strip of at most TW_FOLD_MAXW = 12 columns, ONE strip walk does both: lanes with pair index 0..7
+    // work on the first plane, 8..15 on the second.  Why 12 and not 14: v output columns need the intermediate columns -1..v,
+    // i.e. the producers' pairs 0..(v + 1) / 2, and producer pair p reads raw columns 2p..2p+3 -- for v = 13, 14 that is pair 7
+    // and raw columns 16, 17, which in a folded step hold the SECOND plane's first pixels (the first version allowed 14: one
+    // wrong column per 74-wide plane, 1.4 dB on the 128x96 probe, inside every parity bar -- found by the probe's PSNR moving,
+    // now pinned by a byte-for-byte fold on / off test).  Everything in between (rings,
     // transforms, k-loops) is pair-wise and does not care; what differs is where the raw rows come from and where the results
     // go: the second plane's addresses = the first's + a constant (entry .w = that constant - 2048, flags a.y bit 27 / b.y
     // bit 25; csrc/uva_wino.hip.h).  UVA_TW_FOLD=0: off.
@@ -554,7 +558,7 @@ int build_trunkw_schedule(const std::vector<PlaneDesc>& planes, int grid, size_t
     auto last_x0 = [](const PlaneDesc& p) { return ((p.w + TW_SW - 1) / TW_SW - 1) * TW_SW; };
     if (fold_ok)
         for (size_t i = 0; i < planes.size(); ++i) {
-            if (fold_partner[i] >= 0 || folded_away[i] || planes[i].w - last_x0(planes[i]) > 14) continue;
+            if (fold_partner[i] >= 0 || folded_away[i] || planes[i].w - last_x0(planes[i]) > TW_FOLD_MAXW) continue;
             for (size_t j = i + 1; j < planes.size(); ++j) {
                 if (fold_partner[j] >= 0 || folded_away[j]) continue;
                 const long long delta = ((long long)planes[j].act_off - (long long)planes[i].act_off) * PIXB;

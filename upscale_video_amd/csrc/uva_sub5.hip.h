@@ -13,7 +13,8 @@
 // Organisation: one 12-wave workgroup per CU runs TWO pipelines on two neighbouring 64-column strips (54 valid columns each):
 // waves 0-3 / 4-7 are the four 24->24 layers of pipeline 0 / 1 (a wave IS a layer, its 56 weight registers never move), waves 8, 9
 // the pipelines' LIGHT FRONT wave, waves 10, 11 their LIGHT BACK wave.  The launch's light LAYER (part 0: conv 3->24, part 1:
-// conv 24->3 + residual -> u8) is split between the two by fragments -- front: fragments 0, 1; back: 2, 3 -- and each also
+// conv 24->3 + residual -> u8) is split between the two by fragments -- part 0: front 0, 1, back 2, 3; part 1: front 0, back 1..3
+// (its front wave also waits for HBM) -- and each also
 // moves rows: part 0's front wave brings the u8 rows in, its back wave takes layer 4's rows out to `mid`; part 1's front wave
 // brings the rows of `mid` in.  (First version: the whole light layer on one wave, the other one only moving rows -- the
 // light waves set the row period, as in sub10_kernel, profiles/r05_ab_results.txt.)  Waves w, w+4, w+8 share a SIMD: two
@@ -30,6 +31,10 @@ namespace uva {
 namespace s5 {
 
 constexpr int NW = 12;
+#ifndef S5_TAIL_SPLIT
+#define S5_TAIL_SPLIT 1                          // part 1: the front wave (which also brings the rows of `mid` in: ~940 ticks per row) takes
+#endif                                           // fragments [0, S5_TAIL_SPLIT) of the last layer, the back wave the rest.  With 2 / 2 the front
+                                                 // wave set the row period (3 840 against 2 900 ticks, profiles/r05_ab4_sub5_anatomy.txt)
 constexpr int ROWPX = S5_WC + 2;                 // ring row: one margin pixel either side
 constexpr int PIXB = 48;
 constexpr int ROWB = ROWPX * PIXB;               // 3168 (an even number of 16-byte units: the read recipe needs that)
@@ -267,23 +272,15 @@ __device__ __forceinline__ void rowf(const char* __restrict__ rin, char* __restr
             }
         }
     };
-    f32x4 a0[MB], a1[MB];
-    if constexpr (F1 - F0 == 4) {
-        mma(F0, a0);
-        mma(F0 + 1, a1);
-        epi(F0, a0);
-        mma(F0 + 2, a0);
-        epi(F0 + 1, a1);
-        mma(F0 + 3, a1);
-        epi(F0 + 2, a0);
-        epi(F0 + 3, a1);
-    } else {
-        static_assert(F1 - F0 == 2, "four fragments (a trunk layer) or two (half of the last layer)");
-        mma(F0, a0);
-        mma(F0 + 1, a1);
-        epi(F0, a0);
-        epi(F0 + 1, a1);
-    }
+    // two accumulator sets in turn: fragment f's MFMAs run while fragment f - 1's epilogue is issued
+    f32x4 acc2[2][MB];
+    mma(F0, acc2[0]);
+    static_for<F1 - F0 - 1>([&](auto fc) __attribute__((always_inline)) {
+        constexpr int i = decltype(fc)::value + 1;
+        mma(F0 + i, acc2[i & 1]);
+        epi(F0 + i - 1, acc2[(i - 1) & 1]);
+    });
+    epi(F1 - 1, acc2[(F1 - F0 - 1) & 1]);
 }
 
 // ---- eight waves: conv 24 -> 24 (+ bias, PReLU), stage 1..4 of a pipeline: ring stage-1 -> ring stage;
@@ -433,10 +430,10 @@ __global__ __launch_bounds__(64 * s5::NW, 1) void sub5_kernel(Sub5Args a)
         else body<false, 0, 4, false>(a, L, wave, stage, stage - 1, 2 * stage, lane, xoff, nrows, nsteps);              // layer 4 + stage (ring 0 is loaded, not computed)
     } else if (wave < 10) {
         if (PART == 0) head<0, 2, true>(a, L, wave, lane, xoff, nrows, nsteps);
-        else body<true, 0, 2, true>(a, L, wave, S5_NL, S5_NL - 1, 2 * S5_NL, lane, xoff, nrows, nsteps);               // conv 24 -> 3 reads ring 4
+        else body<true, 0, S5_TAIL_SPLIT, true>(a, L, wave, S5_NL, S5_NL - 1, 2 * S5_NL, lane, xoff, nrows, nsteps);    // conv 24 -> 3 reads ring 4
     } else {
         if (PART == 0) head<2, 4, false>(a, L, wave, lane, xoff, nrows, nsteps);
-        else body<true, 2, 4, false>(a, L, wave, S5_NL, S5_NL - 1, 2 * S5_NL, lane, xoff, nrows, nsteps);
+        else body<true, S5_TAIL_SPLIT, 4, false>(a, L, wave, S5_NL, S5_NL - 1, 2 * S5_NL, lane, xoff, nrows, nsteps);
     }
 }
 

@@ -10,6 +10,7 @@ struct Trunk2Step;                                // uva_devutil.hip.h (32 bytes
 
 constexpr int TW_SW = 30;                         // output columns per strip
 constexpr int TW_PAD_STEPS = 2;                   // dummy entries behind a workgroup's last step (DMA look-ahead)
+constexpr int TW_FOLD_MAXW = 12;                  // widest last strip two planes can share (folded steps: pairs 0..6 per plane)
 
 struct TrunkwArgs {
     const char* in_act;           // activation buffer INCLUDING its leading guard

@@ -73,13 +73,13 @@ static_assert(TW_RAW % 128 == 0 && TW_RAWROWB % 128 == 0, "raw pixel records are
 //      active << 24 | (the workgroup's first step only) all six input rows are to be fetched << 25, z = row pitch in bytes
 //   b: x = byte offset (low 32) of output pixel (yA - 1, x0), y = offset bits 32..39 | v1 << 8 | valid columns << 11 |
 //      v0 << 17 (rows yA-1 + [v0, v1) are stored) | active << 24, z = row pitch in bytes
-//   FOLDED steps (a.y bit 27, b.y bit 25; host: build_trunkw_schedule): the last, narrow (<= 14 columns) strips of TWO planes of one
+//   FOLDED steps (a.y bit 27, b.y bit 25; host: build_trunkw_schedule): the last, narrow (<= TW_FOLD_MAXW = 12 columns) strips of TWO planes of one
 //   size in one walk -- pairs 0..7 belong to the first plane, pairs 8..15 to the second, whose pixels lie a constant further on:
 //   .w = that constant - 2048 (raw column 16 + c of the step is the second plane's column c: 16 pixels back, one plane on), the
 //   first plane's index in the top byte of .z (the pitch is its low 24 bits in every entry).  Rings,
 //   transforms and k-loops are pair-wise and unchanged; the DMA source, the producers' column masks (pair & 7) and the consumers'
-//   store addresses are what a folded step does differently.  Pair 7's transformed values mix the two planes and are never used
-//   (a folded strip has at most 7 consumer pairs per plane).
+//   store addresses are what a folded step does differently.  Pair 7 of either half mixes the two planes (its raw columns 16, 17
+//   are the other plane's) and is never used: a folded strip has at most 12 columns = 6 consumer pairs, which need producer pairs 0..6.
 
 // LDS-DMA piece i of wave `wave`: piece c = 4i + wave covers units [64c, 64c + 64) of a raw slot; unit q is row
 // q / 272, record (q % 272) / 8, slot q % 8 -> (row << 13) | byte offset of that octet inside the source row
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
     static_assert(NF == 64, "written for 64 features");
     constexpr int PIXB = 128;
 #ifndef TW_PFF
-#define TW_PFF 6
+#define TW_PFF 12             // fragments the producers' k-loop reads ahead of its MFMAs (6 until round 5: +0.3-0.6 % on two boxes, 254 VGPRs)
 #endif
 #ifndef TW_XA
 #define TW_XA 0               // raw rows of a step transformed by the PRODUCER group (0, 2 or 4; the consumers take the rest)
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
 #define TW_RAW_STRIDE 2
 #endif
 #ifndef TW_PFF_B
-#define TW_PFF_B TW_PFF       // ... of the consumers' k-loop (the in-stream raw-row transform wants the registers)
+#define TW_PFF_B 6            // ... the consumers': the in-stream raw-row transform has the registers (7: 253, no faster; 8 spills; 4: -0.5 %)
 #endif
     constexpr int PFF_A = TW_PFF;                 // fragments read ahead of their MFMAs: an LDS read takes ~280 cycles to come back
                                                   // while four waves stream fragments, and an MFMA 16 (profiles/r04_ab_results.txt)

@@ -19,9 +19,13 @@ order: denoise, anime pass, upscale; upscale/upscale_processing.py:880-920),
 -g/--gpu a list of HIP ordinals, one worker per entry (duplicates allowed).  Pipes: one reader deals the frames
 out round-robin, one writer puts the results out in frame order.  File to file: one contiguous segment of frames per
 entry, each with its own reader, chain of nets and writer on its own file handles (stream_segments) -- no shared serial
-copy, so the route scales with the GPUs.  Into ONE output file the writers copy through shared MAPPINGS of their own byte
-ranges (MappedSegment): write() / pwrite() calls on one file take its inode lock in turn whatever their offsets, page faults
-on different pages do not.  `-o x,y,...` (and `-i a,b,...`, with more than one -g entry) give every entry a file of its own.
+copy, so the route scales with the GPUs.  A result frame is 25-100 MB and one thread copies ~5 GB/s into the page cache, so a
+regular output file is written with POSITIONAL writes by several threads per worker (`--write-threads`, default 4 for one worker,
+2 for two, 1 beyond): measured on the box's overlay file system a single worker goes from 187 to what the GPU delivers, and four
+workers into one file reach 0.93 of the /dev/null rate (tmpfs stays at ~200 frames/s whatever is done: its page allocation is
+the limit -- profiles/r05_ab_results.txt).  `-o x,y,...` (and `-i a,b,...`, with more than one -g entry) give every entry a
+file of its own.  (MappedSegment -- workers copying through shared mappings of their byte ranges, UVA_RAW_MMAP=1 -- was built to
+get around the inode lock and measured SLOWER than write() on both file systems: kept as an option, off.)
 """
 import argparse
 import mmap
@@ -169,13 +173,25 @@ class Lane:
         return self.stages[last].collect()
 
 
-def stream(fin, fout, h, w, nets_tiles, alloc=None, max_frames=None):
+def _regular_fd(f):
+    """the descriptor behind f if it is a regular file we may write to with os.pwrite, else None"""
+    import stat
+    try:
+        fd = f.fileno()
+        return fd if stat.S_ISREG(os.fstat(fd).st_mode) else None
+    except (AttributeError, OSError, ValueError):
+        return None
+
+
+def stream(fin, fout, h, w, nets_tiles, alloc=None, max_frames=None, write_threads=1):
     """Reads u8 [h][w][3] frames from fin until EOF, pushes each through the nets in order, writes the
     results to fout.  nets_tiles: list of (Net, tile_size) -- one GPU worker -- or a list of such lists,
     one per `-g` entry (duplicates allowed, as in the reference's worker list, README.md:45-61): ONE reader
     deals the frames out round-robin (the partition of upscale_processing.py:565-598, frames being
     independent units), every entry keeps up to PIPE_DEPTH frames in flight per net, and ONE writer puts
-    the results out in frame order.  Returns the number of frames written."""
+    the results out in frame order.  write_threads > 1 and fout a regular file: every result frame is cut into that many pieces
+    written with os.pwrite by a small pool (one thread copies ~5 GB/s into the page cache: a 4K frame every 5 ms, half of what
+    one GPU delivers).  Returns the number of frames written."""
     alloc = alloc or ncnn.pinned_empty
     lanes_spec = nets_tiles if nets_tiles and isinstance(nets_tiles[0], list) else [nets_tiles]
     lanes = [Lane(spec, h, w, alloc) for spec in lanes_spec]
@@ -188,13 +204,39 @@ def stream(fin, fout, h, w, nets_tiles, alloc=None, max_frames=None):
     wq = queue.Queue(maxsize=2)
     werr = []
 
+    fd = _regular_fd(fout) if write_threads > 1 else None
+    pool = None
+    if fd is not None:
+        from concurrent.futures import ThreadPoolExecutor
+        fout.flush()
+        pos0 = fout.tell()
+        pool = ThreadPoolExecutor(max_workers=write_threads)
+
+    def pwrite_all(view, pos):
+        while len(view):
+            k = os.pwrite(fd, view, pos)
+            view, pos = view[k:], pos + k
+
     def writer():
+        pos = pos0 if fd is not None else 0
         try:
             while True:
                 item = wq.get()
                 if item is None:
+                    if fd is not None:
+                        fout.seek(pos)
                     return
-                fout.write(memoryview(item).cast("B"))
+                view = memoryview(item).cast("B")
+                if fd is None:
+                    fout.write(view)
+                    continue
+                n = len(view)
+                per = -(-n // write_threads)
+                piece = -(-per // (1 << 20)) * (1 << 20)              # whole MiB per writer
+                jobs = [pool.submit(pwrite_all, view[o:o + piece], pos + o) for o in range(0, n, piece)]
+                for j in jobs:
+                    j.result()
+                pos += n
         except Exception as e:  # noqa: BLE001
             werr.append(e)
             while wq.get() is not None:
@@ -229,6 +271,8 @@ def stream(fin, fout, h, w, nets_tiles, alloc=None, max_frames=None):
     finally:
         wq.put(None)
         wt.join()
+        if pool is not None:
+            pool.shutdown()
     if werr:
         raise werr[0]
     fout.flush()
@@ -298,15 +342,16 @@ class MappedSegment:
         self.close()
 
 
-def stream_segments(in_path, out_path, h, w, lanes_spec, scale_total, max_frames=None, alloc=None, opener=open, mapped=None):
+def stream_segments(in_path, out_path, h, w, lanes_spec, scale_total, max_frames=None, alloc=None, opener=open, mapped=None,
+                    write_threads=1):
     """The same frames -> the same bytes as stream(), for regular FILES, with NO shared serial copy: one contiguous segment of
     frames per `-g` entry (the reference's batches, upscale/upscale_processing.py:923-948, are such segments), and every entry
     runs its own stream() -- its own reader, its own pipelined chain of nets, its own writer thread -- on its own file handles.
       in_path   one file: cut into len(lanes_spec) segments, each read at its offset;  a list: one input file per entry
-      out_path  one file: sized first (space checked: statvfs; blocks reserved with posix_fallocate where that is cheap, i.e.
-                not on tmpfs, whose fallocate touches every page), then every entry copies its results into a shared mapping
-                of its own byte range (MappedSegment; `mapped=False` / UVA_RAW_MMAP=0: seek + write on its own handle, which
-                serialise on the file's inode lock);  a list: one output file per entry
+      out_path  one file: sized first, then every entry writes at the offset its results belong to, on its own handle (`write_threads`
+                positional writers per entry); `mapped=True` / UVA_RAW_MMAP=1: through a shared mapping of its byte range instead
+                (MappedSegment; space checked with statvfs, blocks reserved with posix_fallocate where that is cheap -- measured
+                slower than write() on tmpfs and on overlayfs, kept as an option);  a list: one output file per entry
     One reader and one writer thread copy ~10 GB/s each, two or three GPUs' worth of 1080p -> 4K frames; N independent pairs
     scale with the entries.  A worker that fails takes the output with it: the file(s) this call created are removed (a
     full-size file of zeros and holes is worse than none).  Returns the number of frames written."""
@@ -317,7 +362,7 @@ def stream_segments(in_path, out_path, h, w, lanes_spec, scale_total, max_frames
     if (ins is not None and len(ins) != nl) or (outs is not None and len(outs) != nl):
         raise ValueError("one input / output file per -g entry: %d entries" % nl)
     if mapped is None:
-        mapped = os.environ.get("UVA_RAW_MMAP", "1") != "0"
+        mapped = os.environ.get("UVA_RAW_MMAP", "0") == "1"
     for i in (ins if ins is not None else [in_path]):
         for o in (outs if outs is not None else [out_path]):
             if os.path.exists(o) and os.path.samefile(i, o):
@@ -376,7 +421,7 @@ def stream_segments(in_path, out_path, h, w, lanes_spec, scale_total, max_frames
                 else:
                     with opener(out_path if outs is None else outs[k], "r+b" if outs is None else "wb") as fout:
                         fout.seek(out_first[k] * fb_out)
-                        done[k] = stream(fin, fout, h, w, lanes_spec[k], alloc=alloc, max_frames=counts[k])
+                        done[k] = stream(fin, fout, h, w, lanes_spec[k], alloc=alloc, max_frames=counts[k], write_threads=write_threads)
         except Exception as e:  # noqa: BLE001
             errs.append(e)
     threads = [threading.Thread(target=work, args=(k,), daemon=True) for k in range(nl)]
@@ -435,6 +480,8 @@ def main(argv=None):
                     help="HIP ordinals, one worker per entry, e.g. 0,1,2,3 or 0,0,1 (upscale_video.py -g; default 0)")
     ap.add_argument("--tile", type=int, default=TILE_SIZE, help="reference tile size of the final pass (960); 0 = whole frame")
     ap.add_argument("--frames", type=int, default=None, help="stop after this many frames")
+    ap.add_argument("--write-threads", type=int, default=0,
+                    help="positional writers per worker for a regular output file (0 = auto: 4 for one worker, 2 for two, 1 beyond)")
     ap.add_argument("--round-robin", action="store_true",
                     help="file to file with several -g entries: deal the frames out one by one through ONE reader and ONE writer "
                          "(what pipes get) instead of one contiguous segment of frames, reader and writer per entry")
@@ -499,6 +546,7 @@ def main(argv=None):
         for o in outs:
             if i != "-" and o != "-" and os.path.exists(i) and os.path.exists(o) and os.path.samefile(i, o):
                 ap.error("%s is input and output at once" % o)
+    wthreads = a.write_threads if a.write_threads > 0 else max(1, min(4, 4 // max(1, len(nets))))
     regular = all(os.path.isfile(f) for f in ins) and all(not os.path.exists(f) or os.path.isfile(f) for f in outs)
     if nets and (len(ins) > 1 or len(outs) > 1 or (len(nets) > 1 and not a.round_robin and a.input != "-" and a.output != "-" and regular)):
         if not regular:
@@ -507,7 +555,7 @@ def main(argv=None):
         for net, _ in nets[0]:
             scale_total *= 1 if isinstance(net, tuple) else net.scale
         n = stream_segments(ins if len(ins) > 1 else ins[0], outs if len(outs) > 1 else outs[0], a.height, a.width, nets, scale_total,
-                            max_frames=a.frames)
+                            max_frames=a.frames, write_threads=wthreads)
         print("%d frames" % n, file=sys.stderr)
         ncnn.destroy_gpu_instance()
         return 0
@@ -519,7 +567,7 @@ def main(argv=None):
     ok = False
     try:
         if nets:
-            n = stream(fin, fout, a.height, a.width, nets, max_frames=a.frames)
+            n = stream(fin, fout, a.height, a.width, nets, max_frames=a.frames, write_threads=wthreads)
         else:
             n = copy_through(fin, fout, a.height, a.width, a.frames)
         ok = True
