@@ -19,13 +19,14 @@ order: denoise, anime pass, upscale; upscale/upscale_processing.py:880-920),
 -g/--gpu a list of HIP ordinals, one worker per entry (duplicates allowed).  Pipes: one reader deals the frames
 out round-robin, one writer puts the results out in frame order.  File to file: one contiguous segment of frames per
 entry, each with its own reader, chain of nets and writer on its own file handles (stream_segments) -- no shared serial
-copy, so the route scales with the GPUs.  A result frame is 25-100 MB and one thread copies ~5 GB/s into the page cache, so a
-regular output file is written with POSITIONAL writes by several threads per worker (`--write-threads`, default 4 for one worker,
-2 for two, 1 beyond): measured on the box's overlay file system a single worker goes from 187 to what the GPU delivers, and four
-workers into one file reach 0.93 of the /dev/null rate (tmpfs stays at ~200 frames/s whatever is done: its page allocation is
-the limit -- profiles/r05_ab_results.txt).  `-o x,y,...` (and `-i a,b,...`, with more than one -g entry) give every entry a
-file of its own.  (MappedSegment -- workers copying through shared mappings of their byte ranges, UVA_RAW_MMAP=1 -- was built to
-get around the inode lock and measured SLOWER than write() on both file systems: kept as an option, off.)
+copy, so the route scales with the GPUs.  Measured on the GPU box (profiles/r05_ab_results.txt blocks 8, 9): on a real file
+system (the container's overlay) positional writes of several workers into ONE file scale -- 187 (one worker), 372 (two), 436
+(four) frames/s at 1080p -> 4K = 0.93 of the /dev/null rate; on tmpfs (/dev/shm) one file takes ~200 frames/s = 5 GB/s whatever
+writes into it and more writers make it worse -- its page allocation under the inode lock is the limit, and only `-o x,y,...`
+(one file per worker: separate inodes, 457-477 frames/s) gets past it there.  Two things built to beat the inode lock and
+measured no better, kept as options: MappedSegment (each worker copying through a shared mapping of its byte range,
+UVA_RAW_MMAP=1: slower than write() on tmpfs, equal on overlay) and `--write-threads N` (a worker's frames cut into pieces
+written with os.pwrite by a pool: +10 % for one worker on overlay, -40 % on tmpfs; default 1).
 """
 import argparse
 import mmap
@@ -481,7 +482,8 @@ def main(argv=None):
     ap.add_argument("--tile", type=int, default=TILE_SIZE, help="reference tile size of the final pass (960); 0 = whole frame")
     ap.add_argument("--frames", type=int, default=None, help="stop after this many frames")
     ap.add_argument("--write-threads", type=int, default=0,
-                    help="positional writers per worker for a regular output file (0 = auto: 4 for one worker, 2 for two, 1 beyond)")
+                    help="positional writers per worker for a regular output file (default 1: more gained 10 %% on a disk-backed file "
+                         "system and lost 40 %% on tmpfs)")
     ap.add_argument("--round-robin", action="store_true",
                     help="file to file with several -g entries: deal the frames out one by one through ONE reader and ONE writer "
                          "(what pipes get) instead of one contiguous segment of frames, reader and writer per entry")
@@ -546,7 +548,7 @@ def main(argv=None):
         for o in outs:
             if i != "-" and o != "-" and os.path.exists(i) and os.path.exists(o) and os.path.samefile(i, o):
                 ap.error("%s is input and output at once" % o)
-    wthreads = a.write_threads if a.write_threads > 0 else max(1, min(4, 4 // max(1, len(nets))))
+    wthreads = max(1, a.write_threads)
     regular = all(os.path.isfile(f) for f in ins) and all(not os.path.exists(f) or os.path.isfile(f) for f in outs)
     if nets and (len(ins) > 1 or len(outs) > 1 or (len(nets) > 1 and not a.round_robin and a.input != "-" and a.output != "-" and regular)):
         if not regular:
