@@ -190,6 +190,23 @@ def test_folded_last_strips_change_no_bit(uva, nets, oracle, key, monkeypatch):
         assert np.array_equal(got, w), (key, t, int(np.abs(got.astype(int) - w.astype(int)).max()), float((got != w).mean()))
 
 
+@pytest.mark.parametrize("key", ["2x", "4x"])
+def test_winograd_trunk_against_the_direct_trunk_1080p(uva, nets, oracle, key, monkeypatch):
+    """the oracle's product mode follows the kernel's rounding points, so the drift of the Winograd F(2,3) trunk
+    (PReLU on halves) against the DIRECT fp16 trunk (trunk2_kernel, UVA_TRUNK_WINO=0: round 2/3's product) is pinned here on its own,
+    on a whole 1080p frame with the reference tiling: both are within one level of the fp32 oracle, so at most two apart; the share
+    of samples that differ and the PSNR between the two go into the parity report (expected below 1 % and around 69-70 dB: the
+    fp16 roundings of the transformed operands), the bars are 2 % and 66 dB."""
+    monkeypatch.setenv("UVA_TRUNK_WINO", "0")
+    direct = load_net(uva, key)
+    img = oracle.synthetic_frame(1080, 1920, seed=2026)
+    a = direct.process_u8(img, tile_size=960, border=10)
+    monkeypatch.delenv("UVA_TRUNK_WINO")
+    b = nets[key].process_u8(img, tile_size=960, border=10)
+    check_u8(f"{key} 1080p: Winograd F(2,3) trunk against the direct trunk", b, a, vs="trunk2_kernel (direct fp16 trunk, UVA_TRUNK_WINO=0)",
+             max_lsb=2, min_psnr=66.0, max_share=0.02, model=key, route="tiled")
+
+
 def test_fused_route_equals_float_route(nets, oracle):
     """The fused u8 device call against the reference-shaped float route (from_pixels ->
     normalize -> extract -> *255 -> convertTo) run tile by tile through the same kernels."""

@@ -15,7 +15,8 @@ if [ -f upscale_video_amd/libuva_prev.so ]; then
     for i in 1 2 3; do
       for v in prev new; do
         L=$REPO/upscale_video_amd/libuva.so; [ $v = prev ] && L=$REPO/upscale_video_amd/libuva_prev.so
-        echo -n "$wl $v: "; UVA_LIB_PATH=$L python bench.py --workload $wl --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | python -c "$P"
+        F=1; [ $v = prev ] && F=0       # (round 5: `prev` = round 4's trunk kernel -- -DTW_RAW_INK=0 -DTW_PFF=6 -- and its schedule: no folded strips)
+        echo -n "$wl $v: "; UVA_TW_FOLD=$F UVA_LIB_PATH=$L python bench.py --workload $wl --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | python -c "$P"
       done
     done
   done > "$OUT/${TAG}_ab_prev_new.txt" 2>&1
@@ -30,6 +31,11 @@ UVA_TRUNK_WINO=0 python bench.py --steps 100 --warmup 10 --no-cpu-baseline > "$O
 UVA_TW_ACT16=0 python bench.py --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_trunkw_fp32_prelu.json" 2>> "$OUT/bench.err"
 python bench.py --gpus 2 --devices 0,0 --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_two_ranks_one_gpu.json" 2>> "$OUT/bench.err"
 UVA_SUB10=0 python bench.py --workload 1x_hurrdeblur_1080p --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_1x_per_pair_kernels.json" 2>> "$OUT/bench.err"
+# round 5: the 1x net as two launches of five layers (sub5_kernel), folded last strips off, the driver's form of the default line
+UVA_SUB5=1 python bench.py --workload 1x_hurrdeblur_1080p --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_1x_sub5_two_launches.json" 2>> "$OUT/bench.err"
+UVA_TW_FOLD=0 python bench.py --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_no_folded_strips.json" 2>> "$OUT/bench.err"
+python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/${TAG}_bench_driver_form.json" 2>> "$OUT/bench.err"
+python bench.py --gpus 8 --devices 0,0,0,0,0,0,0,0 --workload 2x_compact_2160p --steps 8 --warmup 2 --no-cpu-baseline --no-parity > "$OUT/${TAG}_bench_config5_eight_ranks_one_gpu.json" 2>> "$OUT/bench.err"
 python bench.py --workload 1x_hurrdeblur_1080p --tile 960 --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_1x_tiled_960.json" 2>> "$OUT/bench.err"
 (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d /tmp/prof1x_$TAG -o p --output-format csv -- python $REPO/bench.py --workload 1x_hurrdeblur_1080p --tile 0 --steps 120 --warmup 10 --no-cpu-baseline --no-parity > /dev/null 2>&1; cp $(find /tmp/prof1x_$TAG -name "*kernel_stats.csv" | head -1) "$OUT/${TAG}_kernel_stats_1x_rocprofv3.csv")
 bash tools/pmc_sub10.sh /tmp/pmc_sub10_$TAG > "$OUT/${TAG}_sub10_pmc.txt" 2>&1
@@ -63,7 +69,10 @@ python -c "import json; d=json.load(open('$OUT/power_bench.json')); print('bench
 UVA_LIB_PATH=$REPO/upscale_video_amd/libuva_instr.so python tools/trunkw_anatomy.py > "$OUT/${TAG}_trunkw_anatomy.txt" 2>&1
 UVA_TRUNK_WINO=0 UVA_LIB_PATH=$REPO/upscale_video_amd/libuva_instr.so python tools/trunk2_anatomy.py > "$OUT/${TAG}_trunk2_anatomy.txt" 2>&1
 UVA_LIB_PATH=$REPO/upscale_video_amd/libuva_instr.so python tools/sub10_anatomy.py > "$OUT/${TAG}_sub10_anatomy.txt" 2>&1
+UVA_SUB5=1 UVA_LIB_PATH=$REPO/upscale_video_amd/libuva_instr.so python tools/sub5_anatomy.py > "$OUT/${TAG}_sub5_anatomy.txt" 2>&1
 python tools/soak.py 1000 > "$OUT/${TAG}_soak.txt" 2>&1
-timeout 1500 python -m pytest tests -m gpu -q > "$OUT/${TAG}_gpu_tests.txt" 2>&1
+timeout 2400 python -m pytest tests -m gpu -q > "$OUT/${TAG}_gpu_tests.txt" 2>&1
+cp gpurun_out/parity_report.json "$OUT/${TAG}_parity_report.json" 2>/dev/null
+cp gpurun_out/build_on_gpu_box.json "$OUT/${TAG}_build_on_gpu_box.json" 2>/dev/null
 (python -c "import __graft_entry__ as g; g.smoke(); print('smoke: ok')" 2>&1 | tail -3) > "$OUT/${TAG}_smoke.txt"
 ls -la "$OUT"
