@@ -161,6 +161,9 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
 #ifndef TW_RAW_STRIDE
 #define TW_RAW_STRIDE 3
 #endif
+#ifndef TW_DMA_LATE
+#define TW_DMA_LATE 0         // where the producers issue the LDS-DMA of step it + 2's raw rows: 0 in front of their k-loop, 1 behind it
+#endif                        // (they wait at barrier 1 anyway), 2 inside it, one piece every eighth fragment
 #ifndef TW_PRE_BAR
 #define TW_PRE_BAR 0          // a k-loop's first fragments (window row 0: written a period or more ago) are read in front of the barrier that
 #endif                        // opens its phase, not behind it.  Bit 0: the producers' (they wait at that barrier anyway); bit 1: the consumers',
@@ -239,6 +242,20 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
             if (fadd) off += (pc & 0x1800u) ? fadd : 0u;
             glds16_s(base, off, lds0 + TW_RAW + slot * TW_RAWSLOTB + (4 * i + wave) * 1024);
         }
+    };
+    // one piece of the same (TW_DMA_LATE == 2: the pieces ride in the producers' k-loop, one every eighth fragment)
+    [[maybe_unused]] auto issue_piece = [&](const uint4 e, int slot, auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        if (4 * i + wave >= TW_RAW_PIECES) return;
+        const unsigned ey = __builtin_amdgcn_readfirstlane(e.y);
+        const unsigned lo = __builtin_amdgcn_readfirstlane(e.x), hi = ey & 0xffu;
+        const char* base = a.in_act + (((unsigned long long)hi << 32) | lo);
+        const int pitch = __builtin_amdgcn_readfirstlane(e.z) & 0xffffff;
+        const unsigned fadd = ((ey >> 27) & 1u) ? (unsigned)__builtin_amdgcn_readfirstlane(e.w) : 0u;
+        const unsigned pc = (dma_pc2[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+        unsigned off = __umul24(pc >> 13, (unsigned)pitch) + (pc & 0x1fffu);
+        if (fadd) off += (pc & 0x1800u) ? fadd : 0u;
+        glds16_s(base, off, lds0 + TW_RAW + slot * TW_RAWSLOTB + (4 * i + wave) * 1024);
     };
 
     // lane part of a transformed-row address, fragment / transform view (pair pq = lane & 15, K octet oq = lane >> 4): pair
@@ -480,7 +497,9 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
 #endif
         for (int it = 0; it < niter; ++it) {
             TW_STAMP(0);
+#if TW_DMA_LATE == 0
             issue_rows(e_dma, it & 1);             // raw rows of step it + 2 (slot it & 1: transformed one phase ago)
+#endif
             // what the epilogue of step it needs: the masks of a step at its plane's edge
             const unsigned ey = __builtin_amdgcn_readfirstlane(e_own.y);
             const int rmask = (ey >> 8) & 15, c_lo = (ey >> 12) & 63, c_hi = (ey >> 18) & 63;
@@ -565,7 +584,14 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
             if (it < nsteps) {
                 __builtin_amdgcn_s_setprio(TW_PRIO_KA);
                 // steps that touch their plane's edge (uniform, few) mask what lies outside
+#if TW_DMA_LATE == 2
+                auto no_hook = [&](auto fc) __attribute__((always_inline)) {
+                    constexpr int f = decltype(fc)::value;
+                    if constexpr (f % 8 == 4 && f / 8 < 5) issue_piece(e_dma, it & 1, std::integral_constant<int, f / 8>{});
+                };
+#else
                 auto no_hook = [](auto) __attribute__((always_inline)) {};
+#endif
 #if TW_INROWS_A > 0
                 if (edge) kloop(std::false_type{}, a6, [&](auto nc, auto kc) __attribute__((always_inline)) { slice(st2[0], std::true_type{}, nc, kc); }, no_hook, pre);
                 else
@@ -573,6 +599,11 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
                 kloop(std::false_type{}, a6, [&](auto nc, auto kc) __attribute__((always_inline)) { slice(st2[0], std::false_type{}, nc, kc); }, no_hook, pre);
                 __builtin_amdgcn_s_setprio(TW_PRIO_EA);
             }
+#if TW_DMA_LATE == 1
+            issue_rows(e_dma, it & 1);             // ... behind the k-loop: the producers wait at barrier 1 anyway
+#elif TW_DMA_LATE == 2
+            if (it >= nsteps) issue_rows(e_dma, it & 1);       // (no k-loop in the last two iterations: their dummy rows all at once)
+#endif
             e_dma = load_a(it + 3 <= nsteps + TW_PAD_STEPS - 1 ? it + 3 : nsteps + TW_PAD_STEPS - 1);
             // the rows of step it + 1 (issued one iteration ago) are complete once only this phase's pieces are outstanding
             TW_STAMP(1);
