@@ -153,17 +153,18 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
 #define TW_RAW_INK 1          // 1 (default since round 5): the consumers transform the next step's raw rows INSIDE their k-loop -- reads at
 #endif                        // fragment TW_RAW_F0, the four V rows of a channel half TW_RAW_GAP fragments later, one every TW_RAW_STRIDE
 #ifndef TW_RAW_F0             // fragments, then the other half.  Their serial chain epilogue -> raw rows -> k-loop was what a period was
-#define TW_RAW_F0 0           // made of, and the transform is two LDS round trips that nothing overlapped: +3.6-3.8 % frames/s on two boxes
-#endif                        // (profiles/r05_ab_results.txt block 1; GAP 10 / STRIDE 2: +2.2 %, 17 / 2: the same as 14 / 3).  0: round 4's
-#ifndef TW_RAW_GAP            // stand-alone transform in front of the k-loop.
-#define TW_RAW_GAP 14
+#define TW_RAW_F0 4           // made of, and the transform is two LDS round trips that nothing overlapped: +3.6-3.9 % frames/s on three boxes
+#endif                        // with 0 / 14 / 3 (profiles/r05_ab_results.txt block 1; 0 / 10 / 2: +2.2 %), another +0.6-0.8 % with the reads at
+#ifndef TW_RAW_GAP            // fragment 4 (4 / 12 / 3, block 10: the k-loop's own first fragments go first).  0: round 4's stand-alone
+#define TW_RAW_GAP 12         // transform in front of the k-loop.
 #endif
 #ifndef TW_RAW_STRIDE
 #define TW_RAW_STRIDE 3
 #endif
 #ifndef TW_DMA_LATE
-#define TW_DMA_LATE 0         // where the producers issue the LDS-DMA of step it + 2's raw rows: 0 in front of their k-loop, 1 behind it
-#endif                        // (they wait at barrier 1 anyway), 2 inside it, one piece every eighth fragment
+#define TW_DMA_LATE 0         // where the producers issue the LDS-DMA of step it + 2's raw rows: 0 in front of their k-loop, 1 behind it, 2 inside
+#endif                        // it (one piece every eighth fragment).  Measured -8 % and -2 % (block 10): rows requested 1.35 periods ahead
+                              // arrive in time, rows requested one period ahead do not -- the DMA's latency under this load is ~3 us
 #ifndef TW_PRE_BAR
 #define TW_PRE_BAR 0          // a k-loop's first fragments (window row 0: written a period or more ago) are read in front of the barrier that
 #endif                        // opens its phase, not behind it.  Bit 0: the producers' (they wait at that barrier anyway); bit 1: the consumers',
