@@ -60,7 +60,8 @@ constexpr int TW_ARING = 0;
 constexpr int TW_BRING = TW_ARING + TW_AROWS * TW_AROWB;
 constexpr int TW_RAW = TW_BRING + TW_BROWS * TW_BROWB;
 constexpr int TW_PRM = TW_RAW + 2 * TW_RAWSLOTB;
-constexpr int TW_LDS_BYTES = TW_PRM + 2 * PARAM_LDS + 64;       // + a spare unit per lane group (pair 15's writes)
+constexpr int TW_FLAGS_OFF = TW_PRM + 2 * PARAM_LDS + 64;       // (TW_FLAGS) two step counters: [0] producers' k-loops done, [1] consumers'
+constexpr int TW_LDS_BYTES = TW_FLAGS_OFF + 16;                 // + a spare unit per lane group (pair 15's writes) + the counters
 static_assert(TW_RAW_PIECES == 17 && TW_RAWSLOTB % 1024 == 0, "raw slot = whole LDS-DMA pieces");
 static_assert(TW_LDS_BYTES <= 160 * 1024, "trunkw kernel LDS budget");
 static_assert(TW_RAW % 128 == 0 && TW_RAWROWB % 128 == 0, "raw pixel records are 128-byte aligned (the octet XOR flips address bits 4..6)");
@@ -161,6 +162,16 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
 #ifndef TW_RAW_STRIDE
 #define TW_RAW_STRIDE 3
 #endif
+#ifndef TW_FLAGS
+#define TW_FLAGS 0            // bit 0 / bit 1: barrier 1 / barrier 2 of an iteration becomes a ONE-DIRECTIONAL step counter in LDS.  What each barrier
+#endif                        // protects is one-sided: the consumers must not touch the A-ring or the raw slot before the producers' k-loop is done
+                              // and its rows have landed (barrier 1), the producers must not start their next k-loop before the consumers' k-loop
+                              // -- with the raw-row transform in it -- is done (barrier 2); the producers' epilogue and the consumers' epilogue
+                              // (registers -> B-ring block `it` / HBM) wait for nobody.  With s_barrier both groups wait for the other's TAIL
+                              // (~500 ticks per phase); with counters a group goes on to its epilogue at once and the tails overlap.
+#ifndef TW_FLAG_SLEEP
+#define TW_FLAG_SLEEP 1       // s_sleep argument between two looks at a counter (0: none)
+#endif
 #ifndef TW_DMA_LATE
 #define TW_DMA_LATE 0         // where the producers issue the LDS-DMA of step it + 2's raw rows: 0 in front of their k-loop, 1 behind it, 2 inside
 #endif                        // it (one piece every eighth fragment).  Measured -8 % and -2 % (block 10): rows requested 1.35 periods ahead
@@ -185,6 +196,25 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = lds_offset(smem);
     float* const prm_all = (float*)(smem + TW_PRM);       // per layer: bias[64], slope[64], med3 selector[64]
+#if TW_FLAGS
+    // step counters: every wave of a group adds one when its part is done (its own LDS writes waited for first); the other group
+    // spins until all four have (a spin that never ends would hang the GPU: it traps instead after ~0.1 s)
+    auto flag_signal = [&](int which) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (threadIdx.x % 64 == 0) __hip_atomic_fetch_add((int*)(smem + TW_FLAGS_OFF) + which, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto flag_wait = [&](int which, int target) __attribute__((always_inline)) {
+        const volatile int* const f = (const volatile int*)(smem + TW_FLAGS_OFF) + which;
+        int spins = 0;
+        while (__builtin_amdgcn_readfirstlane(*f) < target) {
+#if TW_FLAG_SLEEP > 0
+            __builtin_amdgcn_s_sleep(TW_FLAG_SLEEP);
+#endif
+            if (++spins > (1 << 22)) __builtin_trap();
+        }
+        asm volatile("" ::: "memory");
+    };
+#endif
 
     const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int grp = wave8 >> 2;   // 0: producer (layer i), 1: consumer (layer i+1)
@@ -345,6 +375,9 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
         prm[64 + lane] = prm_s;
         prm[128 + lane] = prm_s <= 1.f ? __builtin_inff() : -__builtin_inff();
     }
+#if TW_FLAGS
+    if (threadIdx.x == 0) { ((int*)(smem + TW_FLAGS_OFF))[0] = 0; ((int*)(smem + TW_FLAGS_OFF))[1] = 0; }
+#endif
     group_barrier();                   // every A wave's pieces have landed (each waited for its own)
     if (grp == 1) {
         transform_rows(0, 2);          // (the consumer group fills the A-ring: see its loop)
@@ -488,7 +521,7 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
         const int oo = 2 * (wave & 1) + (cg >> 1);
         const unsigned wlane = p < 15 ? (unsigned)(TW_BRING + (2 * (cg & 1)) * (TW_BROWB / 4) + (wave >> 1) * (TW_BROWB / 8) + p * 64 +
                                                     ((oo ^ ((p >> 1) & 3)) << 4))
-                                      : (unsigned)(TW_LDS_BYTES - 64 + 16 * cg);
+                                      : (unsigned)(TW_FLAGS_OFF - 64 + 16 * cg);
         const unsigned w64 = (unsigned)(TW_BRING + (wave >> 1) * (TW_BROWB / 8) + p * 64 + ((oo ^ ((p >> 1) & 3)) << 4) + 8 * (cg & 1));
         const unsigned wrow = p < 15 ? (unsigned)TW_BROWB : 0u;      // (pair 15: every row and both units to the same spare place)
         const unsigned wj = p < 15 ? (unsigned)(TW_BROWB / 4) : 0u;
@@ -498,6 +531,9 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
 #endif
         for (int it = 0; it < niter; ++it) {
             TW_STAMP(0);
+#if TW_FLAGS & 2
+            flag_wait(1, 4 * it);                  // the consumers' k-loop of iteration it - 1 (the raw rows of step it -> A-ring in it) is done
+#endif
 #if TW_DMA_LATE == 0
             issue_rows(e_dma, it & 1);             // raw rows of step it + 2 (slot it & 1: transformed one phase ago)
 #endif
@@ -608,7 +644,12 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
             e_dma = load_a(it + 3 <= nsteps + TW_PAD_STEPS - 1 ? it + 3 : nsteps + TW_PAD_STEPS - 1);
             // the rows of step it + 1 (issued one iteration ago) are complete once only this phase's pieces are outstanding
             TW_STAMP(1);
+#if TW_FLAGS & 1
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            flag_signal(0);                        // this wave's k-loop is done and its pieces of step it + 1 have landed: no waiting here
+#else
             if (wave == 0) dma_barrier<5>(); else dma_barrier<4>();
+#endif
             TW_STAMP(2);
 #if TW_XA > 0 && !defined(TW_XA_LAST)
             raw_rows_a();
@@ -638,7 +679,9 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
 #if TW_PRE_BAR & 1
             prefetch(std::false_type{}, a6, pre);  // the next step's window row 0 is this step's row 4: transformed a period ago
 #endif
+#if !(TW_FLAGS & 2)
             group_barrier();
+#endif
             b10 = b10 + 4 >= TW_BROWS ? b10 + 4 - TW_BROWS : b10 + 4;
         }
     } else {
@@ -713,7 +756,9 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
             bp = bp < 0 ? bp + TW_BROWS : bp;
             half8 pre[TW_PFF_B];
             TW_STAMP(1);
-#if TW_PRE_BAR & 2
+#if TW_FLAGS & 1
+            flag_wait(0, 4 * (it + 1));            // the producers' k-loop of this iteration is done, the raw rows of step it + 1 have landed
+#elif TW_PRE_BAR & 2
             prefetch(std::true_type{}, bp, pre);   // window row 0 = the third row of block it - 2: written three phases ago
             asm volatile("s_barrier" ::: "memory");        // (kact above has waited for the step entry; nothing of this phase went to LDS)
 #else
@@ -788,7 +833,11 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
             raw_rows();
 #endif
             TW_STAMP(3);
+#if TW_FLAGS & 2
+            flag_signal(1);                        // this wave's k-loop and its row of the A-ring are done: on to the epilogue at once
+#else
             group_barrier();
+#endif
             a6 = a6 + 4 >= TW_AROWS ? a6 + 4 - TW_AROWS : a6 + 4;
             b10 = b10 + 4 >= TW_BROWS ? b10 + 4 - TW_BROWS : b10 + 4;
         }
