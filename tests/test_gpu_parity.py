@@ -183,6 +183,11 @@ def test_folded_last_strips_change_no_bit(uva, nets, oracle, key, monkeypatch):
     plain = load_net(uva, key)            # (the schedule is built, and the switch read, when a geometry is first seen)
     frames = [(oracle.synthetic_frame(2 * t, 2 * t, kind="random", seed=900 + t), t) for t in (32, 51, 55, 61, 33, 34)]
     frames.append((oracle.synthetic_frame(1080, 1920, seed=77), 960))
+    rng = np.random.default_rng(5)            # ... and a seeded sweep: 3 x 2, 2 x 3, 3 x 3 tile grids (interior tiles with borders on every side)
+    for _ in range(int(os.environ.get("UVA_SWEEP_FACTOR", "1")) * 6):
+        t = int(rng.integers(21, 70))
+        ny, nx = int(rng.integers(2, 4)), int(rng.integers(2, 4))
+        frames.append((oracle.synthetic_frame(ny * t - int(rng.integers(0, 9)), nx * t - int(rng.integers(0, 9)), kind="random", seed=t), t))
     want = [plain.process_u8(img, tile_size=t, border=10) for img, t in frames]
     monkeypatch.delenv("UVA_TW_FOLD")
     for (img, t), w in zip(frames, want):
