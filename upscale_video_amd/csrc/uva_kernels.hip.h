@@ -1304,7 +1304,7 @@ __device__ __forceinline__ void sub10_body(const Sub10Args& a, const Sub10Lds L,
     }
 }
 
-__global__ __launch_bounds__(64 * S10_NW, 1) void sub10_kernel(Sub10Args a)
+__global__ __launch_bounds__(64 * S10_NW, 1) UVA_NO_PK_F32 void sub10_kernel(Sub10Args a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Sub10Lds L = sub10_lds(smem);

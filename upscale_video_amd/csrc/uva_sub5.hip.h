@@ -392,7 +392,7 @@ __device__ __forceinline__ void body(const Sub5Args& a, const Lds L, const int w
 }  // namespace s5
 
 template <int PART>
-__global__ __launch_bounds__(64 * s5::NW, 1) void sub5_kernel(Sub5Args a)
+__global__ __launch_bounds__(64 * s5::NW, 1) UVA_NO_PK_F32 void sub5_kernel(Sub5Args a)
 {
     using namespace s5;
     extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -131,7 +131,7 @@ __device__ __forceinline__ unsigned pk_add_f16(unsigned a, unsigned b)
 #endif
 
 template <int NF, int ACT>
-__global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
+__global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs a)
 {
     static_assert(NF == 64, "written for 64 features");
     constexpr int PIXB = 128;
@@ -176,8 +176,12 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
 #define TW_DMA_LATE 0         // where the producers issue the LDS-DMA of step it + 2's raw rows: 0 in front of their k-loop, 1 behind it, 2 inside
 #endif                        // it (one piece every eighth fragment).  Measured -8 % and -2 % (block 10): rows requested 1.35 periods ahead
                               // arrive in time, rows requested one period ahead do not -- the DMA's latency under this load is ~3 us
+#ifndef TW_DMA_B
+#define TW_DMA_B 1            // the CONSUMERS issue the LDS-DMA of step it + 2's raw rows, at the top of their phase X (their epilogue is the short
+#endif                        // side of that phase: ~600 ticks of slack), and wait for the rows of step it + 1 -- issued an iteration ago -- in front
+                              // of barrier 1 themselves; the producers' k-loop, the long side, starts at once (0: the producers issue, block 13)
 #ifndef TW_PRE_BAR
-#define TW_PRE_BAR 0          // a k-loop's first fragments (window row 0: written a period or more ago) are read in front of the barrier that
+#define TW_PRE_BAR 2          // a k-loop's first fragments (window row 0: written a period or more ago) are read in front of the barrier that
 #endif                        // opens its phase, not behind it.  Bit 0: the producers' (they wait at that barrier anyway); bit 1: the consumers',
                               // who then pass the barrier WITHOUT waiting for the reads (they wrote nothing to LDS in that phase).  3 with a
                               // waiting barrier measured 2.3 % slower (block 3 of the same file): the consumers arrive last, and later still.
@@ -512,7 +516,7 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
         // ---- group A: k-loop(it) with the epilogue of its rows 0..2 in phase X, row 3 in phase Y ----------------------
         // entries fetched one iteration ahead through the scalar cache: e_own = masks of step it, e_dma = rows of step it + 2
         uint4 e_own = load_a(0);
-        uint4 e_dma = load_a(2 <= nsteps + TW_PAD_STEPS - 1 ? 2 : nsteps + TW_PAD_STEPS - 1);
+        [[maybe_unused]] uint4 e_dma = load_a(2 <= nsteps + TW_PAD_STEPS - 1 ? 2 : nsteps + TW_PAD_STEPS - 1);
         int a6 = 0;                    // (4 * it) mod 6: A-ring position of the step's first input row
         int b10 = 0;                   // (4 * it) mod 10: B-ring position of the block written in iteration it
         // lane (p, cg) writes units of channel octet 2 wave + (cg >> 1): even cg V0 and V1, odd cg V2 and V3; the lanes of
@@ -534,7 +538,7 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
 #if TW_FLAGS & 2
             flag_wait(1, 4 * it);                  // the consumers' k-loop of iteration it - 1 (the raw rows of step it -> A-ring in it) is done
 #endif
-#if TW_DMA_LATE == 0
+#if TW_DMA_LATE == 0 && !TW_DMA_B && !defined(TW_ABL_NODMA)      // (TW_ABL_NODMA: CEILING EXPERIMENT, WRONG RESULTS -- no raw rows are fetched at all)
             issue_rows(e_dma, it & 1);             // raw rows of step it + 2 (slot it & 1: transformed one phase ago)
 #endif
             // what the epilogue of step it needs: the masks of a step at its plane's edge
@@ -641,14 +645,22 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
 #elif TW_DMA_LATE == 2
             if (it >= nsteps) issue_rows(e_dma, it & 1);       // (no k-loop in the last two iterations: their dummy rows all at once)
 #endif
+#if !TW_DMA_B
             e_dma = load_a(it + 3 <= nsteps + TW_PAD_STEPS - 1 ? it + 3 : nsteps + TW_PAD_STEPS - 1);
+#endif
             // the rows of step it + 1 (issued one iteration ago) are complete once only this phase's pieces are outstanding
             TW_STAMP(1);
 #if TW_FLAGS & 1
             if (wave == 0) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
             flag_signal(0);                        // this wave's k-loop is done and its pieces of step it + 1 have landed: no waiting here
 #else
+#if TW_DMA_B               // (the consumers wait for their own pieces)
+            group_barrier();
+#elif defined(TW_ABL_NOVM)   // CEILING EXPERIMENT, RESULTS NOT GUARANTEED: nobody waits for the raw rows' LDS-DMA
+            dma_barrier<63>();
+#else
             if (wave == 0) dma_barrier<5>(); else dma_barrier<4>();
+#endif
 #endif
             TW_STAMP(2);
 #if TW_XA > 0 && !defined(TW_XA_LAST)
@@ -733,8 +745,20 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
                 }
             };
         };
+#if TW_DMA_B
+        // the A half of step it + 2's entry (its input rows), fetched one iteration ahead like the producers' own entries
+        uint4 e_dma = load_a(2 <= nsteps + TW_PAD_STEPS - 1 ? 2 : nsteps + TW_PAD_STEPS - 1);
+        unsigned st_prev = 0;          // the previous iteration's epilogue ran (four stores behind that iteration's pieces)
+#endif
         for (int it = 0; it < niter; ++it) {
             TW_STAMP(0);
+#if TW_DMA_B
+            // Raw rows of step it + 2 -> slot it & 1, whose rows this group read (into registers) in the k-loop in front of barrier 2.
+            // They are read again in iteration it + 1's k-loop; every wave waits for ITS pieces in front of that iteration's barrier 1.
+            issue_rows(e_dma, it & 1);
+            e_dma = load_a(it + 3 <= nsteps + TW_PAD_STEPS - 1 ? it + 3 : nsteps + TW_PAD_STEPS - 1);
+            const unsigned st_cur = (unsigned)__builtin_amdgcn_readfirstlane((int)(it >= 2 ? (__builtin_amdgcn_readfirstlane(e_3.y) >> 24) & 1u : 0u));
+#endif
             if (it >= 2 && ((__builtin_amdgcn_readfirstlane(e_3.y) >> 24) & 1u)) {      // row 3 of step it - 2
                 auto sl3 = make_slice(e_3);
                 static_assert(TW_INROWS_B >= 0 && TW_INROWS_B <= 3, "rows 0 .. TW_INROWS_B - 1 ride in the k-loop");
@@ -756,6 +780,24 @@ __global__ __launch_bounds__(512, 2) void trunkw_kernel(TrunkwArgs a)
             bp = bp < 0 ? bp + TW_BROWS : bp;
             half8 pre[TW_PFF_B];
             TW_STAMP(1);
+#if TW_DMA_B
+            // The pieces of iteration it - 1 (the rows of step it + 1, read behind this barrier) have landed once nothing OLDER than what
+            // this wave has issued since is outstanding -- vmcnt counts a wave's loads and stores in order (tools/vmorder_bench.hip):
+            // the previous iteration's stores (4, if its epilogue ran), this iteration's pieces (5 on wave 0, 4 elsewhere) and stores.
+            {
+                const unsigned nst = st_prev + st_cur;
+                if (wave == 0) {
+                    if (nst == 2) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+                    else if (nst == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                } else {
+                    if (nst == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                    else if (nst == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                }
+                st_prev = st_cur;
+            }
+#endif
 #if TW_FLAGS & 1
             flag_wait(0, 4 * (it + 1));            // the producers' k-loop of this iteration is done, the raw rows of step it + 1 have landed
 #elif TW_PRE_BAR & 2
