@@ -177,9 +177,9 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
 #endif                        // it (one piece every eighth fragment).  Measured -8 % and -2 % (block 10): rows requested 1.35 periods ahead
                               // arrive in time, rows requested one period ahead do not -- the DMA's latency under this load is ~3 us
 #ifndef TW_DMA_B
-#define TW_DMA_B 1            // the CONSUMERS issue the LDS-DMA of step it + 2's raw rows, at the top of their phase X (their epilogue is the short
-#endif                        // side of that phase: ~600 ticks of slack), and wait for the rows of step it + 1 -- issued an iteration ago -- in front
-                              // of barrier 1 themselves; the producers' k-loop, the long side, starts at once (0: the producers issue, block 13)
+#define TW_DMA_B 5            // of a wave's five LDS-DMA pieces of step it + 2's raw rows, the CONSUMERS issue the first TW_DMA_B, at the top of their
+#endif                        // phase X (their epilogue was the short side of that phase: ~600 ticks of slack), the producers the rest; each group
+                              // waits for what it issued an iteration ago in front of barrier 1.  0: the producers issue everything (block 13)
 #ifndef TW_PRE_BAR
 #define TW_PRE_BAR 2          // a k-loop's first fragments (window row 0: written a period or more ago) are read in front of the barrier that
 #endif                        // opens its phase, not behind it.  Bit 0: the producers' (they wait at that barrier anyway); bit 1: the consumers',
@@ -260,7 +260,8 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
 #pragma unroll
     for (int i = 0; i < 3; ++i)
         dma_pc2[i] = tw_piece_const(2 * i, wave, lane) | (2 * i + 1 < 5 ? tw_piece_const(2 * i + 1, wave, lane) << 16 : 0u);
-    auto issue_rows = [&](const uint4 e, int slot) __attribute__((always_inline)) {
+    auto issue_rows = [&](const uint4 e, int slot, auto i0c, auto i1c) __attribute__((always_inline)) {
+        constexpr int I0 = decltype(i0c)::value, I1 = decltype(i1c)::value;      // pieces [I0, I1) of this wave's five
         const unsigned ey = __builtin_amdgcn_readfirstlane(e.y);
         const unsigned lo = __builtin_amdgcn_readfirstlane(e.x), hi = ey & 0xffu;
         const char* base = a.in_act + (((unsigned long long)hi << 32) | lo);
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
         // a folded step's raw columns 16.. come from the second plane (uniform branch: one strip in thirty-three)
         const unsigned fadd = ((ey >> 27) & 1u) ? (unsigned)__builtin_amdgcn_readfirstlane(e.w) : 0u;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
+        for (int i = I0; i < I1; ++i) {
             if (4 * i + wave >= TW_RAW_PIECES) continue;
             const unsigned pc = (dma_pc2[i >> 1] >> (16 * (i & 1))) & 0xffffu;
             // (a 24-bit multiply-add: hipcc's v_mad_u64_u32 for the plain expression takes an UNDEFINED register as the high half of
@@ -355,8 +356,8 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
     // fetched by waves 0 and 1 into the (still unused) B-ring and transformed into A-ring rows 0 and 1.
     const bool six = (__builtin_amdgcn_readfirstlane(e_first.y) >> 25) & 1u;
     if (grp == 0) {
-        issue_rows(e_first, 0);
-        issue_rows(e_second, 1);
+        issue_rows(e_first, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+        issue_rows(e_second, 1, std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
         if (six && wave < 2) {
             const unsigned lo = __builtin_amdgcn_readfirstlane(e_first.x), hi = __builtin_amdgcn_readfirstlane(e_first.y) & 0xffu;
             const int pitch = __builtin_amdgcn_readfirstlane(e_first.z) & 0xffffff;
@@ -538,8 +539,8 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
 #if TW_FLAGS & 2
             flag_wait(1, 4 * it);                  // the consumers' k-loop of iteration it - 1 (the raw rows of step it -> A-ring in it) is done
 #endif
-#if TW_DMA_LATE == 0 && !TW_DMA_B && !defined(TW_ABL_NODMA)      // (TW_ABL_NODMA: CEILING EXPERIMENT, WRONG RESULTS -- no raw rows are fetched at all)
-            issue_rows(e_dma, it & 1);             // raw rows of step it + 2 (slot it & 1: transformed one phase ago)
+#if TW_DMA_LATE == 0 && TW_DMA_B < 5 && !defined(TW_ABL_NODMA)      // (TW_ABL_NODMA: CEILING EXPERIMENT, WRONG RESULTS -- no raw rows are fetched at all)
+            issue_rows(e_dma, it & 1, std::integral_constant<int, TW_DMA_B>{}, std::integral_constant<int, 5>{});     // raw rows of step it + 2 (slot it & 1: transformed one phase ago)
 #endif
             // what the epilogue of step it needs: the masks of a step at its plane's edge
             const unsigned ey = __builtin_amdgcn_readfirstlane(e_own.y);
@@ -641,11 +642,11 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
                 __builtin_amdgcn_s_setprio(TW_PRIO_EA);
             }
 #if TW_DMA_LATE == 1
-            issue_rows(e_dma, it & 1);             // ... behind the k-loop: the producers wait at barrier 1 anyway
+            issue_rows(e_dma, it & 1, std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});     // ... behind the k-loop: the producers wait at barrier 1 anyway
 #elif TW_DMA_LATE == 2
-            if (it >= nsteps) issue_rows(e_dma, it & 1);       // (no k-loop in the last two iterations: their dummy rows all at once)
+            if (it >= nsteps) issue_rows(e_dma, it & 1, std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});       // (no k-loop in the last two iterations: their dummy rows all at once)
 #endif
-#if !TW_DMA_B
+#if TW_DMA_B < 5
             e_dma = load_a(it + 3 <= nsteps + TW_PAD_STEPS - 1 ? it + 3 : nsteps + TW_PAD_STEPS - 1);
 #endif
             // the rows of step it + 1 (issued one iteration ago) are complete once only this phase's pieces are outstanding
@@ -654,12 +655,13 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
             if (wave == 0) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
             flag_signal(0);                        // this wave's k-loop is done and its pieces of step it + 1 have landed: no waiting here
 #else
-#if TW_DMA_B               // (the consumers wait for their own pieces)
+#if TW_DMA_B >= 5          // (the consumers wait for their own pieces)
             group_barrier();
 #elif defined(TW_ABL_NOVM)   // CEILING EXPERIMENT, RESULTS NOT GUARANTEED: nobody waits for the raw rows' LDS-DMA
             dma_barrier<63>();
 #else
-            if (wave == 0) dma_barrier<5>(); else dma_barrier<4>();
+            // (this group's pieces of THIS iteration may stay in flight: 5 - TW_DMA_B on wave 0, one less elsewhere)
+            if (wave == 0) dma_barrier<5 - TW_DMA_B>(); else dma_barrier<(4 - TW_DMA_B > 0 ? 4 - TW_DMA_B : 0)>();
 #endif
 #endif
             TW_STAMP(2);
@@ -745,17 +747,17 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
                 }
             };
         };
-#if TW_DMA_B
+#if TW_DMA_B > 0
         // the A half of step it + 2's entry (its input rows), fetched one iteration ahead like the producers' own entries
         uint4 e_dma = load_a(2 <= nsteps + TW_PAD_STEPS - 1 ? 2 : nsteps + TW_PAD_STEPS - 1);
         unsigned st_prev = 0;          // the previous iteration's epilogue ran (four stores behind that iteration's pieces)
 #endif
         for (int it = 0; it < niter; ++it) {
             TW_STAMP(0);
-#if TW_DMA_B
+#if TW_DMA_B > 0
             // Raw rows of step it + 2 -> slot it & 1, whose rows this group read (into registers) in the k-loop in front of barrier 2.
             // They are read again in iteration it + 1's k-loop; every wave waits for ITS pieces in front of that iteration's barrier 1.
-            issue_rows(e_dma, it & 1);
+            issue_rows(e_dma, it & 1, std::integral_constant<int, 0>{}, std::integral_constant<int, (TW_DMA_B < 5 ? TW_DMA_B : 5)>{});
             e_dma = load_a(it + 3 <= nsteps + TW_PAD_STEPS - 1 ? it + 3 : nsteps + TW_PAD_STEPS - 1);
             const unsigned st_cur = (unsigned)__builtin_amdgcn_readfirstlane((int)(it >= 2 ? (__builtin_amdgcn_readfirstlane(e_3.y) >> 24) & 1u : 0u));
 #endif
@@ -780,20 +782,21 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
             bp = bp < 0 ? bp + TW_BROWS : bp;
             half8 pre[TW_PFF_B];
             TW_STAMP(1);
-#if TW_DMA_B
+#if TW_DMA_B > 0
             // The pieces of iteration it - 1 (the rows of step it + 1, read behind this barrier) have landed once nothing OLDER than what
             // this wave has issued since is outstanding -- vmcnt counts a wave's loads and stores in order (tools/vmorder_bench.hip):
-            // the previous iteration's stores (4, if its epilogue ran), this iteration's pieces (5 on wave 0, 4 elsewhere) and stores.
+            // the previous iteration's stores (4, if its epilogue ran), this iteration's pieces (TW_DMA_B; wave 0 has a fifth) and stores.
             {
+                constexpr int P0 = TW_DMA_B < 5 ? TW_DMA_B : 5, P = TW_DMA_B < 4 ? TW_DMA_B : 4;
                 const unsigned nst = st_prev + st_cur;
                 if (wave == 0) {
-                    if (nst == 2) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-                    else if (nst == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                    if (nst == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P0 + 8) : "memory");
+                    else if (nst == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P0 + 4) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P0) : "memory");
                 } else {
-                    if (nst == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                    else if (nst == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    if (nst == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P + 8) : "memory");
+                    else if (nst == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P + 4) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
                 }
                 st_prev = st_cur;
             }
