@@ -8,14 +8,17 @@ OUT=$REPO/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
 bash "$REPO/tools/collect_profiles.sh" "$TAG" > "$OUT/collect.log" 2>&1
 cd "$REPO"
-# same-box A/B against the previous build, when one was shipped beside the library (upscale_video_amd/libuva_prev.so)
+# same-box A/B against earlier kernels shipped beside the library: upscale_video_amd/libuva_prev.so = round 4's trunk kernel
+# (-DTW_RAW_INK=0 -DTW_PFF=6 -DTW_DMA_B=0 -DTW_PRE_BAR=0 -DUVA_NO_PK_F32= and, by UVA_TW_FOLD=0, its schedule without folded strips),
+# libuva_mid.so = the kernel of this round's first evidence set (-DTW_DMA_B=0 -DTW_PRE_BAR=0 -DUVA_NO_PK_F32=)
 if [ -f upscale_video_amd/libuva_prev.so ]; then
   P='import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], d["config"]["kernel_ms_per_frame"], d["roofline"]["frac"])'
+  VS="prev new"; [ -f upscale_video_amd/libuva_mid.so ] && VS="prev mid new"
   for wl in 2x_compact_1080p 4x_compact_1080p; do
     for i in 1 2 3; do
-      for v in prev new; do
-        L=$REPO/upscale_video_amd/libuva.so; [ $v = prev ] && L=$REPO/upscale_video_amd/libuva_prev.so
-        F=1; [ $v = prev ] && F=0       # (round 5: `prev` = round 4's trunk kernel -- -DTW_RAW_INK=0 -DTW_PFF=6 -- and its schedule: no folded strips)
+      for v in $VS; do
+        L=$REPO/upscale_video_amd/libuva.so; [ $v != new ] && L=$REPO/upscale_video_amd/libuva_$v.so
+        F=1; [ $v = prev ] && F=0
         echo -n "$wl $v: "; UVA_TW_FOLD=$F UVA_LIB_PATH=$L python bench.py --workload $wl --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | python -c "$P"
       done
     done

@@ -124,7 +124,9 @@ __device__ __forceinline__ uint4 scalar_load16(const uint4* p)
 // NO issue slot while the other wave's v_mfma_f32_16x16x32_f16 run back to back, and 0.7 per MFMA beside a k-loop with LDS reads,
 // where v_add_f32 / v_fma_f32 / v_pk_*_f16 / DPP moves get 2.3 (tools/coissue_bench.hip, profiles/r05_ab_results.txt block 13).
 // Two scalar instructions in place of one packed one: the same roundings, the same bytes.
+#ifndef UVA_NO_PK_F32         // (-DUVA_NO_PK_F32= : A/B builds with the packed instructions back)
 #define UVA_NO_PK_F32 __attribute__((target("no-packed-fp32-ops")))
+#endif
 
 __device__ __forceinline__ void group_barrier()
 {
