@@ -125,7 +125,11 @@ __device__ __forceinline__ uint4 scalar_load16(const uint4* p)
 // where v_add_f32 / v_fma_f32 / v_pk_*_f16 / DPP moves get 2.3 (tools/coissue_bench.hip, profiles/r05_ab_results.txt block 13).
 // Two scalar instructions in place of one packed one: the same roundings, the same bytes.
 #ifndef UVA_NO_PK_F32         // (-DUVA_NO_PK_F32= : A/B builds with the packed instructions back)
+#ifdef __HIP_DEVICE_COMPILE__ // (the host pass of hipcc does not know the feature and says so)
 #define UVA_NO_PK_F32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define UVA_NO_PK_F32
+#endif
 #endif
 
 __device__ __forceinline__ void group_barrier()

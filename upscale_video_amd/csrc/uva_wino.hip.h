@@ -180,6 +180,9 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
 #define TW_DMA_B 5            // of a wave's five LDS-DMA pieces of step it + 2's raw rows, the CONSUMERS issue the first TW_DMA_B, at the top of their
 #endif                        // phase X (their epilogue was the short side of that phase: ~600 ticks of slack), the producers the rest; each group
                               // waits for what it issued an iteration ago in front of barrier 1.  0: the producers issue everything (block 13)
+#ifndef TW_DEFER_A
+#define TW_DEFER_A 0          // 2: the producers finish rows 2 and 3 of a block at the top of the NEXT iteration (in front of their k-loop, where
+#endif                        // they wait for the consumers) instead of behind barrier 1 (where the consumers wait for them)
 #ifndef TW_PRE_BAR
 #define TW_PRE_BAR 2          // a k-loop's first fragments (window row 0: written a period or more ago) are read in front of the barrier that
 #endif                        // opens its phase, not behind it.  Bit 0: the producers' (they wait at that barrier anyway); bit 1: the consumers',
@@ -534,6 +537,10 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
 #if TW_PRE_BAR & 1
         prefetch(std::false_type{}, 0, pre);
 #endif
+#if TW_DEFER_A
+        unsigned ey_prev = 0;
+        int b10_prev = 0;
+#endif
         for (int it = 0; it < niter; ++it) {
             TW_STAMP(0);
 #if TW_FLAGS & 2
@@ -542,12 +549,20 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
 #if TW_DMA_LATE == 0 && TW_DMA_B < 5 && !defined(TW_ABL_NODMA)      // (TW_ABL_NODMA: CEILING EXPERIMENT, WRONG RESULTS -- no raw rows are fetched at all)
             issue_rows(e_dma, it & 1, std::integral_constant<int, TW_DMA_B>{}, std::integral_constant<int, 5>{});     // raw rows of step it + 2 (slot it & 1: transformed one phase ago)
 #endif
-            // what the epilogue of step it needs: the masks of a step at its plane's edge
+            // what the epilogue of a step needs: the masks of a step at its plane's edge, and where its block lies in the B-ring
+            // (set for the step whose rows are being finished: this one's, or -- TW_DEFER_A -- the previous one's)
             const unsigned ey = __builtin_amdgcn_readfirstlane(e_own.y);
-            const int rmask = (ey >> 8) & 15, c_lo = (ey >> 12) & 63, c_hi = (ey >> 18) & 63;
-            const int pm = ((ey >> 27) & 1u) ? (p & 7) : p;           // a folded step: each half's pairs count from its own plane's column
-            const bool in0 = 2 * pm >= c_lo && 2 * pm < c_hi, in1 = 2 * pm + 1 >= c_lo && 2 * pm + 1 < c_hi;
-            const bool edge = rmask != 15 || c_lo != 0 || c_hi != 32;
+            int rmask = 15, b10w = b10;
+            bool in0 = true, in1 = true, edge = false;
+            auto set_step = [&](const unsigned eyv, const int b10v) __attribute__((always_inline)) {
+                const int c_lo = (eyv >> 12) & 63, c_hi = (eyv >> 18) & 63;
+                rmask = (eyv >> 8) & 15;
+                const int pm = ((eyv >> 27) & 1u) ? (p & 7) : p;      // a folded step: each half's pairs count from its own plane's column
+                in0 = 2 * pm >= c_lo && 2 * pm < c_hi;
+                in1 = 2 * pm + 1 >= c_lo && 2 * pm + 1 < c_hi;
+                edge = rmask != 15 || c_lo != 0 || c_hi != 32;
+                b10w = b10v;
+            };
             auto slice = [&](RowSt& st, auto edge_tag, auto nc, auto kc) __attribute__((always_inline)) {
                 constexpr int n = decltype(nc)::value, k = decltype(kc)::value;
                 if constexpr (k == 0) fin_sum(st, n, 0);
@@ -581,7 +596,7 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
                     // no lane exchange: every lane stores its own four channels of V0..V3 as 8-byte pieces (2-way bank conflicts --
                     // eight even pairs onto four units -- and still 0.7 % faster than four v_permlane16_swap and two 16-byte stores
                     // per row: -DTW_W128, profiles/r04_ab_results.txt block 9)
-                    int pos = b10 + n;
+                    int pos = b10w + n;
                     pos = pos >= TW_BROWS ? pos - TW_BROWS : pos;
                     if (p < 15) {
                         char* const w0 = smem + w64 + (unsigned)pos * TW_BROWB;
@@ -604,7 +619,7 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
                     st.q[0] = s02a[0]; st.q[1] = s02b[0]; st.q[2] = s02a[1]; st.q[3] = s02b[1];
                     st.q[4] = s13a[0]; st.q[5] = s13b[0]; st.q[6] = s13a[1]; st.q[7] = s13b[1];
                 } else {
-                    int pos = b10 + n;
+                    int pos = b10w + n;
                     pos = pos >= TW_BROWS ? pos - TW_BROWS : pos;
                     char* const w0 = smem + wlane + (unsigned)pos * wrow;
                     *(uint4*)w0 = make_uint4(st.q[0], st.q[1], st.q[2], st.q[3]);
@@ -623,6 +638,23 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
 #endif
                 }
             };
+#if TW_DEFER_A
+            // Rows 2 and 3 of the PREVIOUS step's block: their accumulators are untouched since that k-loop, the consumers read them
+            // behind this iteration's barrier 1.  Here -- in front of the k-loop, beside the consumers' epilogue -- the producers have
+            // ~500 ticks to spare; behind barrier 1 their epilogue is the longer side of the phase.
+            if (it >= 1 && it <= nsteps) {
+                set_step(ey_prev, b10_prev);
+                auto late = [&](auto edge_tag) __attribute__((always_inline)) {
+                    static_for<8>([&](auto kc) __attribute__((always_inline)) {
+                        if constexpr (TW_DEFER_A == 2) slice(st2[0], edge_tag, std::integral_constant<int, 2>{}, kc);
+                        slice(st2[1], edge_tag, std::integral_constant<int, 3>{}, kc);
+                    });
+                };
+                if (edge) late(std::true_type{}); else late(std::false_type{});
+            }
+            ey_prev = ey; b10_prev = b10;
+#endif
+            set_step(ey, b10);
             if (it < nsteps) {
                 __builtin_amdgcn_s_setprio(TW_PRIO_KA);
                 // steps that touch their plane's edge (uniform, few) mask what lies outside
@@ -672,7 +704,8 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
                 // two rows at a time, slice by slice: neighbouring instructions are independent of each other
                 auto rest = [&](auto edge_tag) __attribute__((always_inline)) {
                     static_assert(TW_INROWS_A == 0 || TW_INROWS_A == 2, "rows are finished in pairs");
-                    static_for<(4 - TW_INROWS_A) / 2>([&](auto rc) __attribute__((always_inline)) {
+                    static_assert(TW_DEFER_A == 0 || ((TW_DEFER_A == 1 || TW_DEFER_A == 2) && TW_INROWS_A == 0), "one or two rows are deferred");
+                    static_for<(4 - TW_INROWS_A - TW_DEFER_A) / 2>([&](auto rc) __attribute__((always_inline)) {
                         static_for<8>([&](auto kc) __attribute__((always_inline)) {
                             slice(st2[0], edge_tag, std::integral_constant<int, TW_INROWS_A + 2 * decltype(rc)::value>{}, kc);
                             slice(st2[1], edge_tag, std::integral_constant<int, TW_INROWS_A + 2 * decltype(rc)::value + 1>{}, kc);
@@ -681,6 +714,8 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
 #endif
                         });
                     });
+                    if constexpr (TW_DEFER_A == 1)            // (row 2 on its own: row 3 waits for the next iteration)
+                        static_for<8>([&](auto kc) __attribute__((always_inline)) { slice(st2[0], edge_tag, std::integral_constant<int, 2>{}, kc); });
                 };
                 if (edge) rest(std::true_type{}); else rest(std::false_type{});     // (uniform: most steps lie inside their plane)
             }
