@@ -1033,7 +1033,8 @@ int ensure_device(uva_net* n)
                 for (int c = 0; c < g.convs[i].cin; ++c) sin[c] = g.slopes[i - 1][c] > 1.f ? -1.f : 1.f;
             if (i + 1 < g.convs.size())
                 for (int c = 0; c < g.convs[i].cout; ++c) sout[c] = g.slopes[i][c] > 1.f ? -1.f : 1.f;
-            for (int c = 0; c < g.convs[i].cout; ++c) bs[c] = sout[c] * g.convs[i].bias[c];
+            const int brow = g.convs[i].cout == 3 ? 4 : 1;       // (the last layer's channel j sits in MFMA row 4j: pack_sub16)
+            for (int c = 0; c < g.convs[i].cout; ++c) bs[brow * c] = sout[c] * g.convs[i].bias[c];
             std::vector<uint16_t> pks;
             pack_sub16(g.convs[i], pks, nullptr, nullptr, sin.data(), sout.data());
             if (upload(&dl.wpk_s10, pks.data(), pks.size() * 2, n->stream)) return 1;

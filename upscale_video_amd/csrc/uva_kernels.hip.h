@@ -1196,18 +1196,17 @@ __device__ __forceinline__ void sub10_row(const char* __restrict__ rin, char* __
         } else {
             // + input pixel (Interp x1 = identity, BinaryOp add; left in LDS by the head waves), *255, cv2 convertTo(CV_8U);
             // only rows that are written out and only the columns this strip gets right
-            if (emit && row_in && o == 0 && c >= S10_NL && c < S10_WC - S10_NL && X >= 0 && X < w) {
+            // (channel j is lane group j's first result register -- pack_sub16 -- : three groups, one byte each, one store)
+            if (emit && row_in && o < 3 && c >= S10_NL && c < S10_WC - S10_NL && X >= 0 && X < w) {
+#pragma clang fp contract(off)
                 const unsigned r8 = *(const unsigned*)(res + f * 16 * 4);
-                uint8_t* dp = dst + f * 16 * 3;
                 // v_cvt_pk_u8_f32 rounds half to even and saturates: cv2's convertTo(CV_8U) in one instruction
-                unsigned out = 0;
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const float r = (float)((r8 >> (8 * j)) & 0xff) * norm;
-                    const float v = acc[0][j] + r;
-                    out = __builtin_amdgcn_cvt_pk_u8_f32(v * 255.0f, j, out);
-                }
-                dp[0] = (uint8_t)out; dp[1] = (uint8_t)(out >> 8); dp[2] = (uint8_t)(out >> 16);
+                // (three roundings, as the oracle has them: x * (1/255), +, * 255.  Left alone hipcc contracts the first two into one
+                // v_fmac_f32 here and not in sub5_kernel, where the product is formed in another block: the two kernels then differ
+                // in three samples of a 300 x 700 frame)
+                const float r = (float)((r8 >> (8 * o)) & 0xff) * norm;
+                const float v = acc[0][0] + r;
+                dst[f * 16 * 3 + o] = (uint8_t)__builtin_amdgcn_cvt_pk_u8_f32(v * 255.0f, 0, 0u);
             }
         }
     };

@@ -340,6 +340,9 @@ void pack_sub16(const ConvWeights& c, std::vector<uint16_t>& out, int* ks_out, i
                 // the MFMA result (rows 4q..4q+3) owns two real channels instead of four or none
                 int co = 16 * mb + i;
                 if (c.cout == 24 && mb == 1) co = (i & 3) < 2 ? 16 + 2 * (i >> 2) + (i & 3) : -1;
+                // 3 output channels (the last layer): channel j in row 4j -- the first result register of lane group j --, so that
+                // three lane groups finish one channel each and ONE byte store per pixel fragment writes 48 consecutive bytes
+                if (c.cout == 3) co = (i & 3) == 0 && (i >> 2) < 3 ? (i >> 2) : -1;
                 if (co < 0 || co >= c.cout) continue;
                 for (int e = 0; e < 8; ++e) {
                     int tap, ci;

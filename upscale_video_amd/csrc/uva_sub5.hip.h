@@ -259,16 +259,13 @@ __device__ __forceinline__ void rowf(const char* __restrict__ rin, char* __restr
         } else {
             // + input pixel (Interp x1 = identity, BinaryOp add), *255, cv2 convertTo(CV_8U) = v_cvt_pk_u8_f32 (half to even,
             // saturating); only rows that are written out and only the columns this strip gets right
-            if (emit && row_in && o == 0 && c >= S5_NL && c < S5_WC - S5_NL && X >= 0 && X < w) {
-                uint8_t* dp = dst + f * 16 * 3;
-                unsigned out = 0;
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const float r = (float)((r8[f] >> (8 * j)) & 0xff) * norm;
-                    const float v = acc[0][j] + r;
-                    out = __builtin_amdgcn_cvt_pk_u8_f32(v * 255.0f, j, out);
-                }
-                dp[0] = (uint8_t)out; dp[1] = (uint8_t)(out >> 8); dp[2] = (uint8_t)(out >> 16);
+            // (channel j is lane group j's first result register -- pack_sub16 -- : three groups, one byte each, one store)
+            if (emit && row_in && o < 3 && c >= S5_NL && c < S5_WC - S5_NL && X >= 0 && X < w) {
+#pragma clang fp contract(off)
+                // (three roundings, as the oracle has them and as sub10_kernel has them: no contraction into an fma)
+                const float r = (float)r8[f] * norm;
+                const float v = acc[0][0] + r;
+                dst[f * 16 * 3 + o] = (uint8_t)__builtin_amdgcn_cvt_pk_u8_f32(v * 255.0f, 0, 0u);
             }
         }
     };
@@ -356,14 +353,14 @@ __device__ __forceinline__ void body(const Sub5Args& a, const Lds L, const int w
             uint8_t* const dst = a.dst + (size_t)yy * a.dst_stride + (size_t)(x0c + pix) * 3;
             unsigned r8[4] = {0, 0, 0, 0};
             if constexpr (TAIL) {
-                // the residual: this row's input pixels straight from the u8 frame (three bytes each, lanes o == 0), requested
-                // before the MFMAs and used behind them
-                if ((ye & 1) && row_in && o == 0) {
-                    const uint8_t* sp = a.src + (size_t)yy * a.src_stride + (size_t)(x0c + pix) * 3;
+                // the residual: this row's input pixels straight from the u8 frame (lane group o = channel o: one byte each),
+                // requested before the MFMAs and used behind them
+                if ((ye & 1) && row_in && o < 3) {
+                    const uint8_t* sp = a.src + (size_t)yy * a.src_stride + (size_t)(x0c + pix) * 3 + o;
 #pragma unroll
                     for (int f = F0; f < F1; ++f) {
                         const int X = x0c + 16 * f + pix;
-                        if (X >= 0 && X < a.w) r8[f] = (unsigned)sp[f * 48] | ((unsigned)sp[f * 48 + 1] << 8) | ((unsigned)sp[f * 48 + 2] << 16);
+                        if (X >= 0 && X < a.w) r8[f] = (unsigned)sp[f * 48];
                     }
                 }
             }
