@@ -15,6 +15,23 @@ CASES = [("2x_Compact_Pretrain", 1080, 1920, 960), ("4x_Compact_Pretrain", 1080,
          ("4x_Compact_Pretrain", 720, 1280, 960), ("2x_Compact_Pretrain", 1000, 9, 0), ("2x_Compact_Pretrain", 540, 960, 240)]
 
 
+def cases():
+    """the fixed set, plus UVA_IDENTITY_RANDOM seeded random geometries (frame size, tile size: few-step and many-step workgroups)"""
+    out = list(CASES)
+    n = int(os.environ.get("UVA_IDENTITY_RANDOM", "0"))
+    if n:
+        import numpy as np
+        rng = np.random.default_rng(2026)
+        for _ in range(n):
+            stem = "4x_Compact_Pretrain" if rng.integers(0, 4) == 0 else "2x_Compact_Pretrain"
+            h, w = int(rng.integers(1, 700)), int(rng.integers(1, 900))
+            tile = int(rng.choice([0, 0, 32, 48, 64, 100, 240, 960]))
+            if tile and -(-h // tile) * -(-w // tile) > 64:      # (the library's limit: 64 tiles per frame)
+                tile = 240
+            out.append((stem, h, w, tile))
+    return out
+
+
 def child():
     sys.path.insert(0, ROOT)
     import numpy as np  # noqa: F401
@@ -23,7 +40,7 @@ def child():
     out = []
     nets = {}
     for rep in range(int(os.environ.get("UVA_IDENTITY_REPS", "2"))):
-        for k, (stem, h, w, tile) in enumerate(CASES):
+        for k, (stem, h, w, tile) in enumerate(cases()):
             if stem not in nets:
                 n = ncnn.Net()
                 n.set_vulkan_device(0)
