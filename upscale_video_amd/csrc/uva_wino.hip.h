@@ -197,6 +197,7 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
 #ifndef TW_PFF_B
 #define TW_PFF_B 6            // ... the consumers': the in-stream raw-row transform has the registers (7: 253, no faster; 8 spills; 4: -0.5 %)
 #endif
+    static_assert(TW_DMA_LATE == 0 || TW_DMA_B == 0, "TW_DMA_LATE moves the PRODUCERS' issue: build it with -DTW_DMA_B=0");
     constexpr int PFF_A = TW_PFF;                 // fragments read ahead of their MFMAs: an LDS read takes ~280 cycles to come back
                                                   // while four waves stream fragments, and an MFMA 16 (profiles/r04_ab_results.txt)
 
@@ -518,9 +519,12 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
     RowSt st2[2];
     if (grp == 0) {
         // ---- group A: k-loop(it) with the epilogue of its rows 0..2 in phase X, row 3 in phase Y ----------------------
-        // entries fetched one iteration ahead through the scalar cache: e_own = masks of step it, e_dma = rows of step it + 2
+        // entries fetched one iteration ahead through the scalar cache: e_own = masks of step it, e_dma = rows of step it + 2 (where the
+        // producers issue pieces of them: TW_DMA_B < 5)
         uint4 e_own = load_a(0);
-        [[maybe_unused]] uint4 e_dma = load_a(2 <= nsteps + TW_PAD_STEPS - 1 ? 2 : nsteps + TW_PAD_STEPS - 1);
+#if TW_DMA_B < 5
+        uint4 e_dma = load_a(2 <= nsteps + TW_PAD_STEPS - 1 ? 2 : nsteps + TW_PAD_STEPS - 1);
+#endif
         int a6 = 0;                    // (4 * it) mod 6: A-ring position of the step's first input row
         int b10 = 0;                   // (4 * it) mod 10: B-ring position of the block written in iteration it
         // lane (p, cg) writes units of channel octet 2 wave + (cg >> 1): even cg V0 and V1, odd cg V2 and V3; the lanes of
