@@ -73,3 +73,4 @@ def test_trunk_kernel_compiled_on_this_box_is_parity_green_and_byte_identical(tm
         with open(os.path.join(out_dir, "build_on_gpu_box.json"), "w") as f:
             json.dump(rec, f, indent=1)
     print(json.dumps(rec))
+
