@@ -15,8 +15,22 @@ CASES = [("2x_Compact_Pretrain", 1080, 1920, 960), ("4x_Compact_Pretrain", 1080,
          ("4x_Compact_Pretrain", 720, 1280, 960), ("2x_Compact_Pretrain", 1000, 9, 0), ("2x_Compact_Pretrain", 540, 960, 240)]
 
 
+HURR = "1x_HurrDeblur_SubCompact_nf24-nc8_244k_net_g"
+CASES_1X = [(HURR, 1080, 1920, 0), (HURR, 720, 1280, 0), (HURR, 300, 700, 0), (HURR, 61, 59, 0), (HURR, 1, 1, 0), (HURR, 9, 1000, 0),
+            (HURR, 1000, 9, 0), (HURR, 137, 241, 0), (HURR, 2160, 3840, 0), (HURR, 64, 60, 0), (HURR, 23, 121, 0), (HURR, 500, 180, 0)]
+
+
 def cases():
-    """the fixed set, plus UVA_IDENTITY_RANDOM seeded random geometries (frame size, tile size: few-step and many-step workgroups)"""
+    """the fixed set, plus UVA_IDENTITY_RANDOM seeded random geometries (frame size, tile size: few-step and many-step workgroups);
+    UVA_IDENTITY_1X=1: whole frames through the 1x net instead (sub10_kernel), UVA_IDENTITY_RANDOM more of them"""
+    if os.environ.get("UVA_IDENTITY_1X"):
+        out = list(CASES_1X)
+        n = int(os.environ.get("UVA_IDENTITY_RANDOM", "0"))
+        if n:
+            import numpy as np
+            rng = np.random.default_rng(2027)
+            out += [(HURR, int(rng.integers(1, 1200)), int(rng.integers(1, 2000)), 0) for _ in range(n)]
+        return out
     out = list(CASES)
     n = int(os.environ.get("UVA_IDENTITY_RANDOM", "0"))
     if n:

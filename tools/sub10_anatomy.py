@@ -23,7 +23,7 @@ mid = s[30:-30]
 period = np.diff(mid[:, 0, 0])
 print(f"  step period: median {np.median(period):.0f} min {period.min()} max {period.max()}")
 print("  wave: start skew | start -> at the barrier (the row's work) | barrier wait (next start - arrival)   [medians over the steady part]")
-print("  (waves 0-7: trunk layers 1-8; 8, 9: the two halves of the first layer; 10, 11: of the last)")
+print("  (waves 0-7: trunk layers 1-8; S10_BAL builds: 8, 9 the two halves of the last layer, 10, 11 of the first; before: the other way round)")
 for w in range(12):
     st = mid[:-1, w, 0]; br = mid[:-1, w, 2]; nx = mid[1:, w, 0]
     print(f"  {w:2d}: {np.median(st - mid[:-1, :, 0].min(axis=1)):6.0f} | {np.median(br - st):6.0f} | {np.median(nx - br):6.0f}")

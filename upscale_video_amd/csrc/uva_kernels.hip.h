@@ -1166,7 +1166,7 @@ __host__ __device__ constexpr int sub10_dy(int ks, int o) { return ((SUB16_OCTET
 // meanwhile.  Measured and dropped (profiles/r02_sub10_experiments.txt): epilogue arithmetic pinned between the MFMAs,
 // the first operands of the next row fetched before the barrier, a half-step phase shift between the SIMD's two trunk
 // waves, 8-byte reads with swapped halves instead of the conflict-free 16-byte ones.
-template <bool TAIL, int F0, int F1, bool MASKED, int KS, int MB>
+template <bool TAIL, int F0, int F1, int CSH, bool MASKED, int KS, int MB>
 __device__ __forceinline__ void sub10_row(const char* __restrict__ rin, char* __restrict__ px0, char* __restrict__ px1,
                                           const char* __restrict__ res, uint8_t* __restrict__ dst, const unsigned (&adr)[KS],
                                           const half8 (&wgt)[KS][MB], const f32x4 (&binit)[2], const Sub10Prm& q, const int x0c,
@@ -1189,7 +1189,7 @@ __device__ __forceinline__ void sub10_row(const char* __restrict__ rin, char* __
         }
     };
     auto epi = [&](const int f, const f32x4 (&acc)[MB]) {
-        const int c = 16 * f + pix, X = x0c + c;
+        const int c = 16 * f + CSH + pix, X = x0c + c;          // (CSH: the caller's pointers already point CSH columns on)
         if constexpr (!TAIL) {
             // PReLU, zero outside the plane, fp16 -> this layer's ring row (ring column = computed column + 1)
             sub10_store<MASKED>(acc[0], acc[MB - 1], q, px0 + f * 16 * S10_PIXB, px1 + f * 16 * S10_PIXB, row_in && X >= 0 && X < w);
@@ -1212,16 +1212,25 @@ __device__ __forceinline__ void sub10_row(const char* __restrict__ rin, char* __
     };
     f32x4 a0[MB], a1[MB];
     if constexpr (F1 - F0 == 5) {
-        mma(0, a0);
-        mma(1, a1);
-        epi(0, a0);
-        mma(2, a0);
-        epi(1, a1);
-        mma(3, a1);
-        epi(2, a0);
-        mma(4, a0);
-        epi(3, a1);
-        epi(4, a0);
+        mma(F0, a0);
+        mma(F0 + 1, a1);
+        epi(F0, a0);
+        mma(F0 + 2, a0);
+        epi(F0 + 1, a1);
+        mma(F0 + 3, a1);
+        epi(F0 + 2, a0);
+        mma(F0 + 4, a0);
+        epi(F0 + 3, a1);
+        epi(F0 + 4, a0);
+    } else if constexpr (F1 - F0 == 4) {
+        mma(F0, a0);
+        mma(F0 + 1, a1);
+        epi(F0, a0);
+        mma(F0 + 2, a0);
+        epi(F0 + 1, a1);
+        mma(F0 + 3, a1);
+        epi(F0 + 2, a0);
+        epi(F0 + 3, a1);
     } else if constexpr (F1 - F0 == 3) {
         mma(F0, a0);
         mma(F0 + 1, a1);
@@ -1230,6 +1239,7 @@ __device__ __forceinline__ void sub10_row(const char* __restrict__ rin, char* __
         epi(F0 + 1, a1);
         epi(F0 + 2, a0);
     } else {
+        static_assert(F1 - F0 == 2, "fragment counts 2..5");
         mma(F0, a0);
         mma(F0 + 1, a1);
         epi(F0, a0);
@@ -1237,7 +1247,8 @@ __device__ __forceinline__ void sub10_row(const char* __restrict__ rin, char* __
     }
 }
 
-template <bool TAIL, int F0, int F1>
+// CSH: the wave's fragments cover computed columns CSH + 16 F0 .. CSH + 16 F1 - 1 (see S10_BAL at the kernel)
+template <bool TAIL, int F0, int F1, int CSH = 0>
 __device__ __forceinline__ void sub10_body(const Sub10Args& a, const Sub10Lds L, const int wave, const int stage, const int lane,
                                            const int nrows, const int nsteps)
 {
@@ -1260,7 +1271,7 @@ __device__ __forceinline__ void sub10_body(const Sub10Args& a, const Sub10Lds L,
         const int oct = min((int)(o == 0 ? SUB16_OCTET[ks][0] : o == 1 ? SUB16_OCTET[ks][1] : o == 2 ? SUB16_OCTET[ks][2] : SUB16_OCTET[ks][3]), 26);
         const int tap = oct / 3;
         // the wave's first row is d = 0 (at step t = lag): tap row dy reads ring row (dy - 1) & 3
-        adr[ks] = in_ring + ((tap / 3 - 1) & 3) * S10_ROWB + (tap % 3 + pix) * S10_PIXB + (oct % 3) * 16;
+        adr[ks] = in_ring + ((tap / 3 - 1) & 3) * S10_ROWB + (tap % 3 + pix + CSH) * S10_PIXB + (oct % 3) * 16;
     }
     const float* const myprm = L.prm + stage * 96;
     const Sub10Prm q = sub10_params(myprm, o);
@@ -1275,14 +1286,14 @@ __device__ __forceinline__ void sub10_body(const Sub10Args& a, const Sub10Lds L,
             const int ye = __builtin_amdgcn_readfirstlane(desc.x), x0c = __builtin_amdgcn_readfirstlane(desc.y);
             const int yy = ye >> 1;
             const bool row_in = yy >= 0 && yy < a.h;
-            char* const px = out_ring + (d & 3) * S10_ROWB + (pix + 1) * S10_PIXB;
-            const char* const res = L.resring + ((d & (S10_RES_ROWS - 1)) * S10_ROWPX + pix + 1) * 4;
-            uint8_t* const dst = a.dst + (size_t)yy * a.dst_stride + (size_t)(x0c + pix) * 3;
+            char* const px = out_ring + (d & 3) * S10_ROWB + (pix + 1 + CSH) * S10_PIXB;
+            const char* const res = L.resring + ((d & (S10_RES_ROWS - 1)) * S10_ROWPX + pix + 1 + CSH) * 4;
+            uint8_t* const dst = a.dst + (size_t)yy * a.dst_stride + (size_t)(x0c + pix + CSH) * 3;
             if (!TAIL && row_in && x0c >= 0 && x0c + S10_WC <= a.w)
-                sub10_row<TAIL, F0, F1, false, KS, MB>(L.smem, px + 8 * o, px + 32 + 4 * o, res, dst, adr, wgt, binit, q, x0c, a.w,
+                sub10_row<TAIL, F0, F1, CSH, false, KS, MB>(L.smem, px + 8 * o, px + 32 + 4 * o, res, dst, adr, wgt, binit, q, x0c, a.w,
                                                        row_in, (ye & 1) != 0, pix, o);
             else
-                sub10_row<TAIL, F0, F1, true, KS, MB>(L.smem, px + 8 * o, px + 32 + 4 * o, res, dst, adr, wgt, binit, q, x0c, a.w,
+                sub10_row<TAIL, F0, F1, CSH, true, KS, MB>(L.smem, px + 8 * o, px + 32 + 4 * o, res, dst, adr, wgt, binit, q, x0c, a.w,
                                                       row_in, (ye & 1) != 0, pix, o);
             // Next row: every address one ring row on, wrapping after the fourth.  Whether an address wraps depends only
             // on the window row dy its octet comes from -- ring row (d + dy - 1) & 3 now -- so the three increments are
@@ -1332,11 +1343,30 @@ __global__ __launch_bounds__(64 * S10_NW, 1) UVA_NO_PK_F32 void sub10_kernel(Sub
     // Waves w, w+4, w+8 share a SIMD: two trunk layers and one half of the first or the last layer each -- the same
     // MFMA and VALU load on all four.  (No s_setprio: with the light waves halved, raising them or the trunk waves
     // measured 2 % slower than leaving the arbiter alone, profiles/r02_sub10_experiments.txt.)
+#ifndef S10_BAL
+#define S10_BAL 1
+#endif
+#if S10_BAL
+    // Round 5 (profiles/r05_ab_results.txt block 19): only columns 10..69 of the last layer are stored, so trunk layer 8 is needed
+    // on columns 9..70 and layer 7 on 8..71 -- 64 columns, FOUR fragments at a column shift of 8 (an even number of 16-byte units:
+    // the conflict-free read recipe holds), where every layer computed all five.  The last layer likewise: four fragments, two per
+    // wave instead of three and two.  What a SIMD carries was 3 818 / 3 458 / 3 744 / 3 224 ticks per row (head 3 fragments, head 2,
+    // tail 3, tail 2 beside two five-fragment trunk waves each); now the tail halves sit beside the five-fragment layers (waves
+    // 8, 9) and the head halves beside the two four-fragment ones (waves 10, 11).  The rings' columns 0..7 and 72..79 of layers 7
+    // and 8 stay at the zeros the kernel starts with; what reads them is never stored.
+    if (wave < 6) sub10_body<false, 0, 5>(a, L, wave, wave + 1, lane, nrows, nsteps);
+    else if (wave < 8) sub10_body<false, 0, 4, 8>(a, L, wave, wave + 1, lane, nrows, nsteps);
+    else if (wave == 8) sub10_body<true, 0, 2, 8>(a, L, wave, S10_NL - 1, lane, nrows, nsteps);
+    else if (wave == 9) sub10_body<true, 2, 4, 8>(a, L, wave, S10_NL - 1, lane, nrows, nsteps);
+    else if (wave == 10) sub10_head<0>(a, L, wave, lane, nrows, nsteps);
+    else sub10_head<1>(a, L, wave, lane, nrows, nsteps);
+#else
     if (wave < 8) sub10_body<false, 0, 5>(a, L, wave, wave + 1, lane, nrows, nsteps);
     else if (wave == 8) sub10_head<0>(a, L, wave, lane, nrows, nsteps);
     else if (wave == 9) sub10_head<1>(a, L, wave, lane, nrows, nsteps);
     else if (wave == 10) sub10_body<true, 0, 3>(a, L, wave, S10_NL - 1, lane, nrows, nsteps);
     else sub10_body<true, 3, 5>(a, L, wave, S10_NL - 1, lane, nrows, nsteps);
+#endif
 }
 
 // ----------------------------------------------------------------------------------------------
