@@ -42,6 +42,11 @@ def test_every_pixel_written_once_with_its_halo(h, w):
             assert len(emit) >= 1
             assert emit[0] == NL and len(seg) - 1 - emit[-1] == NL, "warm-up / tail rows"
             assert (np.diff(emit) == 1).all()
+            # word 3: how far a row lies outside the rows that are written out (layer s of the net computes a row only where this
+            # is <= 9 - s: the kernel's waves skip what nobody reads) -- 10, 9, .., 1 above, 0 inside, 1, .., 10 below
+            k = np.arange(len(seg))
+            want = np.where(k < emit[0], emit[0] - k, np.where(k > emit[-1], k - emit[-1], 0))
+            assert (seg[:, 3] == want).all() and seg[0, 3] == NL and seg[-1, 3] == NL
             x0 = int(seg[0, 1])
             assert (x0 + NL) % VALID == 0
             y0, y1 = int(seg[emit[0], 0]), int(seg[emit[-1], 0]) + 1

@@ -733,8 +733,12 @@ int build_sub10_rows(int h, int w, int grid, std::vector<uint4>& rows, std::vect
         uint4* out = rows.data() + (size_t)b * D;
         int g = 0;
         for (const Seg& sg : per_wg[c])
-            for (int y = sg.y0 - S10_NL; y < sg.y0 + sg.n + S10_NL; ++y, ++g)
-                out[g] = make_uint4((unsigned)y, (unsigned)(sg.k * S10_VALID - S10_NL), (y >= sg.y0 && y < sg.y0 + sg.n) ? 1u : 0u, 0u);
+            for (int y = sg.y0 - S10_NL; y < sg.y0 + sg.n + S10_NL; ++y, ++g) {
+                // w = how many rows y lies outside the segment's own rows (0 inside, 1..10): layer s (0 = the first) is needed on rows
+                // with w <= 9 - s only, and the kernel's wave of that layer skips the others
+                const int dist = y < sg.y0 ? sg.y0 - y : y >= sg.y0 + sg.n ? y - (sg.y0 + sg.n - 1) : 0;
+                out[g] = make_uint4((unsigned)y, (unsigned)(sg.k * S10_VALID - S10_NL), dist == 0 ? 1u : 0u, (unsigned)dist);
+            }
         nrows[b] = g;
     }
     return 0;

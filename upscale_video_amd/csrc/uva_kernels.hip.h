@@ -934,6 +934,10 @@ constexpr int S10_PRMB = S10_NL * 96 * 4;        // per layer: bias[32], slope[3
 constexpr int S10_RES_ROWS = 32;                 // u8 input rows kept for the residual add: the last layer writes 29 rows behind
 constexpr int S10_RESB = S10_RES_ROWS * S10_ROWPX * 4;
 constexpr int S10_MAX_ROWS = 640;                // row descriptors of a workgroup, copied to LDS (8 B each)
+#ifndef S10_ROWSKIP
+#define S10_ROWSKIP 1                            // a layer's wave skips the rows nobody reads (round 5, block 20); 0: every layer computes every row
+#endif
+constexpr int S10_SKIP_ALL = 15 * 2;             // descriptor word of "no row": distance 15, which no layer takes
 constexpr int S10_DRAIN = 2 * S10_NL;            // steps after the last row went in until it has come out
 __host__ __device__ constexpr int sub10_lag(int stage) { return 2 * stage + 2; }
 constexpr int sub10_lds_bytes() { return (S10_NL - 1) * S10_RINGB + S10_URINGB + S10_PRMB + S10_RESB + S10_MAX_ROWS * 8; }
@@ -1072,7 +1076,7 @@ __device__ __forceinline__ void sub10_head(const Sub10Args& a, const Sub10Lds L,
         px = 0;
         if (r < nrows) {
             const int2 e = L.rows[r];
-            const int y = e.x >> 1, x0c = e.y;
+            const int y = e.x >> 5, x0c = e.y;
             const int qq = Q0 + lane, X = x0c - 1 + qq;
             if (lane < QN && y >= 0 && y < a.h && X >= 0 && X < a.w) {
                 const uint8_t* sp = a.src + (size_t)y * a.src_stride + (size_t)X * 3;
@@ -1084,10 +1088,11 @@ __device__ __forceinline__ void sub10_head(const Sub10Args& a, const Sub10Lds L,
         S10_STAMP(0);
         fetch_row(t + 1, upx_next);
         const int d = t - 2;
-        if (d >= 0 && d < nrows) {
-            const int2 e = L.rows[d];
-            const int ye = __builtin_amdgcn_readfirstlane(e.x), x0c = __builtin_amdgcn_readfirstlane(e.y);
-            const int y = ye >> 1;
+        int2 e = make_int2(S10_SKIP_ALL, 0);
+        if (d >= 0 && d < nrows) e = L.rows[d];
+        const int ye = __builtin_amdgcn_readfirstlane(e.x), x0c = __builtin_amdgcn_readfirstlane(e.y);
+        if (((ye >> 1) & 15) <= (S10_ROWSKIP ? S10_NL - 1 : 14)) {      // (rows ten away from what is written out are only fetched)
+            const int y = ye >> 5;
             const bool row_in = y >= 0 && y < a.h;
             unsigned rb[3];
 #pragma unroll
@@ -1264,6 +1269,7 @@ __device__ __forceinline__ void sub10_body(const Sub10Args& a, const Sub10Lds L,
     // per k-step: the LDS address this lane's K octet is read from.  They are kept for the row the wave works on next and
     // move one ring row per step.
     const int lag = sub10_lag(stage);
+    const int maxdist = S10_ROWSKIP ? S10_NL - 1 - stage : 14;
     const unsigned in_ring = (unsigned)(stage - 1) * S10_RINGB;
     unsigned adr[KS];
 #pragma unroll
@@ -1284,8 +1290,11 @@ __device__ __forceinline__ void sub10_body(const Sub10Args& a, const Sub10Lds L,
         const int d = t - lag;
         if (d >= 0 && d < nrows) {
             const int ye = __builtin_amdgcn_readfirstlane(desc.x), x0c = __builtin_amdgcn_readfirstlane(desc.y);
-            const int yy = ye >> 1;
+            const int yy = ye >> 5;
             const bool row_in = yy >= 0 && yy < a.h;
+            // rows further than 9 - stage from the nearest row that is written out are nobody's input (a segment's first and last
+            // rows: 2 stage + 2 of them per segment); the ring row keeps what it held
+            if (((ye >> 1) & 15) <= maxdist) {
             char* const px = out_ring + (d & 3) * S10_ROWB + (pix + 1 + CSH) * S10_PIXB;
             const char* const res = L.resring + ((d & (S10_RES_ROWS - 1)) * S10_ROWPX + pix + 1 + CSH) * 4;
             uint8_t* const dst = a.dst + (size_t)yy * a.dst_stride + (size_t)(x0c + pix + CSH) * 3;
@@ -1295,6 +1304,7 @@ __device__ __forceinline__ void sub10_body(const Sub10Args& a, const Sub10Lds L,
             else
                 sub10_row<TAIL, F0, F1, CSH, true, KS, MB>(L.smem, px + 8 * o, px + 32 + 4 * o, res, dst, adr, wgt, binit, q, x0c, a.w,
                                                       row_in, (ye & 1) != 0, pix, o);
+            }
             // Next row: every address one ring row on, wrapping after the fourth.  Whether an address wraps depends only
             // on the window row dy its octet comes from -- ring row (d + dy - 1) & 3 now -- so the three increments are
             // scalars; and in all but two k-steps (SUB16_OCTET) the four octet groups share one dy: one add each.
@@ -1322,12 +1332,13 @@ __global__ __launch_bounds__(64 * S10_NW, 1) UVA_NO_PK_F32 void sub10_kernel(Sub
     const int lane = threadIdx.x & 63;
     const int nrows = __builtin_amdgcn_readfirstlane(a.nrows[blockIdx.x]);
     if (nrows <= 0) return;
-    // this workgroup's row descriptors live in LDS, 8 bytes each: {2y + emit, x0}; every wave reads one (or two) per step
+    // this workgroup's row descriptors live in LDS, 8 bytes each: {32 y + 2 dist + emit, x0} (dist: rows between y and the nearest row
+    // of its segment that is written out, 0..10 -- layer s is needed where dist <= 9 - s); every wave reads one (or two) per step
     {
         const uint4* const grows = a.rows + (size_t)blockIdx.x * a.max_rows;
         for (int i = threadIdx.x; i < nrows; i += 64 * S10_NW) {
             const uint4 e = grows[i];
-            L.rows[i] = make_int2((int)e.x * 2 + (int)(e.z & 1), (int)e.y);
+            L.rows[i] = make_int2((int)e.x * 32 + (int)(e.w & 15u) * 2 + (int)(e.z & 1), (int)e.y);
         }
     }
     // rings start as zeros (margins and pipeline fill are never written: no NaN patterns may sit there)
