@@ -914,9 +914,10 @@ __global__ __launch_bounds__(256, 2) void pair24_kernel(ConvArgs a)
 // One 10-wave workgroup per CU is a systolic pipeline: WAVE s IS LAYER s.  Its weights (<= 56 registers) never
 // move; rows of an 80-column strip stream top to bottom through 4-row rings in LDS, one ring per layer output
 // (48 B per pixel), wave s reading rows r-1..r+1 of ring s-1 and writing row r of ring s, two rows behind wave s-1;
-// one workgroup barrier per row.  Every layer is computed on the full 80 columns; what is correct shrinks by one
-// column per side and layer, so 60 columns of the last layer are valid (the same happens at the top of a strip
-// segment: it starts 10 rows early).  Pixels outside the plane are written as zero by every layer (the next layer's
+// one workgroup barrier per row.  What is correct shrinks by one column per side and layer, so 60 of a strip's 80 columns
+// are valid in the last layer (the same happens at the top of a strip segment: it starts 10 rows early); a layer is
+// computed where a stored pixel needs it -- layers 1..6 on all five 16-column fragments, layers 7, 8 and the last on four
+// (S10_BAL), on the rows within reach of a stored row (S10_ROWSKIP).  Pixels outside the plane are written as zero by every layer (the next layer's
 // zero padding).  The head wave also loads the u8 rows (as [B,G,R,0] fp16, the 1/255 goes to the fp32 accumulator);
 // the tail wave adds the input pixel, *255, rounds half-even, saturates and stores 3 bytes per pixel.
 // ----------------------------------------------------------------------------------------------
