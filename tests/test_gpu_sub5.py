@@ -66,3 +66,17 @@ def test_other_frame_sizes_in_turn_reuse_nothing_stale(both, oracle):
     for _ in range(2):
         for f in frames:
             assert np.array_equal(split.process_u8(f, tile_size=0), whole.process_u8(f, tile_size=0))
+
+
+def test_seeded_random_geometries_equal_the_one_launch_kernel(both, oracle):
+    """sub10_kernel computes a layer only where a stored pixel needs it (round 5: four-fragment late layers, rows out of every
+    layer's reach skipped); sub5_kernel computes every column and row of its strips.  Forty seeded frame sizes -- workgroups with
+    one short segment, with several, with segments cut at a strip's end -- must give the same bytes from both."""
+    split, whole = both
+    rng = np.random.default_rng(20260929)
+    sizes = [(int(rng.integers(1, 1300)), int(rng.integers(1, 2000))) for _ in range(36)] + [(1300, 61), (2, 1999), (1199, 60), (257, 121)]
+    for k, (h, w) in enumerate(sizes):
+        img = oracle.synthetic_frame(h, w, kind="random" if k & 1 else "smooth", seed=1000 + k)
+        a = split.process_u8(img, tile_size=0)
+        b = whole.process_u8(img, tile_size=0)
+        assert np.array_equal(a, b), (h, w, int(np.abs(a.astype(int) - b.astype(int)).max()), float((a != b).mean()))
