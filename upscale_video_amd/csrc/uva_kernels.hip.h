@@ -1366,11 +1366,20 @@ __global__ __launch_bounds__(64 * S10_NW, 1) UVA_NO_PK_F32 void sub10_kernel(Sub
     // tail 3, tail 2 beside two five-fragment trunk waves each); now the tail halves sit beside the five-fragment layers (waves
     // 8, 9) and the head halves beside the two four-fragment ones (waves 10, 11).  The rings' columns 0..7 and 72..79 of layers 7
     // and 8 stay at the zeros the kernel starts with; what reads them is never stored.
+#ifndef S10_MAP
+#define S10_MAP 0       // A/B builds (block 22): 1 = the first layer's three-fragment half on wave 11 instead of 10; 2 = the four-fragment
+#endif                  // layers on the OLDER waves of their SIMDs (waves 2, 3 = layers 7, 8; waves 6, 7 = layers 3, 4)
+#if S10_MAP == 2
+    if (wave < 2 || wave == 4 || wave == 5) sub10_body<false, 0, 5>(a, L, wave, wave + 1, lane, nrows, nsteps);
+    else if (wave == 6 || wave == 7) sub10_body<false, 0, 5>(a, L, wave, wave - 3, lane, nrows, nsteps);
+    else if (wave == 2 || wave == 3) sub10_body<false, 0, 4, 8>(a, L, wave, wave + 5, lane, nrows, nsteps);
+#else
     if (wave < 6) sub10_body<false, 0, 5>(a, L, wave, wave + 1, lane, nrows, nsteps);
     else if (wave < 8) sub10_body<false, 0, 4, 8>(a, L, wave, wave + 1, lane, nrows, nsteps);
+#endif
     else if (wave == 8) sub10_body<true, 0, 2, 8>(a, L, wave, S10_NL - 1, lane, nrows, nsteps);
     else if (wave == 9) sub10_body<true, 2, 4, 8>(a, L, wave, S10_NL - 1, lane, nrows, nsteps);
-    else if (wave == 10) sub10_head<0>(a, L, wave, lane, nrows, nsteps);
+    else if (wave == (S10_MAP == 1 ? 11 : 10)) sub10_head<0>(a, L, wave, lane, nrows, nsteps);
     else sub10_head<1>(a, L, wave, lane, nrows, nsteps);
 #else
     if (wave < 8) sub10_body<false, 0, 5>(a, L, wave, wave + 1, lane, nrows, nsteps);
