@@ -637,7 +637,7 @@ def run(args, comm, device):
         layers_per_launch = (nconv - 2) * steps_timed / max(1, n_launch)      # 2 with the fused-pair kernels
         fused = layers_per_launch > 1.5
         # the fused pair runs as Winograd F(2,3) (trunkw_kernel) unless UVA_TRUNK_WINO=0 selects the direct trunk2_kernel
-        kernel = (("trunkw_kernel" if os.environ.get("UVA_TRUNK_WINO", "1") != "0" else "trunk2_kernel") if nf == 64 else "pair24_kernel") if fused else \
+        kernel = (("trunkw_kernel" if not (os.environ.get("UVA_DEBUG_SWITCHES") == "1" and os.environ.get("UVA_TRUNK_WINO", "1") == "0") else "trunk2_kernel") if nf == 64 else "pair24_kernel") if fused else \
                  ("trunk_kernel" if nf == 64 else "conv3x3_kernel")
         trunk_flops_per_launch = layers_per_launch * 2 * 9 * nf * nf * h * w        # algorithmic: un-tiled frame
         whole_net = nf == 24 and layers_per_launch > nconv - 2.5    # sub10_kernel: all ten convolutions of the 1x net in one launch

@@ -25,8 +25,10 @@ def product_flags(route="u8"):
     """The storage mode that restates the HIP path's rounding points: fp16 storage, and -- unless the product is run with
     UVA_TRUNK_WINO=0 (direct convolution, trunk2_kernel) or UVA_TRUNK_FUSION=0 -- the fused 64 -> 64 trunk pairs as
     Winograd F(2,3) (trunkw_kernel) with their PReLU on fp16 values (unless UVA_TW_ACT16=0).  No effect on the 24-feature net."""
-    wino = os.environ.get("UVA_TRUNK_WINO", "1") != "0" and os.environ.get("UVA_TRUNK_FUSION", "1") != "0"
-    act16 = wino and os.environ.get("UVA_TW_ACT16", "1") != "0"
+    dbg = os.environ.get("UVA_DEBUG_SWITCHES") == "1"      # the library ignores its switches without the opt-in; so does this
+    sw = (lambda name: os.environ.get(name, "1")) if dbg else (lambda name: "1")
+    wino = sw("UVA_TRUNK_WINO") != "0" and sw("UVA_TRUNK_FUSION") != "0"
+    act16 = wino and sw("UVA_TW_ACT16") != "0"
     return F16_STORAGE | (WINOGRAD_F23 if wino else 0) | (PRELU_F16 if act16 else 0) | (F16_INPUT if route == "f32" else 0)
 
 

@@ -8,6 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# libuva.so honours its A/B and debug switches (UVA_TRUNK_WINO, UVA_TW_FOLD, ...) only under this opt-in; the tests use them
+# (csrc/uva_devutil.hip.h debug_env; tests/test_host.py::test_debug_switches_need_the_opt_in checks the gate itself)
+os.environ["UVA_DEBUG_SWITCHES"] = "1"
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

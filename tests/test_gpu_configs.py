@@ -373,6 +373,36 @@ def test_config3_chain_at_1080p(uva, net2x, oracle_models, oracle):
         assert np.array_equal(d_out.cpu().numpy(), tiled)
 
 
+def test_config3_every_sample_at_1080p(uva, net2x, oracle_models, oracle):
+    """BASELINE config 3 as the reference runs it -- apply_model (1x, whole frame) -> u8 -> upscale_image (2x, 960/10 tiling) --
+    EVERY output sample of the 3840x2160 result against the fp32 oracle's chain on the host cores (~15 s), with the
+    structured-error question (no row or column of |diff| stands out: a seam, a strip fold, a plane edge would)."""
+    if oracle.cpu_quota() < 12:
+        pytest.skip("the fp32 oracle needs a many-core host for a whole 1080p frame")
+    from parity_report import check_u8, fp32_bar
+    pre = load_net(uva, "1x")
+    img = oracle.synthetic_frame(1080, 1920, seed=34)
+    mid = pre.process_u8(img, tile_size=0)
+    out = net2x.process_u8(mid, tile_size=960, border=10)
+    omid = oracle_models["1x"].apply_model(img)
+    check_u8("config 3: 1x stage, WHOLE 1080p frame, every sample", mid, omid, vs="fp32 oracle", model="1x", route="whole", **fp32_bar("1x", "whole"))
+    want = oracle_models["2x"].upscale_image(omid, tile_size=960, border=10)
+    check_u8("config 3: 1x -> u8 -> 2x (960/10), WHOLE 1080p frame, every sample", out, want, vs="fp32 oracle chain", model="chain", route="tiled",
+             **fp32_bar("chain", "tiled"))
+
+
+def test_config5_every_sample_of_the_2160p_frame(net2x, oracle_models, oracle):
+    """BASELINE config 5's frame, 3840x2160 -> 7680x4320 through the 960/10 tiling (12 planes, 5 seams, > 70 000 trunk steps):
+    EVERY output sample against the fp32 oracle's upscale_image (~45 s of the host's cores), structured-error question included."""
+    if oracle.cpu_quota() < 12:
+        pytest.skip("the fp32 oracle needs a many-core host for a whole 2160p frame")
+    from parity_report import check_u8, fp32_bar
+    img = oracle.synthetic_frame(2160, 3840, seed=55)
+    got = net2x.process_u8(img, tile_size=960, border=10)
+    want = oracle_models["2x"].upscale_image(img, tile_size=960, border=10)
+    check_u8("config 5: 2x (960/10), WHOLE 2160p frame, every sample", got, want, vs="fp32 oracle", model="2x", route="tiled", **fp32_bar("2x", "tiled"))
+
+
 def test_config4_valar_at_1080p(uva, tmp_path):
     """BASELINE config 4 as named, once at full size under pytest (throughput: tools/valar_bench.py): 4x_Valar_v1,
     synthetic weights (the real ones are a missing blob upstream), 1920x1080 -> 7680x4320 with the reference tiling.

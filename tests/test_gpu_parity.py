@@ -23,7 +23,7 @@ except Exception:  # noqa: BLE001
     torch = None
 
 from conftest import ROOT, load_net, psnr_u8
-from parity_report import check_f32, check_u8, record, slack
+from parity_report import check_f32, check_u8, fp32_bar, record, slack
 
 pytestmark = pytest.mark.gpu
 FP32 = "fp32 oracle"
@@ -108,7 +108,7 @@ def test_process_u8_whole_frame_matches_oracle(nets, oracle_models, oracle, key,
     want32 = om.apply_model(img)
     want16 = om.apply_model(img, flags=oracle.product_flags())
     assert got.shape == want32.shape and got.dtype == np.uint8
-    check_u8(f"{key} apply_model {w}x{h} {kind}", got, want32, vs=FP32, max_lsb=2, min_psnr=50, model=key, route="whole")
+    check_u8(f"{key} apply_model {w}x{h} {kind}", got, want32, vs=FP32, model=key, route="whole", **fp32_bar(key, "whole"))
     check_u8(f"{key} apply_model {w}x{h} {kind}", got, want16, vs=PRODUCT, max_lsb=1, max_share=U8_DIFFER(oracle, key, "whole"),
              model=key, route="whole")
 
@@ -150,7 +150,7 @@ def test_tiled_frame_matches_oracle_tiling(nets, oracle_models, oracle, key, h, 
     want32 = om.upscale_image(img, tile_size=ts, border=10)
     check_u8(f"{key} upscale_image {w}x{h} t{ts}", got, want16, vs=PRODUCT, max_lsb=1, max_share=U8_DIFFER(oracle, key, "tiled"),
              model=key, route="tiled")
-    check_u8(f"{key} upscale_image {w}x{h} t{ts}", got, want32, vs=FP32, max_lsb=2, min_psnr=50, model=key, route="tiled")
+    check_u8(f"{key} upscale_image {w}x{h} t{ts}", got, want32, vs=FP32, model=key, route="tiled", **fp32_bar(key, "tiled"))
 
 
 @pytest.mark.parametrize("key", ["2x", "4x"])
@@ -193,6 +193,37 @@ def test_folded_last_strips_change_no_bit(uva, nets, oracle, key, monkeypatch):
     for (img, t), w in zip(frames, want):
         got = nets[key].process_u8(img, tile_size=t, border=10)
         assert np.array_equal(got, w), (key, t, int(np.abs(got.astype(int) - w.astype(int)).max()), float((got != w).mean()))
+
+
+def test_structure_detector_catches_the_fold14_schedule(uva, nets, oracle, oracle_models, monkeypatch):
+    """VERDICT r5 item 1b.  Round 5's first folded-strip schedule (last strips of up to 14 columns share a walk: the last
+    producer pair then reads two raw columns of the OTHER plane) put one wrong column into every 74-wide plane and stayed inside
+    <= 2 LSB / >= 50 dB against the fp32 oracle.  UVA_TW_FOLD=14 (debug opt-in) rebuilds exactly that schedule; every full-size
+    comparison now also asks that no row or column of |HIP - oracle| stands out of its neighbourhood (parity_report.structure_u8),
+    and that question must FAIL on the bad schedule and pass on the shipped one -- against the fp32 oracle, which knows nothing
+    of the kernel's rounding."""
+    import parity_report
+    monkeypatch.setenv("UVA_TW_FOLD", "14")
+    bad = load_net(uva, "2x")             # (the schedule is built, and the switch read, when a geometry is first seen)
+    cases = [(oracle.synthetic_frame(128, 128, seed=31), 64), (oracle.synthetic_frame(384, 128, seed=32), 64),
+             (oracle.synthetic_frame(128, 128, seed=33, kind="random"), 64)]
+    bad_out = [bad.process_u8(img, tile_size=t, border=10) for img, t in cases]
+    monkeypatch.delenv("UVA_TW_FOLD")
+    for (img, t), b in zip(cases, bad_out):
+        want = oracle_models["2x"].upscale_image(img, tile_size=t, border=10)
+        good = nets["2x"].process_u8(img, tile_size=t, border=10)
+        assert not np.array_equal(good, b), "UVA_TW_FOLD=14 did not change the frame: the known-bad schedule is not being built"
+        st_good = check_u8(f"2x {img.shape[1]}x{img.shape[0]} t{t}: shipped schedule", good, want, vs=FP32, model="2x", route="tiled",
+                           **fp32_bar("2x", "tiled"))
+        d = np.abs(b.astype(np.int16) - want.astype(np.int16))
+        st = parity_report.structure_u8(d)
+        record(f"2x {img.shape[1]}x{img.shape[0]} t{t}: fold-14 schedule (KNOWN BAD, must be caught)", kind="u8", vs=FP32, model=None, route=None,
+               samples=int(d.size), max_lsb=int(d.max()), psnr_db=parity_report.psnr_u8(b, want), differ_share=float((d > 0).mean()),
+               bar_max_lsb=None, bar_min_psnr_db=None, bar_max_share=None, structure=st, bar_structure_z=parity_report.STRUCTURE_Z)
+        assert st["col_z"] > 2 * parity_report.STRUCTURE_Z, ("the detector does not see the wrong columns", st)
+        with pytest.raises(AssertionError, match="structured error"):
+            check_u8("fold-14 through the bars (recorded again on purpose)", b, want, vs=FP32 + " [expected to fail]", model=None, route=None,
+                     **fp32_bar("2x", "tiled"))
 
 
 @pytest.mark.parametrize("key", ["2x", "4x"])
@@ -238,8 +269,8 @@ def test_chain_1x_then_2x(nets, oracle_models, oracle):
     out = nets["2x"].process_u8(mid, tile_size=960, border=10)
     omid = oracle_models["1x"].apply_model(img)
     want = oracle_models["2x"].upscale_image(omid)
-    check_u8("chain: 1x stage 80x48", mid, omid, vs=FP32, max_lsb=2, min_psnr=50, model="1x", route="whole")
-    check_u8("chain: 1x -> u8 -> 2x 80x48", out, want, vs=FP32 + " chain", max_lsb=3, min_psnr=48, model="chain", route="tiled")
+    check_u8("chain: 1x stage 80x48", mid, omid, vs=FP32, model="1x", route="whole", **fp32_bar("1x", "whole"))
+    check_u8("chain: 1x -> u8 -> 2x 80x48", out, want, vs=FP32 + " chain", model="chain", route="tiled", **fp32_bar("chain", "tiled"))
 
 
 def test_row_strides_and_repeatability(nets, uva, oracle):
@@ -284,7 +315,7 @@ def test_full_size_frame_properties(nets, oracle_models, oracle, key):
         want = om.apply_model(crop)[(y0 - cy0) * s:(y0 - cy0 + win) * s, (x0 - cx0) * s:(x0 - cx0 + win) * s]
         got = whole[y0 * s:(y0 + win) * s, x0 * s:(x0 + win) * s]
         check_u8(f"{key} 1080p whole frame, window ({y0},{x0})", np.ascontiguousarray(got), np.ascontiguousarray(want), vs=FP32,
-                 max_lsb=2, min_psnr=50, model=key, route="whole")
+                 model=key, route="whole", **fp32_bar(key, "whole"))
     if s > 1:
         tiled = net.process_u8(img, tile_size=960, border=10)
         d = np.abs(tiled.astype(int) - whole.astype(int))
@@ -448,8 +479,8 @@ def test_random_geometries_match_oracle(nets, oracle_models, oracle, key):
         assert rc == 0, net._L.uva_last_error()
         got = dst[:, :w * s * 3].reshape(h * s, w * s, 3)
         assert (dst[:, w * s * 3:] == 0xA5).all(), (key, case, "row padding was written")
-        check_u8(f"{key} sweep case {case}: {w}x{h} t{ts}", np.ascontiguousarray(got), want, vs=FP32, max_lsb=2, min_psnr=50.0,
-                 model=key, route="tiled" if ts else "whole")
+        check_u8(f"{key} sweep case {case}: {w}x{h} t{ts}", np.ascontiguousarray(got), want, vs=FP32,
+                 model=key, route="tiled" if ts else "whole", **fp32_bar(key, "tiled" if ts else "whole"))
 
 
 @pytest.mark.parametrize("key", ["2x", "1x"])
@@ -489,15 +520,8 @@ def test_whole_1080p_frame_against_the_oracle(nets, oracle_models, oracle, key):
     got = nets[key].process_u8(img, tile_size=960, border=10)
     want = oracle_models[key].upscale_image(img, tile_size=960, border=10)
     assert got.shape == (1080 * s, 1920 * s, 3)
-    worst, nz, se = 0, 0, 0.0
-    for y in range(0, got.shape[0], 540):        # by bands: the 4x frames are 100 MB each
-        d = np.abs(got[y:y + 540].astype(np.int16) - want[y:y + 540].astype(np.int16))
-        worst, nz, se = max(worst, int(d.max())), nz + int((d > 0).sum()), se + float((d.astype(np.float64) ** 2).sum())
-    psnr = 10 * np.log10(255.0 ** 2 / (se / got.size)) if se else 99.0
-    print(f"whole 1080p frame, {key}: max |diff| {worst} LSB, PSNR {psnr:.2f} dB, {100 * nz / got.size:.3f} % of the samples differ")
-    record(f"{key} WHOLE 1080p frame, reference tiling 960/10, every sample", kind="u8", vs=FP32, model=key, route="tiled",
-           samples=int(got.size), max_lsb=worst, psnr_db=float(psnr), differ_share=nz / got.size, bar_max_lsb=2, bar_min_psnr_db=60.0,
-           bar_max_share=0.05)
-    assert worst <= 2, worst
-    assert psnr >= 60.0, psnr
-    assert nz / got.size < 0.05, nz / got.size
+    # bars: the measured distance of this frame (2x: 71.3 dB, 0.48 % of the samples one level apart; 4x: 69.9 dB, 0.66 %) less a
+    # margin, and no row or column standing out of its neighbourhood (parity_report.structure_u8)
+    worst, psnr, share = check_u8(f"{key} WHOLE 1080p frame, reference tiling 960/10, every sample", got, want, vs=FP32, max_lsb=1,
+                                  min_psnr={"2x": 69.3, "4x": 67.9}[key], max_share=0.02, model=key, route="tiled")
+    print(f"whole 1080p frame, {key}: max |diff| {worst} LSB, PSNR {psnr:.2f} dB, {100 * share:.3f} % of the samples differ")

@@ -11,7 +11,7 @@ except Exception:  # noqa: BLE001
     torch = None
 
 from conftest import load_net
-from parity_report import check_u8
+from parity_report import check_u8, fp32_bar
 
 pytestmark = pytest.mark.gpu
 FP32 = "fp32 oracle"
@@ -40,7 +40,7 @@ def test_two_launches_of_five_layers_give_the_bytes_of_the_one_launch_kernel(bot
     b = whole.process_u8(img, tile_size=0)
     assert np.array_equal(a, b), (h, w, int(np.abs(a.astype(int) - b.astype(int)).max()), float((a != b).mean()))
     if h * w <= 130 * 216:
-        check_u8(f"1x sub5_kernel {w}x{h} {kind}", a, oracle_models["1x"].apply_model(img), vs=FP32, max_lsb=2, min_psnr=50, model="1x", route="whole")
+        check_u8(f"1x sub5_kernel {w}x{h} {kind}", a, oracle_models["1x"].apply_model(img), vs=FP32, model="1x", route="whole", **fp32_bar("1x", "whole"))
 
 
 def test_full_size_frame_equals_the_one_launch_kernel_and_the_oracle_in_windows(both, oracle_models, oracle):

@@ -203,3 +203,33 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".h", ".hip")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "uvoracle" not in text and "liboracle" not in text and "oracle/" not in text, f
+
+
+def test_debug_switches_need_the_opt_in(uva):
+    """A stray UVA_* variable in a user's shell must not change what the drop-in library does: the A/B and
+    debug switches are read through csrc/uva_devutil.hip.h debug_env, which returns them only under UVA_DEBUG_SWITCHES=1 and
+    otherwise names the ignored variable once on stderr.  Observable without a GPU: the trunkw step lists of a frame whose
+    two 70-wide planes fold their last strips (host-only hook uva_debug_trunkw_schedule); UVA_TW_FOLD=0 un-folds them."""
+    import subprocess
+    import sys
+    code = ("import sys, hashlib; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from upscale_video_amd import ncnn\n"
+            "from test_trunkw_schedule import schedule\n"
+            "steps, nsteps, planes, guard = schedule(ncnn, 40, 120, 60, 10)\n"
+            "print(int(nsteps.sum()), hashlib.sha256(steps.tobytes()).hexdigest()[:16])\n") % (ROOT, os.path.join(ROOT, "tests"))
+
+    def run(**env):
+        e = {k: v for k, v in os.environ.items() if not k.startswith("UVA_")}
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        return r.stdout.split(), r.stderr
+    base, err = run()
+    assert "IGNORED" not in err
+    ignored, err = run(UVA_TW_FOLD="0", UVA_TRUNK_WINO="0")
+    assert ignored == base                                               # same step lists, byte for byte
+    assert err.count("UVA_TW_FOLD is set but IGNORED") == 1              # named, once
+    honoured, err = run(UVA_TW_FOLD="0", UVA_DEBUG_SWITCHES="1")
+    assert honoured != base and int(honoured[0]) > int(base[0]) and "IGNORED" not in err
+    again, _ = run(UVA_DEBUG_SWITCHES="1")
+    assert again == base

@@ -537,7 +537,7 @@ int build_trunkw_schedule(const std::vector<PlaneDesc>& planes, int grid, size_t
     // (profiles/r04_ab_results.txt block 20): segments at the TOP of a plane starting on two zero rows written by the consumers
     // -- with the six-row starts 73 -> 72 steps at the reference tiling, and the same launch time: a segment's fill step, in
     // which the consumers idle, costs about half a step.
-    const char* const sx = std::getenv("UVA_TW_SIX");
+    const char* const sx = uva::debug_env("UVA_TW_SIX");
     const int six_mode = sx ? (std::atoi(sx) != 0 ? 1 : 0) : -1;
     const bool top_ok = false;
     // FOLDED last strips (round 5).  A strip costs its 16 MFMA pair columns whatever its width, and 970 columns (the reference
@@ -551,14 +551,17 @@ int build_trunkw_schedule(const std::vector<PlaneDesc>& planes, int grid, size_t
     // transforms, k-loops) is pair-wise and does not care; what differs is where the raw rows come from and where the results
     // go: the second plane's addresses = the first's + a constant (entry .w = that constant - 2048, flags a.y bit 27 / b.y
     // bit 25; csrc/uva_wino.hip.h).  UVA_TW_FOLD=0: off.
-    const char* const sf = std::getenv("UVA_TW_FOLD");
+    // UVA_TW_FOLD=14 (debug opt-in only) is that first version, kept as the known-bad schedule the tests' structured-error
+    // detector must catch (tests/test_gpu_parity.py::test_structure_detector_catches_the_fold14_schedule).
+    const char* const sf = uva::debug_env("UVA_TW_FOLD");
     const bool fold_ok = !sf || std::atoi(sf) != 0;
+    const int fold_maxw = sf && std::atoi(sf) == 14 ? 14 : TW_FOLD_MAXW;
     std::vector<int> fold_partner(planes.size(), -1);
     std::vector<char> folded_away(planes.size(), 0);
     auto last_x0 = [](const PlaneDesc& p) { return ((p.w + TW_SW - 1) / TW_SW - 1) * TW_SW; };
     if (fold_ok)
         for (size_t i = 0; i < planes.size(); ++i) {
-            if (fold_partner[i] >= 0 || folded_away[i] || planes[i].w - last_x0(planes[i]) > TW_FOLD_MAXW) continue;
+            if (fold_partner[i] >= 0 || folded_away[i] || planes[i].w - last_x0(planes[i]) > fold_maxw) continue;
             for (size_t j = i + 1; j < planes.size(); ++j) {
                 if (fold_partner[j] >= 0 || folded_away[j]) continue;
                 const long long delta = ((long long)planes[j].act_off - (long long)planes[i].act_off) * PIXB;
@@ -884,7 +887,7 @@ int launch_pair24(uva_net* n, const ConvArgs& a)
 int launch_head(uva_net* n, bool f32, const HeadArgs& a)
 {
     // headp_kernel (persistent, the next tile's pixels requested while this one is computed) unless UVA_HEAD_PERSIST=0
-    const char* const hp = std::getenv("UVA_HEAD_PERSIST");        // (read per call: the GPU test switches it between two frames)
+    const char* const hp = uva::debug_env("UVA_HEAD_PERSIST");        // (read per call: the GPU test switches it between two frames)
     const bool persist = !hp || std::atoi(hp) != 0;
     if (persist && a.sink) {
         const dim3 grid(std::min(a.ntiles, n->ncu * HEADP_WG_PER_CU)), block(256);
@@ -939,14 +942,14 @@ int ensure_device(uva_net* n)
         ~Undo() { if (!n->dev_ready) n->free_device(); }
     } undo{n};
     HIP_TRY(hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking));
-    if (const char* e = std::getenv("UVA_TRUNK_FUSION")) n->fuse_pairs = std::atoi(e) != 0;
-    if (const char* e = std::getenv("UVA_TRUNK_WINO")) n->wino = std::atoi(e) != 0;
-    if (const char* e = std::getenv("UVA_TW_ACT16")) n->act16 = std::atoi(e) != 0;
-    if (const char* e = std::getenv("UVA_TW_CARRY")) n->carry = std::atoi(e) != 0;
-    if (const char* e = std::getenv("UVA_SUB10")) n->fuse_all = std::atoi(e) != 0;
-    if (const char* e = std::getenv("UVA_SUB5")) n->split5 = std::atoi(e) != 0;
-    if (const char* e = std::getenv("UVA_GENERIC_LDS")) n->generic_lds_conv = std::atoi(e) != 0;
-    if (const char* e = std::getenv("UVA_GENERIC_FUSE_ADD")) n->generic_fuse_add = std::atoi(e) != 0;
+    if (const char* e = uva::debug_env("UVA_TRUNK_FUSION")) n->fuse_pairs = std::atoi(e) != 0;
+    if (const char* e = uva::debug_env("UVA_TRUNK_WINO")) n->wino = std::atoi(e) != 0;
+    if (const char* e = uva::debug_env("UVA_TW_ACT16")) n->act16 = std::atoi(e) != 0;
+    if (const char* e = uva::debug_env("UVA_TW_CARRY")) n->carry = std::atoi(e) != 0;
+    if (const char* e = uva::debug_env("UVA_SUB10")) n->fuse_all = std::atoi(e) != 0;
+    if (const char* e = uva::debug_env("UVA_SUB5")) n->split5 = std::atoi(e) != 0;
+    if (const char* e = uva::debug_env("UVA_GENERIC_LDS")) n->generic_lds_conv = std::atoi(e) != 0;
+    if (const char* e = uva::debug_env("UVA_GENERIC_FUSE_ADD")) n->generic_fuse_add = std::atoi(e) != 0;
     HIP_TRY(hipMalloc((void**)&n->d_sink, 64 * 128 + 256));
     if (n->generic) {
         // generic graph: every convolution's MFMA image ([tap][cin/32][cout/16][lane][8]) and padded bias
@@ -1153,7 +1156,7 @@ int get_workspace(uva_net* n, int h, int w, int tile_size, int border, Workspace
                 }
         }
         ws.grid2 = std::max(8, (n->ncu / 8) * 8);
-        const char* const nv = std::getenv("UVA_T2_NARROW");      // (A/B switch: 0 = every strip computes both fragment columns)
+        const char* const nv = uva::debug_env("UVA_T2_NARROW");      // (A/B switch: 0 = every strip computes both fragment columns)
         if (build_trunk2_schedule(ws.planes, ws.grid2, ws.guard_bytes, steps2, nsteps2, &ws.max_steps2, !(nv && std::atoi(nv) == 0))) return 1;
         if (build_trunkw_schedule(ws.planes, ws.grid2, ws.guard_bytes, stepsw, nstepsw, &ws.max_stepsw)) return 1;
     }
@@ -1548,7 +1551,7 @@ struct PlaneJob {
 // and several of them per workgroup on frames small enough for the numpy restatement)
 inline int generic_grid(const uva_net* n)
 {
-    static const int forced = [] { const char* e = std::getenv("UVA_GENERIC_GRID"); return e ? std::atoi(e) : 0; }();
+    static const int forced = [] { const char* e = uva::debug_env("UVA_GENERIC_GRID"); return e ? std::atoi(e) : 0; }();
     return forced > 0 ? forced : std::max(8, (n->ncu / 8) * 8);
 }
 // (the strip kernels want 32 / 64 output columns at 1x, 2x or 4x the plane's width; a batch is planned with its narrowest
@@ -1633,7 +1636,7 @@ int generic_run_planes(uva_net* n, bool f32, const std::vector<PlaneJob>& jobs)
     // g_conv3_sw (the 192 -> 64 and 64 -> 64 convolutions on planes wide enough for its strips) also takes a SECOND sum
     // behind the first -- the `rrdb_in*1.0 + rdb_out*0.2` that closes every third dense block of 4x_Valar_v1
     // (models/4x_Valar_v1.param:55-56): the first sum's result then never goes to memory either.
-    static const bool sw_on = [] { const char* e = std::getenv("UVA_GENERIC_SW"); return !e || std::atoi(e) != 0; }();
+    static const bool sw_on = [] { const char* e = uva::debug_env("UVA_GENERIC_SW"); return !e || std::atoi(e) != 0; }();
     auto sw_cols_of = [&](size_t li) -> int {      // strip width g_conv3_sw would use for layer li on this plane, 0: not its case
         const GLayer& l = g.layers[li];
         if (!sw_on || !n->generic_lds_conv || l.kind != GLayer::CONV || l.ksize != 3) return 0;
@@ -1653,7 +1656,7 @@ int generic_run_planes(uva_net* n, bool f32, const std::vector<PlaneJob>& jobs)
         return -1;
     };
     std::vector<int> fuse_add2(g.layers.size(), -1), fuse_pos2(g.layers.size(), 0);
-    static const bool add2_on = [] { const char* e = std::getenv("UVA_GENERIC_FUSE_ADD2"); return !e || std::atoi(e) != 0; }();
+    static const bool add2_on = [] { const char* e = uva::debug_env("UVA_GENERIC_FUSE_ADD2"); return !e || std::atoi(e) != 0; }();
     if (n->generic_lds_conv && n->generic_fuse_add && add2_on) {
         std::vector<int> producer(g.blobs.size(), -1);
         std::vector<std::vector<int>> readers(g.blobs.size());
@@ -1681,7 +1684,7 @@ int generic_run_planes(uva_net* n, bool f32, const std::vector<PlaneJob>& jobs)
     // A nearest-neighbour 2x Interp whose only reader is a 64 -> 64 convolution of g_conv3_sw is folded into that
     // convolution's row DMA (g_conv3_sw<..., UP>): the enlarged array is never written (models/4x_Valar_v1.param:1000-1003:
     // at 4x it is 16x the 1x plane).  UVA_GENERIC_FUSE_INTERP=0: the Interp as a launch of its own, the A/B switch.
-    static const bool up_on = [] { const char* e = std::getenv("UVA_GENERIC_FUSE_INTERP"); return !e || std::atoi(e) != 0; }();
+    static const bool up_on = [] { const char* e = uva::debug_env("UVA_GENERIC_FUSE_INTERP"); return !e || std::atoi(e) != 0; }();
     std::vector<int> up_of(g.layers.size(), -1);
     if (up_on) {
         std::vector<int> producer(g.blobs.size(), -1);
@@ -1700,7 +1703,7 @@ int generic_run_planes(uva_net* n, bool f32, const std::vector<PlaneJob>& jobs)
     }
     // On the u8 route the graph's last convolution (3 output channels, no activation, no sum, g_conv3_lds) writes the frame's
     // bytes itself (GConvArgs::u8dst): no fp16 result array, no g_output_u8 launch.  UVA_GENERIC_FUSE_OUT=0: the A/B switch.
-    static const bool out_on = [] { const char* e = std::getenv("UVA_GENERIC_FUSE_OUT"); return !e || std::atoi(e) != 0; }();
+    static const bool out_on = [] { const char* e = uva::debug_env("UVA_GENERIC_FUSE_OUT"); return !e || std::atoi(e) != 0; }();
     int out_conv = -1;
     if (out_on && !f32 && n->generic_lds_conv) {
         for (size_t li = 0; li < g.layers.size(); ++li) {
@@ -1714,7 +1717,7 @@ int generic_run_planes(uva_net* n, bool f32, const std::vector<PlaneJob>& jobs)
     }
     // residual dense blocks whose first four convolutions run as one rdb4_kernel launch at the first one (UVA_GENERIC_RDB=0:
     // layer by layer, the A/B switch): the other six layers are bookkeeping only, and none of their sums is fused elsewhere
-    static const bool rdb_on = [] { const char* e = std::getenv("UVA_GENERIC_RDB"); return !e || std::atoi(e) != 0; }();
+    static const bool rdb_on = [] { const char* e = uva::debug_env("UVA_GENERIC_RDB"); return !e || std::atoi(e) != 0; }();
     std::vector<int> rdb_at(g.layers.size(), -1);
     std::vector<char> rdb_skip(g.layers.size(), 0);
     if (rdb_on && use_groups && wmin >= 16) {
@@ -1791,7 +1794,7 @@ int generic_run_planes(uva_net* n, bool f32, const std::vector<PlaneJob>& jobs)
             ra.slope = m.slope;
             ra.segs = plan.segs; ra.seg_begin = plan.seg_begin; ra.sink = n->d_sink;
 #ifdef UVA_INSTRUMENT
-            if (std::getenv("UVA_RDB_STAMPS")) {
+            if (uva::debug_env("UVA_RDB_STAMPS")) {
                 if (!n->gd.rdb_dbg) HIP_TRY(hipMalloc((void**)&n->gd.rdb_dbg, 1024 * 16 * 8));
                 HIP_TRY(hipMemsetAsync(n->gd.rdb_dbg, 0, 1024 * 16 * 8, n->stream));
                 ra.dbg = n->gd.rdb_dbg;
@@ -1863,7 +1866,7 @@ int generic_run_planes(uva_net* n, bool f32, const std::vector<PlaneJob>& jobs)
                 // 192 inputs: UVA_GENERIC_SK=1 takes g_conv3_sk (32x32x16 MFMAs, the k-loop split between wave pairs) instead of
                 // g_conv3_sw<6, 1>.  Measured equal within 1 % (profiles/r03_ab_results.txt, block 10: both sit at the package's
                 // power limit), so the simpler kernel stays the default; the other is kept runnable for the next round's work.
-                static const bool sk_on = [] { const char* e = std::getenv("UVA_GENERIC_SK"); return e && std::atoi(e) != 0; }();
+                static const bool sk_on = [] { const char* e = uva::debug_env("UVA_GENERIC_SK"); return e && std::atoi(e) != 0; }();
                 if (variant == 0 && sk_on) { if (launch_sw(g_conv3_sk<2, 0>, 32, sk_lds_bytes())) return 1; }
                 else if (variant == 1 && sk_on) { if (launch_sw(g_conv3_sk<2, 2>, 33, sk_lds_bytes())) return 1; }
                 else if (variant == 4 && sk_on) { if (launch_sw(g_conv3_sk<0, 0>, 34, sk_lds_bytes())) return 1; }
@@ -1917,10 +1920,10 @@ int generic_run_planes(uva_net* n, bool f32, const std::vector<PlaneJob>& jobs)
                 }
                 const int mbn = cd.cout_pad / 16;
                 // (UVA_GENERIC_WG=0: the 3x3 convolutions stage their weights through LDS again -- the A/B switch)
-                static const int wg_max = [] { const char* e = std::getenv("UVA_GENERIC_WG"); return e ? std::atoi(e) : 4; }();
+                static const int wg_max = [] { const char* e = uva::debug_env("UVA_GENERIC_WG"); return e ? std::atoi(e) : 4; }();
                 const bool wg = gl.ksize == 3 && mbn <= wg_max && (mbn == 2 || mbn == 4);
                 // 16-row tiles (8 waves) where the plane is tall enough to keep every CU busy with them
-                static const int nw_max = [] { const char* e = std::getenv("UVA_GENERIC_NW"); return e ? std::atoi(e) : 4; }();
+                static const int nw_max = [] { const char* e = uva::debug_env("UVA_GENERIC_NW"); return e ? std::atoi(e) : 4; }();
                 const int nw = (wg && nw_max >= 8 && (long long)((a.w + GC_TW - 1) / GC_TW) * ((a.h + 15) / 16) >= 4LL * n->ncu) ? 8 : 4;
                 const size_t lds = g_conv3_lds_bytes(cd.cin_pad, mbn, gl.ksize, wg, nw);
                 const dim3 g3((a.w + GC_TW - 1) / GC_TW, (a.h + 2 * nw - 1) / (2 * nw));
@@ -2053,8 +2056,8 @@ void generic_plan_batches(const std::vector<PlaneDesc>& planes, bool batch_on, l
 // (2.13 Mpixel) -- measured with 4x_Valar_v1 at 3840x2160 (12 planes), same bytes every way: this bound 0.343 s per frame
 // and 33 GB in use, 4.2 Mpixel 0.345 s and 61 GB, all planes in one batch 0.338 s and 64 GB, one plane after the other
 // 0.361 s and 33 GB
-bool generic_batch_on() { static const bool on = [] { const char* e = std::getenv("UVA_GENERIC_BATCH"); return !e || std::atoi(e) != 0; }(); return on; }
-long long generic_batch_pixels() { static const long long v = [] { const char* e = std::getenv("UVA_GENERIC_BATCH_PIXELS"); return e ? std::atoll(e) : 2200000ll; }(); return v; }
+bool generic_batch_on() { static const bool on = [] { const char* e = uva::debug_env("UVA_GENERIC_BATCH"); return !e || std::atoi(e) != 0; }(); return on; }
+long long generic_batch_pixels() { static const long long v = [] { const char* e = uva::debug_env("UVA_GENERIC_BATCH_PIXELS"); return e ? std::atoll(e) : 2200000ll; }(); return v; }
 
 // the u8 frame call for a generic graph: every reference tile (upscale_processing.py:499-516) is one plane; planes that
 // take the same kernels go through the graph together
@@ -2502,7 +2505,7 @@ int uva_net_load_param(uva_net* n, const char* path)
     n->gg = GenericGraph();
     std::string err;
     // UVA_GENERIC=1 (tests): run even the SRVGGNetCompact graphs through the generic executor
-    const char* force = std::getenv("UVA_GENERIC");
+    const char* force = uva::debug_env("UVA_GENERIC");
     if (!(force && std::atoi(force)) && parse_param(path, n->g, err)) return 0;
     // not the SRVGGNetCompact pattern the fused kernels are written for: the generic executor, if every layer
     // type is one it knows (4x_Valar_v1 is); otherwise the first parser's message stands

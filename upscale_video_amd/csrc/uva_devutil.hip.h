@@ -5,10 +5,38 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
 #include <type_traits>
 #include <utility>
 
 namespace uva {
+
+// Host side.  The library's A/B and debug switches (kernel choice, schedule variants, several of
+// which change the output bytes) are environment variables, and a drop-in library must not change its numerics because of
+// a stray variable in a user's shell: they are honoured only under the explicit opt-in UVA_DEBUG_SWITCHES=1 (the tests
+// and tools set it).  Without the opt-in a set switch is ignored and named once on stderr.
+inline const char* debug_env(const char* name)
+{
+    const char* const v = std::getenv(name);
+    if (!v) return nullptr;
+    static const bool opt_in = [] { const char* e = std::getenv("UVA_DEBUG_SWITCHES"); return e && std::strcmp(e, "1") == 0; }();
+    if (opt_in) return v;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    static char warned[32][40];
+    static int nwarned = 0;
+    for (int i = 0; i < nwarned; ++i)
+        if (std::strncmp(warned[i], name, sizeof warned[i] - 1) == 0) return nullptr;
+    if (nwarned < 32) {
+        std::strncpy(warned[nwarned], name, sizeof warned[0] - 1);
+        ++nwarned;
+        std::fprintf(stderr, "libuva: %s is set but IGNORED: debug switches need UVA_DEBUG_SWITCHES=1\n", name);
+    }
+    return nullptr;
+}
 
 // compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{}).
 // Used where a loop body must see its index as a constant expression (if constexpr, builtin

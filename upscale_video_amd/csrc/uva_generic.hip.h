@@ -496,7 +496,7 @@ inline void sw_segments(const std::vector<int>& dims, int cols, int grid, std::v
     // Several planes: like rdb_segments, a segment's start (two barriers and the wait for its first six rows) is counted as
     // SW_FILL blocks and the budget of blocks + starts is what the workgroups share evenly (UVA_RDB_DEAL=0: blocks alone).
     constexpr int SW_FILL = 1;
-    static const bool by_steps = [] { const char* e = std::getenv("UVA_RDB_DEAL"); return !e || std::atoi(e) != 0; }();
+    static const bool by_steps = [] { const char* e = uva::debug_env("UVA_RDB_DEAL"); return !e || std::atoi(e) != 0; }();
     if (by_steps && dims.size() > 2) {
         auto deal = [&](long long T, bool emit) -> int {
             size_t si = 0;
@@ -616,7 +616,7 @@ inline void rdb_segments(const std::vector<int>& dims, int grid, std::vector<Rdb
     // the others: the launch's tail).  A workgroup takes strip rows, in order, until its budget T is used up; T is the
     // smallest budget with which `grid` workgroups are enough.  UVA_RDB_DEAL=0: rows dealt evenly, the A/B switch.
     constexpr int RDB_FILL = 9;                // rdb4_kernel's RA_LAG
-    static const bool by_steps = [] { const char* e = std::getenv("UVA_RDB_DEAL"); return !e || std::atoi(e) != 0; }();
+    static const bool by_steps = [] { const char* e = uva::debug_env("UVA_RDB_DEAL"); return !e || std::atoi(e) != 0; }();
     auto deal = [&](long long T, bool emit) -> int {
         size_t si = 0;
         int y = 0, g = 0;
