@@ -6,7 +6,7 @@
  * this library, and only as the checker.  The product (upscale_video_amd/) never
  * links, imports or executes anything under oracle/.
  *
- * PARITY UNPINNED: the arithmetic of this path lives in the third-party,
+ * PARITY UNPINNED at the ncnn boundary (layer arithmetic); host logic pinned, see below.  The arithmetic of this path lives in the third-party,
  * un-vendored, un-pinned `ncnn_vulkan` wheel (reference README.md:29) and in
  * opencv-python; neither is installed here nor installable (no network), and the
  * reference holds no tests, golden vectors or fixtures for the path (SURVEY.md
@@ -26,6 +26,15 @@
  * It is cross-checked in this container against an independent torch-CPU
  * evaluation of the same .param/.bin (oracle/independent_check.py) and by loader
  * known-answer tests (byte-exact consumption of every .bin).
+ *
+ * Since round 6 the HOST LOGIC restated here (uvo_upscale_image_u8's 960/10
+ * windows and paste, uvo_apply_model_u8's pre/post steps, the u8 conversion) IS
+ * pinned by the reference's own code, executed: oracle/ref_host_fixtures.py
+ * imports /root/reference/upscale/upscale_processing.py unchanged under stand-in
+ * cv2 / ncnn_vulkan / wakepy modules, runs its upscale_image / process_tile /
+ * apply_model and writes tests/golden/ref_host.npz; tests/test_ref_host.py holds
+ * this file to those frames (equal except .5 ties).  What stays unpinned is the
+ * layer arithmetic (ncnn's published semantics, the wheel being absent).
  *
  * Arithmetic: fp32 throughout, one rounding per multiply and per add (build with
  * -ffp-contract=off), accumulation order bias, then ci-major / ky / kx.
