@@ -935,9 +935,7 @@ constexpr int S10_PRMB = S10_NL * 96 * 4;        // per layer: bias[32], slope[3
 constexpr int S10_RES_ROWS = 32;                 // u8 input rows kept for the residual add: the last layer writes 29 rows behind
 constexpr int S10_RESB = S10_RES_ROWS * S10_ROWPX * 4;
 constexpr int S10_MAX_ROWS = 640;                // row descriptors of a workgroup, copied to LDS (8 B each)
-#ifndef S10_ROWSKIP
 #define S10_ROWSKIP 1                            // a layer's wave skips the rows nobody reads (round 5, block 20); 0: every layer computes every row
-#endif
 constexpr int S10_SKIP_ALL = 15 * 2;             // descriptor word of "no row": distance 15, which no layer takes
 constexpr int S10_DRAIN = 2 * S10_NL;            // steps after the last row went in until it has come out
 __host__ __device__ constexpr int sub10_lag(int stage) { return 2 * stage + 2; }
@@ -988,26 +986,16 @@ __device__ __forceinline__ void sub10_barrier() { asm volatile("s_waitcnt lgkmcn
 // per-lane parameters of a 24-channel layer's epilogue: block 0 rows 4o..4o+3 = channels 4o..4o+3, block 1 rows
 // 4o, 4o+1 = channels 16+2o, 16+2o+1 (pack_sub16)
 struct Sub10Prm {
-#ifdef S10_ACT_F32
-    f32x4 s0;
-    f32x2 s1;
-#else
     half2v h[3];          // the slopes as packed halves
-#endif
 };
 __device__ __forceinline__ Sub10Prm sub10_params(const float* myprm, int o)
 {
     Sub10Prm q;
     const f32x4 s0 = *(const f32x4*)(myprm + 32 + 4 * o);
     const f32x2 s1 = *(const f32x2*)(myprm + 32 + 16 + 2 * o);
-#ifdef S10_ACT_F32
-    q.s0 = s0;
-    q.s1 = s1;
-#else
     q.h[0] = half2v{(_Float16)s0[0], (_Float16)s0[1]};
     q.h[1] = half2v{(_Float16)s0[2], (_Float16)s0[3]};
     q.h[2] = half2v{(_Float16)s1[0], (_Float16)s1[1]};
-#endif
     return q;
 }
 // PReLU (x already holds the bias) as max(x, slope*x) -- channels with a slope above 1 arrive negated, the host folded
@@ -1016,7 +1004,6 @@ template <bool MASKED>
 __device__ __forceinline__ void sub10_store(const f32x4 x0, const f32x4 x1, const Sub10Prm& q, char* px0, char* px1, bool inside)
 {
     const f32x2 xa = {x0[0], x0[1]}, xb = {x0[2], x0[3]}, xc = {x1[0], x1[1]};
-#ifndef S10_ACT_F32
     // on packed halves, like trunkw_kernel's TW_ACT_F16 (uva_wino.h): the sum rounded to fp16, times the fp16 slope, max of the
     // two -- nine instructions per fragment instead of twelve (-DS10_ACT_F32: the fp32 form below)
     const half2v ha = __builtin_convertvector(xa, half2v), hb = __builtin_convertvector(xb, half2v), hc = __builtin_convertvector(xc, half2v);
@@ -1024,20 +1011,6 @@ __device__ __forceinline__ void sub10_store(const f32x4 x0, const f32x4 x1, cons
     w0.x = __builtin_bit_cast(unsigned, __builtin_elementwise_max(ha, ha * q.h[0]));
     w0.y = __builtin_bit_cast(unsigned, __builtin_elementwise_max(hb, hb * q.h[1]));
     unsigned w1 = __builtin_bit_cast(unsigned, __builtin_elementwise_max(hc, hc * q.h[2]));
-#else
-    const f32x2 ya = xa * f32x2{q.s0[0], q.s0[1]}, yb = xb * f32x2{q.s0[2], q.s0[3]}, yc = xc * q.s1;
-    // max as med3(x, y, +inf), the +inf hidden from the optimiser in a scalar register: one instruction (fmaxf, and
-    // med3 with a visible constant, cost a second one that quiets signalling NaNs)
-    float inf = __builtin_inff();
-    asm("" : "+s"(inf));
-    const f32x2 va = {__builtin_amdgcn_fmed3f(xa[0], ya[0], inf), __builtin_amdgcn_fmed3f(xa[1], ya[1], inf)};
-    const f32x2 vb = {__builtin_amdgcn_fmed3f(xb[0], yb[0], inf), __builtin_amdgcn_fmed3f(xb[1], yb[1], inf)};
-    const f32x2 vc = {__builtin_amdgcn_fmed3f(xc[0], yc[0], inf), __builtin_amdgcn_fmed3f(xc[1], yc[1], inf)};
-    uint2 w0;
-    w0.x = __builtin_bit_cast(unsigned, __builtin_convertvector(va, half2v));
-    w0.y = __builtin_bit_cast(unsigned, __builtin_convertvector(vb, half2v));
-    unsigned w1 = __builtin_bit_cast(unsigned, __builtin_convertvector(vc, half2v));
-#endif
     if (MASKED && !inside) { w0 = make_uint2(0, 0); w1 = 0; }
     *(uint2*)px0 = w0;
     *(unsigned*)px1 = w1;
@@ -1355,10 +1328,7 @@ __global__ __launch_bounds__(64 * S10_NW, 1) UVA_NO_PK_F32 void sub10_kernel(Sub
     // Waves w, w+4, w+8 share a SIMD: two trunk layers and one half of the first or the last layer each -- the same
     // MFMA and VALU load on all four.  (No s_setprio: with the light waves halved, raising them or the trunk waves
     // measured 2 % slower than leaving the arbiter alone, profiles/r02_sub10_experiments.txt.)
-#ifndef S10_BAL
 #define S10_BAL 1
-#endif
-#if S10_BAL
     // Round 5 (profiles/r05_ab_results.txt block 19): only columns 10..69 of the last layer are stored, so trunk layer 8 is needed
     // on columns 9..70 and layer 7 on 8..71 -- 64 columns, FOUR fragments at a column shift of 8 (an even number of 16-byte units:
     // the conflict-free read recipe holds), where every layer computed all five.  The last layer likewise: four fragments, two per
@@ -1366,28 +1336,14 @@ __global__ __launch_bounds__(64 * S10_NW, 1) UVA_NO_PK_F32 void sub10_kernel(Sub
     // tail 3, tail 2 beside two five-fragment trunk waves each); now the tail halves sit beside the five-fragment layers (waves
     // 8, 9) and the head halves beside the two four-fragment ones (waves 10, 11).  The rings' columns 0..7 and 72..79 of layers 7
     // and 8 stay at the zeros the kernel starts with; what reads them is never stored.
-#ifndef S10_MAP
 #define S10_MAP 0       // A/B builds (block 22): 1 = the first layer's three-fragment half on wave 11 instead of 10; 2 = the four-fragment
-#endif                  // layers on the OLDER waves of their SIMDs (waves 2, 3 = layers 7, 8; waves 6, 7 = layers 3, 4)
-#if S10_MAP == 2
-    if (wave < 2 || wave == 4 || wave == 5) sub10_body<false, 0, 5>(a, L, wave, wave + 1, lane, nrows, nsteps);
-    else if (wave == 6 || wave == 7) sub10_body<false, 0, 5>(a, L, wave, wave - 3, lane, nrows, nsteps);
-    else if (wave == 2 || wave == 3) sub10_body<false, 0, 4, 8>(a, L, wave, wave + 5, lane, nrows, nsteps);
-#else
+                              // layers on the OLDER waves of their SIMDs (waves 2, 3 = layers 7, 8; waves 6, 7 = layers 3, 4)
     if (wave < 6) sub10_body<false, 0, 5>(a, L, wave, wave + 1, lane, nrows, nsteps);
     else if (wave < 8) sub10_body<false, 0, 4, 8>(a, L, wave, wave + 1, lane, nrows, nsteps);
-#endif
     else if (wave == 8) sub10_body<true, 0, 2, 8>(a, L, wave, S10_NL - 1, lane, nrows, nsteps);
     else if (wave == 9) sub10_body<true, 2, 4, 8>(a, L, wave, S10_NL - 1, lane, nrows, nsteps);
     else if (wave == (S10_MAP == 1 ? 11 : 10)) sub10_head<0>(a, L, wave, lane, nrows, nsteps);
     else sub10_head<1>(a, L, wave, lane, nrows, nsteps);
-#else
-    if (wave < 8) sub10_body<false, 0, 5>(a, L, wave, wave + 1, lane, nrows, nsteps);
-    else if (wave == 8) sub10_head<0>(a, L, wave, lane, nrows, nsteps);
-    else if (wave == 9) sub10_head<1>(a, L, wave, lane, nrows, nsteps);
-    else if (wave == 10) sub10_body<true, 0, 3>(a, L, wave, S10_NL - 1, lane, nrows, nsteps);
-    else sub10_body<true, 3, 5>(a, L, wave, S10_NL - 1, lane, nrows, nsteps);
-#endif
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -2233,9 +2189,7 @@ __global__ __launch_bounds__(512, 2) void tail_kernel(ConvArgs a)
     constexpr int KS = 18;                    // k-steps of 32: (tap, input-channel half)
     constexpr int CPW = TG::CPW;
     constexpr int SLOTB = TG::SLOTB;
-#ifndef TAIL_PFF
 #define TAIL_PFF 4
-#endif
     constexpr int PFF = TAIL_PFF;             // B fragments read ahead (an LDS read comes back after ~200-280 cycles, an MFMA issues in 16)
     constexpr int CPW_K = 8;                  // DMA pieces issued in the k-loop phase (the rest in the epilogue phase):
                                               // all 8 measured slightly better than 5 + 3
@@ -2422,9 +2376,7 @@ __global__ __launch_bounds__(512, 2) void tail_kernel(ConvArgs a)
                     acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[((Rr * 3 + dx) * 2) + ch], b, st == 0 ? zero4 : acc[0], 0, 0, 0);
                 if constexpr (Rr >= 1)    // output row 1, tap (dy = Rr - 1, dx)
                     acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[(((Rr - 1) * 3 + dx) * 2) + ch], b, st == 1 ? zero4 : acc[1], 0, 0, 0);
-#ifndef TAIL_NO_PIN
                 __builtin_amdgcn_sched_barrier(0);
-#endif
             });
             __builtin_amdgcn_s_setprio(0);
         }
@@ -2540,12 +2492,8 @@ __global__ __launch_bounds__(512, 2) void tail4_kernel(ConvArgs a)
     constexpr int R = 4, MB = TAIL4_MB;
     constexpr int CPW = TG::CPW;
     constexpr int SLOTB = TG::SLOTB;
-#ifndef TAIL4_PFF
 #define TAIL4_PFF 6
-#endif
-#ifndef TAIL4_AD
 #define TAIL4_AD 2
-#endif
     constexpr int PFF = TAIL4_PFF;            // B fragments read ahead
     constexpr int NSTEP = 24;
 
@@ -2715,9 +2663,7 @@ __global__ __launch_bounds__(512, 2) void tail4_kernel(ConvArgs a)
                     if constexpr (Rr >= 1)    // output row 1, tap (dy = Rr - 1, dx): the previous step's weights
                         acc[1][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aq[(st + AQ - 1) % AQ][m], b, st == 1 ? zero4 : acc[1][m], 0, 0, 0);
                 }
-#ifndef TAIL_NO_PIN
                 __builtin_amdgcn_sched_barrier(0);
-#endif
             });
             __builtin_amdgcn_s_setprio(0);
         }
@@ -2791,9 +2737,7 @@ __global__ __launch_bounds__(512, 2) void tail4_kernel(ConvArgs a)
 // accumulator.  SRC 1: f32 planar source (an ncnn::Mat the caller normalised), rounded to fp16.
 // K is laid out as [tap][4] (3 channels + 1 zero) -> 36, padded to 3 k-steps of 16.
 // ----------------------------------------------------------------------------------------------
-#ifndef HEAD_WPE
 #define HEAD_WPE 3            // waves per SIMD the register allocation aims at (= workgroups per CU: one wave per SIMD each)
-#endif
 template <int NF, int SRC>
 __global__ __launch_bounds__(256, HEAD_WPE) void head_kernel(HeadArgs a)
 {
@@ -2813,7 +2757,6 @@ __global__ __launch_bounds__(256, HEAD_WPE) void head_kernel(HeadArgs a)
     // (weights were fetched behind the pixel loop, whose iterations each waited for their own loads).  The kernel
     // writes 128 B per pixel and computes next to nothing: its time is the length of this chain divided by the
     // workgroups a CU holds (profiles/r04_ab_results.txt block 17).
-#ifndef HEAD_SERIAL_LOADS
     half8 w[3][MF];
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks)
@@ -2821,7 +2764,6 @@ __global__ __launch_bounds__(256, HEAD_WPE) void head_kernel(HeadArgs a)
         for (int m = 0; m < MF; ++m) w[ks][m] = a.wpk[(ks * MF + m) * 64 + lane];
     float prm_b = 0.f, prm_s = 0.f;
     if (threadIdx.x < MF * 32) { prm_b = a.bias[threadIdx.x]; prm_s = a.slope[threadIdx.x]; }
-#endif
     const PlaneDesc* gpl = a.planes;
     TileId id;
     id.plane = __builtin_amdgcn_readfirstlane(
@@ -2835,10 +2777,6 @@ __global__ __launch_bounds__(256, HEAD_WPE) void head_kernel(HeadArgs a)
         id.ty = local / ntx;
         id.tx = local - id.ty * ntx;
     }
-#ifdef HEAD_SERIAL_LOADS
-    float prm_b = 0.f, prm_s = 0.f;
-    if (threadIdx.x < MF * 32) { prm_b = a.bias[threadIdx.x]; prm_s = a.slope[threadIdx.x]; }
-#endif
     // the halo tile's pixels: 340 for 256 threads -- two per thread, both requested before either is used
     constexpr int PPT = (NPIX + 255) / 256;
     float pv[PPT][3];
@@ -2874,13 +2812,6 @@ __global__ __launch_bounds__(256, HEAD_WPE) void head_kernel(HeadArgs a)
             tile[p] = v;
         }
     }
-#ifdef HEAD_SERIAL_LOADS
-    half8 w[3][MF];
-#pragma unroll
-    for (int ks = 0; ks < 3; ++ks)
-#pragma unroll
-        for (int m = 0; m < MF; ++m) w[ks][m] = a.wpk[(ks * MF + m) * 64 + lane];
-#endif
     __syncthreads();
 
     f32x16 acc[2][MF];

@@ -26,27 +26,14 @@
 
 #include "uva_kernels.hip.h"
 
-#ifndef UVA_SW_D
 #define UVA_SW_D 3
-#endif
-#ifndef UVA_RA_D
 #define UVA_RA_D 2       // rdb4_kernel: k-steps (of 3 fragment reads) the reads run ahead of the MFMAs
-#endif
-#ifndef UVA_SK_DBG
 #define UVA_SK_DBG 0      // g_conv3_sk timing experiments only (results are wrong): 1 no epilogue, 2 no exchange, 4 no DMA
-#endif
-#ifndef UVA_SW_HALFREAD
 #define UVA_SW_HALFREAD 0
-#endif
-#ifndef UVA_SW_DBG
 #define UVA_SW_DBG 0
-#endif
-#ifndef UVA_SW_DBG_X
 #define UVA_SW_DBG_X 0     // CEILING EXPERIMENT (wrong results), with UVA_RA_DBG=1: g_conv3_sw<6,..> fetches the channels behind the first 64
-#endif                     // (x1..x4 of a dense block) from ONE fixed array row, i.e. from L2: together "x1..x4 never cross HBM"
-#ifndef UVA_RA_DBG
+                              // (x1..x4 of a dense block) from ONE fixed array row, i.e. from L2: together "x1..x4 never cross HBM"
 #define UVA_RA_DBG 0       // timing experiments only (results are wrong): 1 no HBM stores, 2 no epilogue, 4 no x DMA, 8 no hand-over
-#endif
 
 namespace uva {
 

@@ -31,9 +31,8 @@ namespace uva {
 namespace s5 {
 
 constexpr int NW = 12;
-#ifndef S5_TAIL_SPLIT
 #define S5_TAIL_SPLIT 1                          // part 1: the front wave (which also brings the rows of `mid` in: ~940 ticks per row) takes
-#endif                                           // fragments [0, S5_TAIL_SPLIT) of the last layer, the back wave the rest.  With 2 / 2 the front
+                              // fragments [0, S5_TAIL_SPLIT) of the last layer, the back wave the rest.  With 2 / 2 the front
                                                  // wave set the row period (3 840 against 2 900 ticks, profiles/r05_ab4_sub5_anatomy.txt)
 constexpr int ROWPX = S5_WC + 2;                 // ring row: one margin pixel either side
 constexpr int PIXB = 48;

@@ -103,26 +103,14 @@ __device__ __forceinline__ unsigned pk_add_f16(unsigned a, unsigned b)
 }
 
 // wave priorities inside the k-loops / everywhere else (A/B builds override them)
-#ifndef TW_PRIO_K
 #define TW_PRIO_K 2
-#endif
-#ifndef TW_PRIO_E
 #define TW_PRIO_E 0
-#endif
 // per group (A = waves 0-3, the producers; B = waves 4-7, the consumers, whose phases are the longer ones): k-loop / elsewhere.
 // The guide's "static priority for the younger half" is TW_PRIO_KB = TW_PRIO_EB = 1 with group A at 0 throughout.
-#ifndef TW_PRIO_KA
 #define TW_PRIO_KA TW_PRIO_K
-#endif
-#ifndef TW_PRIO_EA
 #define TW_PRIO_EA TW_PRIO_E
-#endif
-#ifndef TW_PRIO_KB
 #define TW_PRIO_KB TW_PRIO_K
-#endif
-#ifndef TW_PRIO_EB
 #define TW_PRIO_EB TW_PRIO_E
-#endif
 
 #ifdef UVA_INSTRUMENT
 #define TW_STAMP(k) do { if (stamp) a.dbg[16 * it + 8 * grp + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -135,94 +123,31 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
 {
     static_assert(NF == 64, "written for 64 features");
     constexpr int PIXB = 128;
-#ifndef TW_PFF
-#define TW_PFF 12             // fragments the producers' k-loop reads ahead of its MFMAs (6 until round 5: +0.3-0.6 % on two boxes, 254 VGPRs)
-#endif
-#ifndef TW_XA
-#define TW_XA 0               // raw rows of a step transformed by the PRODUCER group (0, 2 or 4; the consumers take the rest)
-#endif
-#ifndef TW_INROWS
-#define TW_INROWS 0           // rows of a block whose epilogue slices run inside the k-loop (A/B builds: 0..3)
-#endif
-#ifndef TW_INROWS_A
-#define TW_INROWS_A TW_INROWS // ... per group: the producers' / the consumers' rows
-#endif
-#ifndef TW_INROWS_B
-#define TW_INROWS_B TW_INROWS
-#endif
-#ifndef TW_RAW_INK
-#define TW_RAW_INK 1          // 1 (default since round 5): the consumers transform the next step's raw rows INSIDE their k-loop -- reads at
-#endif                        // fragment TW_RAW_F0, the four V rows of a channel half TW_RAW_GAP fragments later, one every TW_RAW_STRIDE
-#ifndef TW_RAW_F0             // fragments, then the other half.  Their serial chain epilogue -> raw rows -> k-loop was what a period was
-#define TW_RAW_F0 4           // made of, and the transform is two LDS round trips that nothing overlapped: +3.6-3.9 % frames/s on three boxes
-#endif                        // with 0 / 14 / 3 (profiles/r05_ab_results.txt block 1; 0 / 10 / 2: +2.2 %), another +0.6-0.8 % with the reads at
-#ifndef TW_RAW_GAP            // fragment 4 (4 / 12 / 3, block 10: the k-loop's own first fragments go first).  0: round 4's stand-alone
-#define TW_RAW_GAP 12         // transform in front of the k-loop.
-#endif
-#ifndef TW_RAW_STRIDE
-#define TW_RAW_STRIDE 3
-#endif
-#ifndef TW_FLAGS
-#define TW_FLAGS 0            // bit 0 / bit 1: barrier 1 / barrier 2 of an iteration becomes a ONE-DIRECTIONAL step counter in LDS.  What each barrier
-#endif                        // protects is one-sided: the consumers must not touch the A-ring or the raw slot before the producers' k-loop is done
-                              // and its rows have landed (barrier 1), the producers must not start their next k-loop before the consumers' k-loop
-                              // -- with the raw-row transform in it -- is done (barrier 2); the producers' epilogue and the consumers' epilogue
-                              // (registers -> B-ring block `it` / HBM) wait for nobody.  With s_barrier both groups wait for the other's TAIL
-                              // (~500 ticks per phase); with counters a group goes on to its epilogue at once and the tails overlap.
-#ifndef TW_FLAG_SLEEP
-#define TW_FLAG_SLEEP 1       // s_sleep argument between two looks at a counter (0: none)
-#endif
-#ifndef TW_DMA_LATE
-#define TW_DMA_LATE 0         // where the producers issue the LDS-DMA of step it + 2's raw rows: 0 in front of their k-loop, 1 behind it, 2 inside
-#endif                        // it (one piece every eighth fragment).  Measured -8 % and -2 % (block 10): rows requested 1.35 periods ahead
-                              // arrive in time, rows requested one period ahead do not -- the DMA's latency under this load is ~3 us
-#ifndef TW_DMA_B
-#define TW_DMA_B 5            // of a wave's five LDS-DMA pieces of step it + 2's raw rows, the CONSUMERS issue the first TW_DMA_B, at the top of their
-#endif                        // phase X (their epilogue was the short side of that phase: ~600 ticks of slack), the producers the rest; each group
-                              // waits for what it issued an iteration ago in front of barrier 1.  0: the producers issue everything (block 13)
-#ifndef TW_DEFER_A
-#define TW_DEFER_A 0          // 2: the producers finish rows 2 and 3 of a block at the top of the NEXT iteration (in front of their k-loop, where
-#endif                        // they wait for the consumers) instead of behind barrier 1 (where the consumers wait for them)
-#ifndef TW_PRE_BAR
-#define TW_PRE_BAR 2          // a k-loop's first fragments (window row 0: written a period or more ago) are read in front of the barrier that
-#endif                        // opens its phase, not behind it.  Bit 0: the producers' (they wait at that barrier anyway); bit 1: the consumers',
-                              // who then pass the barrier WITHOUT waiting for the reads (they wrote nothing to LDS in that phase).  3 with a
-                              // waiting barrier measured 2.3 % slower (block 3 of the same file): the consumers arrive last, and later still.
-#ifndef TW_RAW_GAP
-#define TW_RAW_GAP 10
-#endif
-#ifndef TW_RAW_STRIDE
-#define TW_RAW_STRIDE 2
-#endif
-#ifndef TW_PFF_B
-#define TW_PFF_B 6            // ... the consumers': the in-stream raw-row transform has the registers (7: 253, no faster; 8 spills; 4: -0.5 %)
-#endif
-    static_assert(TW_DMA_LATE == 0 || TW_DMA_B == 0, "TW_DMA_LATE moves the PRODUCERS' issue: build it with -DTW_DMA_B=0");
+    // Schedule constants.  Each is the survivor of a measured A/B (profiles/r04_ab_results.txt, r05_ab_results.txt); the
+    // variants that lost -- raw rows transformed by the producers (TW_XA), epilogue rows inside the k-loop (TW_INROWS), LDS step
+    // counters instead of barriers (TW_FLAGS), the producers' LDS-DMA issued late (TW_DMA_LATE) or by both groups (TW_DMA_B < 5),
+    // deferred producer rows (TW_DEFER_A), both groups pre-reading (TW_PRE_BAR = 3), 128-bit stores (TW_W128) and the two
+    // wrong-result ceiling experiments (TW_EXP_2D, TW_ABL_*) -- left this file in round 6: tools/experiments/tw_variants_r05.patch.
+    constexpr int TW_PFF = 12;        // fragments the producers' k-loop reads ahead of its MFMAs (an LDS read takes ~280 cycles to come
+                                      // back while four waves stream fragments, an MFMA 16; 6 until round 5: +0.3-0.6 %, 254 VGPRs)
+    constexpr int TW_PFF_B = 6;       // ... the consumers': the in-stream raw-row transform has the registers (7: no faster; 8 spills; 4: -0.5 %).
+                                      // The consumers read these first fragments (window row 0: written a period or more ago) in FRONT of the
+                                      // barrier that opens their phase and pass it without waiting for them; the producers read behind theirs.
+    // The consumers transform the next step's raw rows INSIDE their k-loop: four ds_read_b128 at fragment TW_RAW_F0, the four V rows of a
+    // channel half TW_RAW_GAP fragments later (an LDS round trip), one every TW_RAW_STRIDE fragments, then the other half.  Their serial
+    // chain epilogue -> raw rows -> k-loop was what a period was made of: +3.6-3.9 % on three boxes (0 / 14 / 3), +0.6-0.8 % more with
+    // the k-loop's own first fragments going first (4 / 12 / 3).
+    constexpr int TW_RAW_F0 = 4, TW_RAW_GAP = 12, TW_RAW_STRIDE = 3;
+    // Of a wave's five LDS-DMA pieces of step it + 2's raw rows the CONSUMERS issue all, at the top of their phase X (their epilogue was
+    // the short side of that phase: ~600 ticks of slack), and wait for what they issued an iteration ago in front of barrier 1: rows
+    // requested 1.35 periods ahead arrive in time, rows requested one period ahead do not (the DMA's latency under this load is ~3 us).
+    constexpr int TW_DMA_PIECES = 5;
     constexpr int PFF_A = TW_PFF;                 // fragments read ahead of their MFMAs: an LDS read takes ~280 cycles to come back
                                                   // while four waves stream fragments, and an MFMA 16 (profiles/r04_ab_results.txt)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = lds_offset(smem);
     float* const prm_all = (float*)(smem + TW_PRM);       // per layer: bias[64], slope[64], med3 selector[64]
-#if TW_FLAGS
-    // step counters: every wave of a group adds one when its part is done (its own LDS writes waited for first); the other group
-    // spins until all four have (a spin that never ends would hang the GPU: it traps instead after ~0.1 s)
-    auto flag_signal = [&](int which) __attribute__((always_inline)) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (threadIdx.x % 64 == 0) __hip_atomic_fetch_add((int*)(smem + TW_FLAGS_OFF) + which, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    auto flag_wait = [&](int which, int target) __attribute__((always_inline)) {
-        const volatile int* const f = (const volatile int*)(smem + TW_FLAGS_OFF) + which;
-        int spins = 0;
-        while (__builtin_amdgcn_readfirstlane(*f) < target) {
-#if TW_FLAG_SLEEP > 0
-            __builtin_amdgcn_s_sleep(TW_FLAG_SLEEP);
-#endif
-            if (++spins > (1 << 22)) __builtin_trap();
-        }
-        asm volatile("" ::: "memory");
-    };
-#endif
 
     const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int grp = wave8 >> 2;   // 0: producer (layer i), 1: consumer (layer i+1)
@@ -283,20 +208,6 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
             glds16_s(base, off, lds0 + TW_RAW + slot * TW_RAWSLOTB + (4 * i + wave) * 1024);
         }
     };
-    // one piece of the same (TW_DMA_LATE == 2: the pieces ride in the producers' k-loop, one every eighth fragment)
-    [[maybe_unused]] auto issue_piece = [&](const uint4 e, int slot, auto ic) __attribute__((always_inline)) {
-        constexpr int i = decltype(ic)::value;
-        if (4 * i + wave >= TW_RAW_PIECES) return;
-        const unsigned ey = __builtin_amdgcn_readfirstlane(e.y);
-        const unsigned lo = __builtin_amdgcn_readfirstlane(e.x), hi = ey & 0xffu;
-        const char* base = a.in_act + (((unsigned long long)hi << 32) | lo);
-        const int pitch = __builtin_amdgcn_readfirstlane(e.z) & 0xffffff;
-        const unsigned fadd = ((ey >> 27) & 1u) ? (unsigned)__builtin_amdgcn_readfirstlane(e.w) : 0u;
-        const unsigned pc = (dma_pc2[i >> 1] >> (16 * (i & 1))) & 0xffffu;
-        unsigned off = __umul24(pc >> 13, (unsigned)pitch) + (pc & 0x1fffu);
-        if (fadd) off += (pc & 0x1800u) ? fadd : 0u;
-        glds16_s(base, off, lds0 + TW_RAW + slot * TW_RAWSLOTB + (4 * i + wave) * 1024);
-    };
 
     // lane part of a transformed-row address, fragment / transform view (pair pq = lane & 15, K octet oq = lane >> 4): pair
     // record (64 B) + swizzled unit.  Recomputed from an opaque copy of the lane id where it is used: everything derived
@@ -341,13 +252,6 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
         *(half8*)(vrow + 2 * 2048) = pk_sub(d2, d1);
         *(half8*)(vrow + 3 * 2048) = pk_sub(d1, d3);
     };
-    // rows [2 first_pair, 2 first_pair + 2) of the slot: wave w takes half (w & 1) of row 2 first_pair + (w >> 1)
-    auto transform_pair = [&](int slot, int pos0, int first_pair) __attribute__((always_inline)) {
-        const int r = 2 * first_pair + (wave >> 1);
-        int pos = pos0 + r;
-        pos = pos >= TW_AROWS ? pos - TW_AROWS : pos;
-        transform_half(smem + TW_RAW + slot * TW_RAWSLOTB + r * TW_RAWROWB, pos, wave & 1);
-    };
 
     auto transform_rows = [&](int slot, int pos0) __attribute__((always_inline)) {
         int pos = pos0 + wave;
@@ -384,9 +288,6 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
         prm[64 + lane] = prm_s;
         prm[128 + lane] = prm_s <= 1.f ? __builtin_inff() : -__builtin_inff();
     }
-#if TW_FLAGS
-    if (threadIdx.x == 0) { ((int*)(smem + TW_FLAGS_OFF))[0] = 0; ((int*)(smem + TW_FLAGS_OFF))[1] = 0; }
-#endif
     group_barrier();                   // every A wave's pieces have landed (each waited for its own)
     if (grp == 1) {
         transform_rows(0, 2);          // (the consumer group fills the A-ring: see its loop)
@@ -424,7 +325,7 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
     };
     auto kloop = [&](auto ring_tag, int base_pos, auto&& slice, auto&& hook, [[maybe_unused]] const auto& pre) __attribute__((always_inline)) {
         constexpr bool BR = decltype(ring_tag)::value;
-        constexpr int INR = BR ? TW_INROWS_B : TW_INROWS_A;
+        constexpr int INR = 0;             // epilogue rows whose slices ride inside the k-loop (the variant that lost: 0)
         constexpr int ROWB = BR ? TW_BROWB : TW_AROWB, NROWS = BR ? TW_BROWS : TW_AROWS;
         constexpr int JS = ROWB / 4, CS = ROWB / 8;
         constexpr int PFF = BR ? TW_PFF_B : PFF_A;
@@ -445,7 +346,7 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int f = 0; f < PFF; ++f) {
-            if constexpr ((TW_PRE_BAR >> (BR ? 1 : 0)) & 1) bq[f] = pre[f];
+            if constexpr (BR) bq[f] = pre[f];       // (the consumers: read in front of the barrier)
             else bq[f] = read_f(f);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -456,11 +357,7 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
             const half8 b = bq[f % RQ];
             static_for<4>([&](auto nc) __attribute__((always_inline)) {
                 constexpr int n = decltype(nc)::value, dy = R - n;
-#ifdef TW_EXP_2D        // CEILING EXPERIMENT, WRONG RESULTS: the MFMA count of a 2-D Winograd F(2x2,3x3) k-loop (64 of the 96)
-                if constexpr (dy >= 0 && dy <= 2 && dy != 1) {
-#else
                 if constexpr (dy >= 0 && dy <= 2) {
-#endif
                     constexpr bool first = dy == 0 && ch == 0;
                     // M1 enters both results with a plus sign: its accumulator starts at the bias
                     acc[n][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[(j * 3 + dy) * 2 + ch], b, first ? (j == 1 ? bias4 : zero4) : acc[n][j], 0, 0, 0);
@@ -520,11 +417,8 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
     if (grp == 0) {
         // ---- group A: k-loop(it) with the epilogue of its rows 0..2 in phase X, row 3 in phase Y ----------------------
         // entries fetched one iteration ahead through the scalar cache: e_own = masks of step it, e_dma = rows of step it + 2 (where the
-        // producers issue pieces of them: TW_DMA_B < 5)
+        // producers would issue pieces of them: they issue none)
         uint4 e_own = load_a(0);
-#if TW_DMA_B < 5
-        uint4 e_dma = load_a(2 <= nsteps + TW_PAD_STEPS - 1 ? 2 : nsteps + TW_PAD_STEPS - 1);
-#endif
         int a6 = 0;                    // (4 * it) mod 6: A-ring position of the step's first input row
         int b10 = 0;                   // (4 * it) mod 10: B-ring position of the block written in iteration it
         // lane (p, cg) writes units of channel octet 2 wave + (cg >> 1): even cg V0 and V1, odd cg V2 and V3; the lanes of
@@ -538,23 +432,10 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
         const unsigned wrow = p < 15 ? (unsigned)TW_BROWB : 0u;      // (pair 15: every row and both units to the same spare place)
         const unsigned wj = p < 15 ? (unsigned)(TW_BROWB / 4) : 0u;
         half8 pre[PFF_A];
-#if TW_PRE_BAR & 1
-        prefetch(std::false_type{}, 0, pre);
-#endif
-#if TW_DEFER_A
-        unsigned ey_prev = 0;
-        int b10_prev = 0;
-#endif
         for (int it = 0; it < niter; ++it) {
             TW_STAMP(0);
-#if TW_FLAGS & 2
-            flag_wait(1, 4 * it);                  // the consumers' k-loop of iteration it - 1 (the raw rows of step it -> A-ring in it) is done
-#endif
-#if TW_DMA_LATE == 0 && TW_DMA_B < 5 && !defined(TW_ABL_NODMA)      // (TW_ABL_NODMA: CEILING EXPERIMENT, WRONG RESULTS -- no raw rows are fetched at all)
-            issue_rows(e_dma, it & 1, std::integral_constant<int, TW_DMA_B>{}, std::integral_constant<int, 5>{});     // raw rows of step it + 2 (slot it & 1: transformed one phase ago)
-#endif
             // what the epilogue of a step needs: the masks of a step at its plane's edge, and where its block lies in the B-ring
-            // (set for the step whose rows are being finished: this one's, or -- TW_DEFER_A -- the previous one's)
+            // (set for the step whose rows are being finished)
             const unsigned ey = __builtin_amdgcn_readfirstlane(e_own.y);
             int rmask = 15, b10w = b10;
             bool in0 = true, in1 = true, edge = false;
@@ -587,16 +468,7 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
                     st.q[2] = pk_add_f16(st.y0, st.t[0]); st.q[3] = pk_add_f16(st.y1, st.t[1]);      // V1 = d1 + d2
                     st.q[4] = pk_sub_f16(st.t[0], st.y0); st.q[5] = pk_sub_f16(st.t[1], st.y1);      // V2 = d2 - d1
                     st.q[6] = pk_sub_f16(st.y0, st.t[2]); st.q[7] = pk_sub_f16(st.y1, st.t[3]);      // V3 = d1 - d3
-#if defined(TW_EXP_2D) && TW_EXP_2D >= 2   // ... + the VALU a y-transform of these values would add: 16 packed adds per row, four independent
-                    {                      // chains whose results go nowhere (the frame keeps the bytes of TW_EXP_2D=1: same operand data, same power)
-                        unsigned sk[4] = {st.q[0], st.q[1], st.q[2], st.q[3]};
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) sk[e & 3] = pk_add_f16(sk[e & 3], st.q[4 + ((e >> 2) & 3)]);
-                        asm volatile("" :: "v"(sk[0]), "v"(sk[1]), "v"(sk[2]), "v"(sk[3]));
-                    }
-#endif
                 } else if constexpr (k == 6) {
-#ifndef TW_W128
                     // no lane exchange: every lane stores its own four channels of V0..V3 as 8-byte pieces (2-way bank conflicts --
                     // eight even pairs onto four units -- and still 0.7 % faster than four v_permlane16_swap and two 16-byte stores
                     // per row: -DTW_W128, profiles/r04_ab_results.txt block 9)
@@ -606,16 +478,9 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
                         char* const w0 = smem + w64 + (unsigned)pos * TW_BROWB;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) *(uint2*)(w0 + j * (TW_BROWB / 4)) = make_uint2(st.q[2 * j], st.q[2 * j + 1]);
-#if defined(TW_EXP_2D) && TW_EXP_2D >= 3   // ... + the ring traffic: a 2-D transform writes twice the rows (the same bytes again: harmless)
-                        char* w1 = w0;
-                        asm volatile("" : "+v"(w1) :: "memory");       // (the same place, which hipcc must not know)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) *(uint2*)(w1 + j * (TW_BROWB / 4)) = make_uint2(st.q[2 * j], st.q[2 * j + 1]);
-#endif
                     }
                 } else if constexpr (k == 7) {
                 } else if constexpr (k == 8) {
-#endif
                     const auto s02a = __builtin_amdgcn_permlane16_swap(st.q[0], st.q[4], false, false);
                     const auto s02b = __builtin_amdgcn_permlane16_swap(st.q[1], st.q[5], false, false);
                     const auto s13a = __builtin_amdgcn_permlane16_swap(st.q[2], st.q[6], false, false);
@@ -630,111 +495,34 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
                     *(uint4*)(w0 + wj) = make_uint4(st.q[4], st.q[5], st.q[6], st.q[7]);
                 }
             };
-            // this group's share of the raw rows of step it + 1 -> A-ring (TW_XA of the four rows; the consumers take the rest)
-            [[maybe_unused]] auto raw_rows_a = [&]() __attribute__((always_inline)) {
-                if (it + 1 < nsteps) {
-                    int pos0 = a6 + 4 + 2;
-                    pos0 = pos0 >= TW_AROWS ? pos0 - TW_AROWS : pos0;
-#if TW_XA == 4
-                    transform_rows((it + 1) & 1, pos0);
-#else
-                    transform_pair((it + 1) & 1, pos0, 1);
-#endif
-                }
-            };
-#if TW_DEFER_A
-            // Rows 2 and 3 of the PREVIOUS step's block: their accumulators are untouched since that k-loop, the consumers read them
-            // behind this iteration's barrier 1.  Here -- in front of the k-loop, beside the consumers' epilogue -- the producers have
-            // ~500 ticks to spare; behind barrier 1 their epilogue is the longer side of the phase.
-            if (it >= 1 && it <= nsteps) {
-                set_step(ey_prev, b10_prev);
-                auto late = [&](auto edge_tag) __attribute__((always_inline)) {
-                    static_for<8>([&](auto kc) __attribute__((always_inline)) {
-                        if constexpr (TW_DEFER_A == 2) slice(st2[0], edge_tag, std::integral_constant<int, 2>{}, kc);
-                        slice(st2[1], edge_tag, std::integral_constant<int, 3>{}, kc);
-                    });
-                };
-                if (edge) late(std::true_type{}); else late(std::false_type{});
-            }
-            ey_prev = ey; b10_prev = b10;
-#endif
             set_step(ey, b10);
             if (it < nsteps) {
                 __builtin_amdgcn_s_setprio(TW_PRIO_KA);
                 // steps that touch their plane's edge (uniform, few) mask what lies outside
-#if TW_DMA_LATE == 2
-                auto no_hook = [&](auto fc) __attribute__((always_inline)) {
-                    constexpr int f = decltype(fc)::value;
-                    if constexpr (f % 8 == 4 && f / 8 < 5) issue_piece(e_dma, it & 1, std::integral_constant<int, f / 8>{});
-                };
-#else
                 auto no_hook = [](auto) __attribute__((always_inline)) {};
-#endif
-#if TW_INROWS_A > 0
-                if (edge) kloop(std::false_type{}, a6, [&](auto nc, auto kc) __attribute__((always_inline)) { slice(st2[0], std::true_type{}, nc, kc); }, no_hook, pre);
-                else
-#endif
                 kloop(std::false_type{}, a6, [&](auto nc, auto kc) __attribute__((always_inline)) { slice(st2[0], std::false_type{}, nc, kc); }, no_hook, pre);
                 __builtin_amdgcn_s_setprio(TW_PRIO_EA);
             }
-#if TW_DMA_LATE == 1
-            issue_rows(e_dma, it & 1, std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});     // ... behind the k-loop: the producers wait at barrier 1 anyway
-#elif TW_DMA_LATE == 2
-            if (it >= nsteps) issue_rows(e_dma, it & 1, std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});       // (no k-loop in the last two iterations: their dummy rows all at once)
-#endif
-#if TW_DMA_B < 5
-            e_dma = load_a(it + 3 <= nsteps + TW_PAD_STEPS - 1 ? it + 3 : nsteps + TW_PAD_STEPS - 1);
-#endif
             // the rows of step it + 1 (issued one iteration ago) are complete once only this phase's pieces are outstanding
             TW_STAMP(1);
-#if TW_FLAGS & 1
-            if (wave == 0) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-            flag_signal(0);                        // this wave's k-loop is done and its pieces of step it + 1 have landed: no waiting here
-#else
-#if TW_DMA_B >= 5          // (the consumers wait for their own pieces)
             group_barrier();
-#elif defined(TW_ABL_NOVM)   // CEILING EXPERIMENT, RESULTS NOT GUARANTEED: nobody waits for the raw rows' LDS-DMA
-            dma_barrier<63>();
-#else
-            // (this group's pieces of THIS iteration may stay in flight: 5 - TW_DMA_B on wave 0, one less elsewhere)
-            if (wave == 0) dma_barrier<5 - TW_DMA_B>(); else dma_barrier<(4 - TW_DMA_B > 0 ? 4 - TW_DMA_B : 0)>();
-#endif
-#endif
             TW_STAMP(2);
-#if TW_XA > 0 && !defined(TW_XA_LAST)
-            raw_rows_a();
-#endif
             if (it < nsteps) {                     // the last row: beside the consumers' k-loop
                 // two rows at a time, slice by slice: neighbouring instructions are independent of each other
                 auto rest = [&](auto edge_tag) __attribute__((always_inline)) {
-                    static_assert(TW_INROWS_A == 0 || TW_INROWS_A == 2, "rows are finished in pairs");
-                    static_assert(TW_DEFER_A == 0 || ((TW_DEFER_A == 1 || TW_DEFER_A == 2) && TW_INROWS_A == 0), "one or two rows are deferred");
-                    static_for<(4 - TW_INROWS_A - TW_DEFER_A) / 2>([&](auto rc) __attribute__((always_inline)) {
+                    static_for<2>([&](auto rc) __attribute__((always_inline)) {
                         static_for<8>([&](auto kc) __attribute__((always_inline)) {
-                            slice(st2[0], edge_tag, std::integral_constant<int, TW_INROWS_A + 2 * decltype(rc)::value>{}, kc);
-                            slice(st2[1], edge_tag, std::integral_constant<int, TW_INROWS_A + 2 * decltype(rc)::value + 1>{}, kc);
-#ifdef TW_EPI_FENCE
-                            __builtin_amdgcn_sched_barrier(0);
-#endif
+                            slice(st2[0], edge_tag, std::integral_constant<int, 2 * decltype(rc)::value>{}, kc);
+                            slice(st2[1], edge_tag, std::integral_constant<int, 2 * decltype(rc)::value + 1>{}, kc);
                         });
                     });
-                    if constexpr (TW_DEFER_A == 1)            // (row 2 on its own: row 3 waits for the next iteration)
-                        static_for<8>([&](auto kc) __attribute__((always_inline)) { slice(st2[0], edge_tag, std::integral_constant<int, 2>{}, kc); });
                 };
                 if (edge) rest(std::true_type{}); else rest(std::false_type{});     // (uniform: most steps lie inside their plane)
             }
-#if TW_XA > 0 && defined(TW_XA_LAST)
-            raw_rows_a();
-#endif
             e_own = load_a(it + 1 < nsteps ? it + 1 : nsteps - 1);
             TW_STAMP(3);
             a6 = a6 + 4 >= TW_AROWS ? a6 + 4 - TW_AROWS : a6 + 4;
-#if TW_PRE_BAR & 1
-            prefetch(std::false_type{}, a6, pre);  // the next step's window row 0 is this step's row 4: transformed a period ago
-#endif
-#if !(TW_FLAGS & 2)
             group_barrier();
-#endif
             b10 = b10 + 4 >= TW_BROWS ? b10 + 4 - TW_BROWS : b10 + 4;
         }
     } else {
@@ -772,48 +560,30 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
                     const auto x = __builtin_amdgcn_permlane16_swap(st.x0, st.y0, false, false);
                     const auto y = __builtin_amdgcn_permlane16_swap(st.x1, st.y1, false, false);
                     st.q[0] = x[0]; st.q[1] = y[0]; st.q[2] = x[1]; st.q[3] = y[1];
-#if defined(TW_EXP_2D) && TW_EXP_2D >= 2   // ... + the second output transform's adds (results discarded, see above)
-                    {
-                        unsigned sk[4] = {st.x0, st.x1, st.y0, st.y1};
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) sk[e & 3] = pk_add_f16(sk[e & 3], st.q[(e >> 2) & 3]);
-                        asm volatile("" :: "v"(sk[0]), "v"(sk[1]), "v"(sk[2]), "v"(sk[3]));
-                    }
-#endif
                 } else if constexpr (k == 5) {
                     char* dst = (n >= v0 && n < vy && colok) ? obase + (size_t)n * pitch : sink;
                     *(uint4*)dst = make_uint4(st.q[0], st.q[1], st.q[2], st.q[3]);
                 }
             };
         };
-#if TW_DMA_B > 0
         // the A half of step it + 2's entry (its input rows), fetched one iteration ahead like the producers' own entries
         uint4 e_dma = load_a(2 <= nsteps + TW_PAD_STEPS - 1 ? 2 : nsteps + TW_PAD_STEPS - 1);
         unsigned st_prev = 0;          // the previous iteration's epilogue ran (four stores behind that iteration's pieces)
-#endif
         for (int it = 0; it < niter; ++it) {
             TW_STAMP(0);
-#if TW_DMA_B > 0
             // Raw rows of step it + 2 -> slot it & 1, whose rows this group read (into registers) in the k-loop in front of barrier 2.
             // They are read again in iteration it + 1's k-loop; every wave waits for ITS pieces in front of that iteration's barrier 1.
-            issue_rows(e_dma, it & 1, std::integral_constant<int, 0>{}, std::integral_constant<int, (TW_DMA_B < 5 ? TW_DMA_B : 5)>{});
+            issue_rows(e_dma, it & 1, std::integral_constant<int, 0>{}, std::integral_constant<int, TW_DMA_PIECES>{});
             e_dma = load_a(it + 3 <= nsteps + TW_PAD_STEPS - 1 ? it + 3 : nsteps + TW_PAD_STEPS - 1);
             const unsigned st_cur = (unsigned)__builtin_amdgcn_readfirstlane((int)(it >= 2 ? (__builtin_amdgcn_readfirstlane(e_3.y) >> 24) & 1u : 0u));
-#endif
             if (it >= 2 && ((__builtin_amdgcn_readfirstlane(e_3.y) >> 24) & 1u)) {      // row 3 of step it - 2
                 auto sl3 = make_slice(e_3);
-                static_assert(TW_INROWS_B >= 0 && TW_INROWS_B <= 3, "rows 0 .. TW_INROWS_B - 1 ride in the k-loop");
-                static_for<(4 - TW_INROWS_B) / 2>([&](auto rc) __attribute__((always_inline)) {      // the rest in pairs, slice by slice
+                static_for<2>([&](auto rc) __attribute__((always_inline)) {      // in pairs, slice by slice
                     static_for<6>([&](auto kc) __attribute__((always_inline)) {
-                        sl3(st2[0], std::integral_constant<int, TW_INROWS_B + 2 * decltype(rc)::value>{}, kc);
-                        sl3(st2[1], std::integral_constant<int, TW_INROWS_B + 2 * decltype(rc)::value + 1>{}, kc);
-#ifdef TW_EPI_FENCE
-                        __builtin_amdgcn_sched_barrier(0);
-#endif
+                        sl3(st2[0], std::integral_constant<int, 2 * decltype(rc)::value>{}, kc);
+                        sl3(st2[1], std::integral_constant<int, 2 * decltype(rc)::value + 1>{}, kc);
                     });
                 });
-                if constexpr ((4 - TW_INROWS_B) % 2 == 1)                                             // ... and the odd one out
-                    static_for<6>([&](auto kc) __attribute__((always_inline)) { sl3(st2[0], std::integral_constant<int, 3>{}, kc); });
             }
             e_k = load_b(it >= 1 ? it - 1 : 0);
             const unsigned kact = (it >= 1 && it <= nsteps) ? (__builtin_amdgcn_readfirstlane(e_k.y) >> 24) & 1u : 0u;
@@ -821,12 +591,18 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
             bp = bp < 0 ? bp + TW_BROWS : bp;
             half8 pre[TW_PFF_B];
             TW_STAMP(1);
-#if TW_DMA_B > 0
             // The pieces of iteration it - 1 (the rows of step it + 1, read behind this barrier) have landed once nothing OLDER than what
             // this wave has issued since is outstanding -- vmcnt counts a wave's loads and stores in order (tools/vmorder_bench.hip):
-            // the previous iteration's stores (4, if its epilogue ran), this iteration's pieces (TW_DMA_B; wave 0 has a fifth) and stores.
+            // the previous iteration's stores (4, if its epilogue ran), this iteration's pieces (four; wave 0 has a fifth) and stores.
+            // The count is by hand: it holds as long as an epilogue is EXACTLY four VMEM stores per wave and nothing else of this wave
+            // goes through the vector memory path.  The instrumented build's stamps are global stores: it waits for
+            // everything instead.
+#ifdef UVA_INSTRUMENT
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            st_prev = st_cur;
+#else
             {
-                constexpr int P0 = TW_DMA_B < 5 ? TW_DMA_B : 5, P = TW_DMA_B < 4 ? TW_DMA_B : 4;
+                constexpr int P0 = TW_DMA_PIECES, P = TW_DMA_PIECES - 1;
                 const unsigned nst = st_prev + st_cur;
                 if (wave == 0) {
                     if (nst == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P0 + 8) : "memory");
@@ -840,14 +616,8 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
                 st_prev = st_cur;
             }
 #endif
-#if TW_FLAGS & 1
-            flag_wait(0, 4 * (it + 1));            // the producers' k-loop of this iteration is done, the raw rows of step it + 1 have landed
-#elif TW_PRE_BAR & 2
             prefetch(std::true_type{}, bp, pre);   // window row 0 = the third row of block it - 2: written three phases ago
             asm volatile("s_barrier" ::: "memory");        // (kact above has waited for the step entry; nothing of this phase went to LDS)
-#else
-            group_barrier();
-#endif
             TW_STAMP(2);
             // The raw rows of step it + 1 (landed: the producers waited for them in front of barrier 1) -> A-ring.  FIRST: the
             // producers' epilogue runs beside it at full speed (beside a k-loop it gets one instruction through per MFMA), and
@@ -856,17 +626,9 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
                 if (it + 1 < nsteps) {
                     int pos0 = a6 + 4 + 2;         // step it + 1's new rows follow its two shared ones
                     pos0 = pos0 >= TW_AROWS ? pos0 - TW_AROWS : pos0;
-#if TW_XA == 0
                     transform_rows((it + 1) & 1, pos0);
-#elif TW_XA == 2
-                    transform_pair((it + 1) & 1, pos0, 0);
-#endif
                 }
             };
-#if !defined(TW_TRANSFORM_LAST) && !TW_RAW_INK
-            raw_rows();
-#endif
-#if TW_RAW_INK
             unsigned solo = (unsigned)__builtin_amdgcn_readfirstlane((int)((kact ^ 1u) & (it + 1 < nsteps ? 1u : 0u)));
             asm volatile("" : "+s"(solo));         // (opaque: seen as the k-loop's `else`, hipcc lays the two out as one region and spills 115 registers)
             if (solo) {                            // (no k-loop to hide it in: the first iteration, a segment's fill step) -- half a
@@ -877,12 +639,10 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
                 __builtin_amdgcn_sched_barrier(0);
                 transform_half(rr, pos, 1);
             }
-#endif
             TW_STAMP(4);
             if (kact) {
                 __builtin_amdgcn_s_setprio(TW_PRIO_KB);
                 auto slk = make_slice(e_k);
-#if TW_RAW_INK
                 // The next step's raw row `wave` -> A-ring, cut into pieces that ride in this k-loop's instruction stream: four
                 // ds_read_b128 (d0..d3 of one channel half) at fragment F0, then one V row (four v_pk_add_f16, one ds_write_b128) every
                 // STRIDE fragments from F0 + GAP on -- an LDS round trip later --, then the other half.  Past the frame's last step
@@ -906,22 +666,12 @@ __global__ __launch_bounds__(512, 2) UVA_NO_PK_F32 void trunkw_kernel(TrunkwArgs
                     else if constexpr (g == TW_RAW_GAP + 2 * TW_RAW_STRIDE) *(half8*)(vrow + 1 * 2048 + t * 1024) = rd[1] + rd[2];
                     else if constexpr (g == TW_RAW_GAP + 3 * TW_RAW_STRIDE) *(half8*)(vrow + 2 * 2048 + t * 1024) = pk_sub(rd[2], rd[1]);
                 };
-#else
-                auto raw_hook = [](auto) __attribute__((always_inline)) {};
-#endif
                 kloop(std::true_type{}, bp, [&](auto nc, auto kc) __attribute__((always_inline)) { slk(st2[0], nc, kc); }, raw_hook, pre);
                 __builtin_amdgcn_s_setprio(TW_PRIO_EB);
             }
             e_3 = e_k;
-#ifdef TW_TRANSFORM_LAST
-            raw_rows();
-#endif
             TW_STAMP(3);
-#if TW_FLAGS & 2
-            flag_signal(1);                        // this wave's k-loop and its row of the A-ring are done: on to the epilogue at once
-#else
             group_barrier();
-#endif
             a6 = a6 + 4 >= TW_AROWS ? a6 + 4 - TW_AROWS : a6 + 4;
             b10 = b10 + 4 >= TW_BROWS ? b10 + 4 - TW_BROWS : b10 + 4;
         }
