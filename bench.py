@@ -68,15 +68,128 @@ def shard_frames(n_frames, rank, world):
     return list(range(rank, n_frames, world))
 
 
-def timed_region(run_steps, sync, barrier, max_over_ranks):
-    """barrier + sync, run, sync + barrier; returns the MAX wall seconds over ranks."""
+def timed_region(run_steps, sync, barrier, max_over_ranks, own=None):
+    """barrier + sync, run, sync + barrier; returns the MAX wall seconds over ranks.  `own` (a list) also receives this rank's
+    seconds from the common start to its OWN last result (before the closing barrier): the per-rank records' rate."""
     sync()
     barrier()
     t0 = time.perf_counter()
     run_steps()
     sync()
+    mine = time.perf_counter() - t0
     barrier()
+    if own is not None:
+        own.append(mine)
     return max_over_ranks(time.perf_counter() - t0)
+
+
+class FileCounter:
+    """One counter for all ranks of a node (--dynamic: the frame queue of SURVEY.md 8e -- every rank takes the next frame index
+    when it is ready for one, as the reference's pool hands out tasks, upscale/upscale_processing.py:565-601 -- instead of
+    shard_frames' fixed r, r + world, ...): eight bytes in a file under /dev/shm, fetch-and-add under flock.  It works the same for
+    self-launched ranks and for torch.distributed.run's, needs no collective, and costs ~2 us per take."""
+
+    def __init__(self, path, create=False):
+        import fcntl
+        self._fcntl = fcntl
+        self.path = path
+        self._fd = os.open(path, os.O_RDWR | (os.O_CREAT if create else 0), 0o600)
+        if create:
+            self.reset()
+
+    def reset(self, value=0):
+        self._fcntl.flock(self._fd, self._fcntl.LOCK_EX)
+        try:
+            os.pwrite(self._fd, int(value).to_bytes(8, "little"), 0)
+        finally:
+            self._fcntl.flock(self._fd, self._fcntl.LOCK_UN)
+
+    def take(self, n=1):
+        """-> the counter's value before `n` was added"""
+        self._fcntl.flock(self._fd, self._fcntl.LOCK_EX)
+        try:
+            v = int.from_bytes(os.pread(self._fd, 8, 0) or b"\0", "little")
+            os.pwrite(self._fd, (v + n).to_bytes(8, "little"), 0)
+        finally:
+            self._fcntl.flock(self._fd, self._fcntl.LOCK_UN)
+        return v
+
+    def close(self):
+        os.close(self._fd)
+
+
+def job_scratch_dir():
+    """where the ranks of THIS job meet on the node's file system (per-rank records, --dynamic's counter): launch_ranks makes it
+    for self-launched ranks; under torch.distributed.run it is named after the rendezvous port"""
+    d = os.environ.get("UVA_BENCH_JOB_DIR")
+    if not d:
+        base = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+        d = os.path.join(base, "uva_bench_%s_%s" % (os.environ.get("MASTER_PORT", "solo"), os.environ.get("TORCHELASTIC_RUN_ID", os.getppid())))
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def gather_records(comm, record):
+    """every rank's dict -> the list of all of them, in rank order, on every rank (through the job's scratch directory and two
+    fences: no collective, any launcher)"""
+    d = job_scratch_dir()
+    tmp = os.path.join(d, "rank%d.json.tmp" % comm.rank)
+    with open(tmp, "w") as f:
+        json.dump(record, f)
+    os.replace(tmp, os.path.join(d, "rank%d.json" % comm.rank))
+    comm.barrier()
+    out = []
+    for r in range(comm.world):
+        with open(os.path.join(d, "rank%d.json" % r)) as f:
+            out.append(json.load(f))
+    comm.barrier()                      # nobody rewrites its file before everybody has read
+    return out
+
+
+def per_rank_summary(records):
+    """min / max / mean of every numeric field over the ranks (what to look at first when 8 GPUs give less than 8 x)"""
+    out = {}
+    for key in sorted({k for r in records for k, v in r.items() if isinstance(v, (int, float)) and not isinstance(v, bool)}):
+        if key in ("rank", "device", "numa_node"):
+            continue
+        vals = [r[key] for r in records if isinstance(r.get(key), (int, float))]
+        if vals:
+            out[key] = {"min": round(min(vals), 3), "max": round(max(vals), 3), "mean": round(sum(vals) / len(vals), 3)}
+    return out
+
+
+def gpu_numa_node(gpu):
+    """NUMA node of the GPU's PCIe function (sysfs), or None"""
+    try:
+        import ctypes
+        from upscale_video_amd import _lib
+        buf = ctypes.create_string_buffer(64)
+        if _lib.load().uva_get_gpu_pci_bus_id(int(gpu), buf, 64) != 0:
+            return None
+        with open("/sys/bus/pci/devices/%s/numa_node" % buf.value.decode().lower()) as f:
+            return int(f.read().strip())
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def pcie_rates(torch, sync, barrier, mbytes=128, reps=3):
+    """(h2d GB/s, d2h GB/s) of this rank's page-locked copies while EVERY rank copies at once (fenced): what the host route has
+    per GPU when all of them pull on the node's memory and PCIe root complexes together"""
+    n = mbytes << 20
+    host = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+    dev = torch.empty(n, dtype=torch.uint8, device="cuda")
+    out = []
+    for src, dst in ((host, dev), (dev, host)):
+        dst.copy_(src, non_blocking=True)
+        sync()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        out.append(n * reps / (time.perf_counter() - t0) / 1e9)
+        barrier()
+    return out[0], out[1]
 
 
 def whole_job_rate(units_per_rank, world, max_elapsed):
@@ -356,9 +469,12 @@ def launch_ranks(world, devices, argv, target=None, poll_s=0.2, grace_s=5.0):
     driver's timeout), the rest get `grace_s` seconds to go and are then terminated, and the job's exit code is that rank's.
     Returns 0 or the first failing exit code (negative = killed by that signal); prints what happened to stderr."""
     import multiprocessing as mp
+    import tempfile
     ctx = mp.get_context("spawn")
     barrier, slots = ctx.Barrier(world), ctx.Array("d", world)
     target = target or _fork_rank
+    if not os.environ.get("UVA_BENCH_JOB_DIR"):     # (the ranks inherit the environment: per-rank records, --dynamic's counter)
+        os.environ["UVA_BENCH_JOB_DIR"] = tempfile.mkdtemp(prefix="uva_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     procs = [ctx.Process(target=target, args=(r, world, devices[r], barrier, slots, list(argv))) for r in range(world)]
     for p in procs:
         p.start()
@@ -436,6 +552,12 @@ def parse_args(argv=None):
     ap.add_argument("--devices", default=None,
                     help="comma-separated device ordinal per rank (default 0,1,..,N-1); '0,0' puts two ranks on one GPU, the "
                          "reference's own way of loading a GPU with several workers (README.md:45-61)")
+    ap.add_argument("--dynamic", action="store_true",
+                    help="N > 1: the ranks pull frame indices from ONE shared counter (the reference's pool queue, "
+                         "upscale_processing.py:565-601) instead of owning --steps frames each; the job is still steps x N frames")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="frames per uva_net_process_u8_device_batch call for the workloads with the 1x net (default 4; 1 = one "
+                         "call per frame).  Ignored for the other workloads: their nets run frame by frame either way")
     ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps each; the median is reported (SURVEY.md 8d)")
     return ap.parse_args(argv)
 
@@ -518,6 +640,9 @@ def run(args, comm, device):
     frames = [torch.from_numpy(synthetic_frame(h, w, seed=20260928 + 17 * rank + i)).cuda() for i in range(n_src)]
     out = torch.empty((h * s, w * s, 3), dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
+    # frames per call for the workloads with the 1x net (uva_net_process_u8_device_batch: up to eight frames per sub10_kernel launch)
+    batch = max(1, min(8, args.batch if args.batch else 4)) if (key == "1x" or args.workload.startswith("chain_")) else 1
+    outs = [out] + [torch.empty_like(out) for _ in range(batch - 1)] if key == "1x" else [out]
 
     pre = None
     if args.workload.startswith("chain_"):
@@ -525,7 +650,7 @@ def run(args, comm, device):
         pre.set_vulkan_device(local_rank)
         pbase = os.path.join(ROOT, "models", "1x_HurrDeblur_SubCompact_nf24-nc8_244k_net_g")
         assert pre.load_param(pbase + ".param") == 0 and pre.load_model(pbase + ".bin") == 0
-        mid = [torch.empty((h, w, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        mid = [torch.empty((h, w, 3), dtype=torch.uint8, device="cuda") for _ in range(max(2, batch))]
         torch.cuda.synchronize()
 
     def step(i):
@@ -538,23 +663,78 @@ def run(args, comm, device):
             src = m.data_ptr()
         net.process_u8_device(src, h, w, out.data_ptr(), tile_size=args.tile, border=10)
 
+    def step_group(i0, k):
+        """frames i0 .. i0 + k - 1: one call per frame, or -- the workloads with the 1x net, --batch > 1 -- one batch call of the
+        1x net for all k (the chain: k frames through the 1x net, then each through the 2x net)"""
+        if batch == 1 or k == 1:
+            for i in range(i0, i0 + k):
+                step(i)
+        elif pre is None:
+            net.process_u8_device_batch([frames[(i0 + j) % n_src].data_ptr() for j in range(k)], h, w,
+                                        [outs[j].data_ptr() for j in range(k)], tile_size=args.tile, border=10)
+        else:
+            pre.wait_for(net)                     # the mid buffers were last read by the previous group's 2x passes
+            pre.process_u8_device_batch([frames[(i0 + j) % n_src].data_ptr() for j in range(k)], h, w,
+                                        [mid[j].data_ptr() for j in range(k)], tile_size=0)
+            net.wait_for(pre)
+            for j in range(k):
+                net.process_u8_device(mid[j].data_ptr(), h, w, out.data_ptr(), tile_size=args.tile, border=10)
+
+    def run_static(n_frames):
+        for i0 in range(0, n_frames, batch):
+            step_group(i0, min(batch, n_frames - i0))
+
+    counter = None
+    if args.dynamic and world > 1:
+        cpath = os.path.join(job_scratch_dir(), "frame_counter")
+        if rank == 0:
+            FileCounter(cpath, create=True).close()
+        barrier()
+        counter = FileCounter(cpath)
+    taken = [0]
+
+    def run_dynamic(total):
+        """every rank takes the next `chunk` frame indices off the one counter when its queue has drained (the launches are
+        asynchronous: without the wait one rank would take the whole job into its stream in a millisecond)"""
+        chunk = max(batch, 4)
+        taken[0] = 0
+        while True:
+            i0 = counter.take(chunk)
+            if i0 >= total:
+                break
+            k = min(chunk, total - i0)
+            for j0 in range(0, k, batch):
+                step_group(i0 + j0, min(batch, k - j0))
+            taken[0] += k
+            sync()
+
     def sync():
         if pre is not None:
             pre.synchronize()
         net.synchronize()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
+    t_first = time.perf_counter()
+    step_group(0, batch)                          # the first call: workspace, schedules, row tables
+    sync()
+    first_frame_ms = (time.perf_counter() - t_first) * 1e3
+    run_static(args.warmup)
     sync()
     # >= 3 timed regions of exactly --steps steps each (every one bracketed by barrier + sync, MAX over ranks); the MEDIAN region
     # counts -- for `value` and for the kernel event statistics alike: set_profiling(True) zeroes the counters, so every region
     # has its own, and the roofline's launch time is the reported region's (a process's first ~40 launches run while the clock
     # still ramps: with the driver's --steps 20 --warmup 5 they sit in the first region; profiles/r04_ab_results.txt block 21)
-    regions, region_stats = [], []
+    regions, region_stats, own_s, own_frames = [], [], [], []
     for _ in range(max(1, args.repeats)):
         net.set_profiling(True)
-        regions.append(timed_region(lambda: [step(i) for i in range(args.steps)], sync, barrier, max_over_ranks))
+        if counter is not None:
+            if rank == 0:
+                counter.reset()
+            regions.append(timed_region(lambda: run_dynamic(args.steps * world), sync, barrier, max_over_ranks, own=own_s))
+            own_frames.append(taken[0])
+        else:
+            regions.append(timed_region(lambda: run_static(args.steps), sync, barrier, max_over_ranks, own=own_s))
+            own_frames.append(args.steps)
         region_stats.append([net.kernel_stats(k) for k in range(3)])
     net.set_profiling(False)
     median_idx = sorted(range(len(regions)), key=lambda i: regions[i])[len(regions) // 2]
@@ -563,7 +743,7 @@ def run(args, comm, device):
                                                                                        # rdb4_kernel), kind 2: tail (conv5)
 
     fps = whole_job_rate(args.steps, world, elapsed)
-    steps_timed = args.steps                       # the kernel event statistics are the median region's
+    steps_timed = max(1, own_frames[median_idx])   # the kernel event statistics are the median region's, of THIS rank's frames
 
     # (E) pipelined host route, PCIe inclusive, on every rank at once: frames in page-locked host memory,
     # submit/collect with 3 frames in flight (SURVEY.md 8d "host-to-host with stream overlap")
@@ -585,10 +765,28 @@ def run(args, comm, device):
             net.collect_u8(inflight.pop(0))
 
     host_fps = None
+    own_host = []
     if pre is None:
         host_pipeline(6)
-        host_elapsed = timed_region(lambda: host_pipeline(n_host), sync, barrier, max_over_ranks)
+        host_elapsed = timed_region(lambda: host_pipeline(n_host), sync, barrier, max_over_ranks, own=own_host)
         host_fps = whole_job_rate(n_host, world, host_elapsed)
+
+    # the 1x net one frame per launch beside the batch figure (the reference's unit is the frame: both are reported)
+    single_fps = None
+    if batch > 1 and pre is None:
+        t_single = timed_region(lambda: [step(i) for i in range(args.steps)], sync, barrier, max_over_ranks)
+        single_fps = whole_job_rate(args.steps, world, t_single)
+
+    # per-rank records (when eight GPUs give less than 6 x, the one JSON line must say which rank, which
+    # NUMA node, which PCIe direction): every rank's own rates, gathered through the job's scratch directory
+    h2d, d2h = pcie_rates(torch, sync, barrier)
+    record = {"rank": rank, "device": local_rank, "numa_node": gpu_numa_node(local_rank), "cpus_pinned": (len(numa_cpus) if numa_cpus else None),
+              "frames_K": own_frames[median_idx], "fps_K": round(own_frames[median_idx] / own_s[median_idx], 2),
+              "fps_E": (round(n_host / own_host[0], 2) if own_host else None),
+              "h2d_GBps": round(h2d, 2), "d2h_GBps": round(d2h, 2), "first_frame_ms": round(first_frame_ms, 1)}
+    per_rank = gather_records(comm, record)
+    if counter is not None:
+        counter.close()
 
     if rank == 0 and generic:
         # dominant kernel: rdb4_kernel, the first four convolutions (+ the 1x1) of a residual dense block for all planes of
@@ -617,8 +815,10 @@ def run(args, comm, device):
                 "kernel_ms_per_frame": {"rdb4_kernel": round(trunk_ms / steps_timed, 3), "conv5 (g_conv3_sw<6,1>)": round(tail_ms / steps_timed, 3)},
                 "numa_cpus_rank0": (len(numa_cpus) if numa_cpus else None),
                 "pinned_host_bytes_all_ranks": pinned_need, "host_memory_available_bytes": pinned_avail,
+                "frame_queue": "dynamic (one shared counter)" if counter is not None else "static (frames r, r + N, ...)",
                 "library": library_record(),
             },
+            "per_rank": per_rank, "per_rank_summary": per_rank_summary(per_rank),
             "roofline": {"kernel": "rdb4_kernel (conv1..conv4 + the 1x1 of a residual dense block, every plane of the frame, one launch)",
                          "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
@@ -642,8 +842,9 @@ def run(args, comm, device):
         trunk_flops_per_launch = layers_per_launch * 2 * 9 * nf * nf * h * w        # algorithmic: un-tiled frame
         whole_net = nf == 24 and layers_per_launch > nconv - 2.5    # sub10_kernel: all ten convolutions of the 1x net in one launch
         split5 = nf == 24 and 3.5 < layers_per_launch < 4.5         # sub5_kernel (UVA_SUB5=1): the same net as two launches of five layers
+        frames_per_launch = steps_timed / max(1, n_launch) if whole_net else 1.0      # (uva_net_process_u8_device_batch: up to 8)
         if whole_net:
-            trunk_flops_per_launch = conv_flops_per_px(nf, nconv, s) * h * w
+            trunk_flops_per_launch = conv_flops_per_px(nf, nconv, s) * h * w * frames_per_launch
         if split5:
             trunk_flops_per_launch = conv_flops_per_px(nf, nconv, s) * h * w / 2.0     # (the frame's convolutions over its two launches)
         avg_ms = trunk_ms / max(1, n_launch)
@@ -674,17 +875,20 @@ def run(args, comm, device):
                                         "tail": round(tail_ms / steps_timed, 4)},
                 "numa_cpus_rank0": (len(numa_cpus) if numa_cpus else None),
                 "pinned_host_bytes_all_ranks": pinned_need, "host_memory_available_bytes": pinned_avail,
+                "frame_queue": "dynamic (one shared counter)" if counter is not None else "static (frames r, r + N, ...)",
+                "frames_per_call": batch,
                 "library": library_record(),
             },
+            "per_rank": per_rank, "per_rank_summary": per_rank_summary(per_rank),
             "roofline": {
-                "kernel": ("sub10_kernel (the whole 1x net: 3->24, 8 x 24->24, 24->3, + input, one launch per frame)" if whole_net else
+                "kernel": (f"sub10_kernel (the whole 1x net: 3->24, 8 x 24->24, 24->3, + input; {frames_per_launch:.3g} frame(s) per launch)" if whole_net else
                            "sub5_kernel (the 1x net as two launches of five layers, two pipelines per workgroup; per launch: half the net's FLOPs)" if split5 else
                            (f"{kernel}<{nf}>" if nf == 64 else ("pair24_kernel" if fused else f"conv3x3_kernel<{nf},0,1>")) +
                            (f" ({int(round(layers_per_launch))} trunk layers {nf}->{nf} + PReLU per launch)")),
                 "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "flops_per_launch": trunk_flops_per_launch, "avg_launch_ms": round(avg_ms, 4), "launches": n_launch,
-                "layers_per_launch": round(layers_per_launch, 2),
+                "layers_per_launch": round(layers_per_launch, 2), "frames_per_launch": round(frames_per_launch, 3),
                 # `achieved` / `frac` count the ALGORITHMIC FLOPs of the direct 3x3 convolution (SURVEY.md 8d's per-unit figure)
                 # -- what the roofline contract asks for; trunkw_kernel ISSUES two thirds of them (1-D Winograd F(2,3): four
                 # multiplications for two columns instead of six) and recomputes strip edges, so the matrix pipes' own utilisation is
@@ -701,6 +905,8 @@ def run(args, comm, device):
         if host_fps is not None:
             result["config"]["host_route_fps_pcie_inclusive"] = round(host_fps, 2)
             result["config"]["host_route_frames_per_rank"] = n_host
+        if single_fps is not None:
+            result["config"]["one_frame_per_call_fps"] = round(single_fps, 2)      # the same net through uva_net_process_u8_device
         if world == 1:
             # informational: pageable numpy in/out, one synchronous call per frame (what one reference worker does)
             net.process_u8(host_in, tile_size=args.tile, border=10)

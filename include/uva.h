@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UVA_ABI_VERSION 14  /* 2: + uva_net_submit_u8 / uva_net_collect_u8 / uva_host_alloc / uva_host_free;
+#define UVA_ABI_VERSION 15  /* 2: + uva_net_submit_u8 / uva_net_collect_u8 / uva_host_alloc / uva_host_free;
                                3: + uva_get_gpu_pci_bus_id, uva_debug_trunk2_schedule;
                                4: + uva_denoise_u8, uva_debug_denoise_stage; generic graphs (4x_Valar_v1) load;
                                5: + uva_debug_sub10_rows;
@@ -38,7 +38,9 @@ extern "C" {
                                11: + uva_debug_generic_batches;
                                12: + uva_debug_trunkw_schedule (trunkw_kernel: fused trunk pairs as Winograd F(2,3));
                                13: + uva_denoise_u8_device, uva_denoise_synchronize;
-                               14: + uva_net_device, uva_debug_sub5_rows (sub5_kernel: the 1x net as two launches of five layers) */
+                               14: + uva_net_device, uva_debug_sub5_rows (sub5_kernel: the 1x net as two launches of five layers);
+                               15: + uva_net_process_u8_device_batch (several frames of one geometry per call; the 1x net takes up to
+                                   eight per launch), uva_debug_sub10_rows_batch */
 
 typedef struct uva_net uva_net;
 
@@ -157,6 +159,15 @@ int uva_debug_png_deflate_host(const uint8_t* bgr, int h, int w, size_t stride, 
 int uva_net_process_u8_device(uva_net* net, const void* d_in, int h, int w, size_t in_stride,
                               void* d_out, size_t out_stride, int tile_size, int border);
 
+/* `count` frames of ONE geometry in one call, every d_in[i] / d_out[i] resident in this device's HBM: what a worker that
+ * holds several decoded frames (the raw-video route, the frame pool, `-m a` in front of the 2x pass) hands over instead of
+ * `count` calls of apply_model (upscale/upscale_processing.py:258-299) -- the reference has no such call, its unit is the frame.
+ * The 1x HurrDeblur net runs up to eight of them per kernel launch (the launch's pipeline fill and the strips' warm-up rows
+ * are then paid once per launch, not once per frame); every other net, and whatever does not fit, is processed frame by
+ * frame.  The result bytes are exactly those of `count` uva_net_process_u8_device calls.  Asynchronous on the net's stream. */
+int uva_net_process_u8_device_batch(uva_net* net, const void* const* d_in, void* const* d_out, int count, int h, int w,
+                                    size_t in_stride, size_t out_stride, int tile_size, int border);
+
 int uva_net_synchronize(uva_net* net);
 
 /* Device-side ordering between two nets of one process (each net owns a stream): everything
@@ -262,10 +273,14 @@ int uva_debug_generic_batches(int h, int w, int tile_size, int border, long long
 
 /* Test hook (host only): the row lists sub10_kernel (the whole 24-feature 1x net, one launch) walks for an h x w
  * frame on `grid` workgroups.  Every workgroup has `*stride` 16-byte entries of 4 words {y, x0, emit, 0}
- * (csrc/uva_kernels.hip.h Sub10Args), nrows[b] of them real: the kernel computes columns x0 .. x0+79 of row y and
+ * (csrc/uva_sub10.h Sub10Args), nrows[b] of them real: the kernel computes columns x0 .. x0+79 of row y and
  * writes columns x0+10 .. x0+69 of it when emit is set. */
 int uva_debug_sub10_rows(int h, int w, int grid, uint32_t* rows_words, size_t capacity_words, size_t* needed_words,
                          int* nrows, int* stride);
+/* ... for `frames` (1..8) frames of that geometry in one launch: the sequence runs over (frame, strip, row); the frame of an
+ * entry is emit >> 8 (emit & 1 as above), the fourth word the distance to the nearest row of the segment that is written out. */
+int uva_debug_sub10_rows_batch(int h, int w, int frames, int grid, uint32_t* rows_words, size_t capacity_words, size_t* needed_words,
+                               int* nrows, int* stride);
 /* The same for sub5_kernel (UVA_SUB5=1: that net as two launches of five layers, two pipelines -- a PAIR of 54-column strips --
  * per workgroup; csrc/uva_sub5.hip.h).  Entries {row y, column of computed column 0 of the pair's first strip, 1 = written
  * out, 0}; both launches walk the same lists. */

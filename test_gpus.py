@@ -32,8 +32,29 @@ def timed_upscale(png, scale, gpus, workers_used=0):
     t0 = time.perf_counter()
     log = [["info", "Testing GPU: %s" % gpus[slot]]]
     log.extend(upscale_image(png, None, scale, None, 1, 1, remove=False))
-    log.append(["info", "%s seconds to upscale %s" % (time.perf_counter() - t0, os.path.basename(png))])
+    dt = time.perf_counter() - t0
+    log.append(["info", "%s seconds to upscale %s" % (dt, os.path.basename(png))])
+    log.append(["debug", "%s %d %s %.6f" % (WORKER_TIME_TAG, slot, gpus[slot], dt)])      # for the parent's per-worker table
     return log
+
+
+WORKER_TIME_TAG = "worker-time"
+
+
+def per_worker_table(times, elapsed):
+    """{(slot, gpu): [seconds per call]} -> log lines: one per worker, slowest last but one, then the spread.  The reference
+    prints seconds per call and the total (test_gpus.py:79-112); with `-g 0,..,7` the question after a run is WHICH worker
+    was slow, so the calls are also shown per worker."""
+    lines = ["per worker (calls, mean seconds per call, frames/s of the worker while it ran):"]
+    rates = []
+    for (slot, gpu), ts in sorted(times.items()):
+        rate = len(ts) / sum(ts)
+        rates.append(rate)
+        lines.append("  worker %d on GPU %s: %d calls, %.4f s per call, %.2f frames/s" % (slot, gpu, len(ts), sum(ts) / len(ts), rate))
+    if rates:
+        lines.append("  slowest / fastest worker: %.2f / %.2f frames/s; sum of the workers' rates %.2f, the pool's %.2f"
+                     % (min(rates), max(rates), sum(rates), sum(len(t) for t in times.values()) / elapsed))
+    return lines
 
 
 def list_devices():
@@ -56,12 +77,24 @@ def time_pool(gpu_list, scale, runs, png):
                  "(what is timed, as in the reference's harness: every run's PNG decode and worker start-up -- the pool's spawn "
                  "and model load fall inside the total; a host-side figure, not the GPUs' rate, which is bench.py's)", RULE):
         logging.info(line)
+    times = {}
+
+    def collect(log_list):
+        for level, message in log_list:
+            if level == "debug" and message.startswith(WORKER_TIME_TAG + " "):
+                _, slot, gpu, dt = message.split()
+                times.setdefault((int(slot), gpu), []).append(float(dt))
+        logging_callback(log_list)
+
     t0 = time.perf_counter()
     for _ in range(runs):
-        workers.apply_async(timed_upscale, (png, scale, gpu_list, used), callback=logging_callback)
+        workers.apply_async(timed_upscale, (png, scale, gpu_list, used), callback=collect)
     workers.close()
     workers.join()
     elapsed = time.perf_counter() - t0
+    logging.info(RULE)
+    for line in per_worker_table(times, elapsed):
+        logging.info(line)
     logging.info(RULE)
     logging.info("%s seconds total to run tests.", elapsed)
     logging.info("%.3f frames/s file-to-HBM-to-host (PNG decode included, no encode)", runs / elapsed)

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(uva):
     L = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert _lib.load().uva_abi_version() == _lib.ABI_VERSION == 14
+    assert _lib.load().uva_abi_version() == _lib.ABI_VERSION == 15
 
 
 @pytest.mark.parametrize("key,facts", [("2x", (2, 64, 18)), ("4x", (4, 64, 18)), ("1x", (1, 24, 10))])

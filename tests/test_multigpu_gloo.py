@@ -227,3 +227,95 @@ def test_bench_parity_windows_are_exact_for_an_exact_result(tile):
     bad = got.copy()
     bad[0, 0, 0] ^= 4
     assert bench.parity_windows("2x", img, bad, 2, 18, tile, win=24)["max_abs_lsb"] == 4
+
+
+# ---- round 6: per-rank records, the shared frame counter (--dynamic) ----------------------------------------------------------
+def _record_rank(rank, world, device, barrier, slots, argv):
+    """a rank of launch_ranks(): pulls frames off the ONE counter (a slow rank takes fewer), then the ranks exchange records"""
+    sys.path.insert(0, ROOT)
+    import time
+    import bench
+    comm = bench.ForkComm(rank, world, barrier, slots)
+    cpath = os.path.join(bench.job_scratch_dir(), "frame_counter")
+    if rank == 0:
+        bench.FileCounter(cpath, create=True).close()
+    comm.barrier()
+    counter = bench.FileCounter(cpath)
+    total, mine = 64, []
+
+    def region():
+        while True:
+            i = counter.take(2)
+            if i >= total:
+                break
+            mine.extend(range(i, min(i + 2, total)))
+            time.sleep(0.02 if rank == 1 else 0.002)        # rank 1 is the slow GPU
+    own = []
+    elapsed = bench.timed_region(region, lambda: None, comm.barrier, comm.max_over_ranks, own=own)
+    assert 0 < own[0] <= elapsed + 1e-6
+    rec = {"rank": rank, "device": device, "numa_node": rank % 2, "frames_K": len(mine), "fps_K": len(mine) / own[0], "fps_E": None,
+           "h2d_GBps": 50.0 + rank, "d2h_GBps": 40.0, "first_frame_ms": 12.5, "frames": mine}
+    records = bench.gather_records(comm, rec)
+    assert [r["rank"] for r in records] == list(range(world))
+    flat = sorted(f for r in records for f in r["frames"])
+    assert flat == list(range(total)), "every frame taken exactly once"
+    assert records[1]["frames_K"] < min(r["frames_K"] for r in records if r["rank"] != 1), "the slow rank took fewer frames"
+    summary = bench.per_rank_summary(records)
+    assert summary["h2d_GBps"] == {"min": 50.0, "max": 50.0 + world - 1, "mean": round(50.0 + (world - 1) / 2, 3)}
+    assert "rank" not in summary and "numa_node" not in summary and summary["frames_K"]["max"] > summary["frames_K"]["min"]
+    if rank == 0:
+        with open(argv[1], "w") as f:
+            import json
+            json.dump({"per_rank": records, "per_rank_summary": summary}, f)
+
+
+def test_eight_ranks_share_one_frame_counter_and_report_per_rank(tmp_path, monkeypatch):
+    """the first real 8-GPU run must explain itself -- per-rank records (device, NUMA node, K and E rates,
+    PCIe rates, first-frame time) in the one JSON line, min / max / mean over ranks, and a --dynamic mode in which the ranks pull
+    frame indices from one shared counter.  Eight self-launched ranks on CPU: schema, exactly-once, and the slow rank takes less."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.delenv("UVA_BENCH_JOB_DIR", raising=False)
+    out = tmp_path / "line.json"
+    assert bench.launch_ranks(8, list(range(8)), ["bench.py", str(out)], target=_record_rank) == 0
+    line = json.loads(out.read_text())
+    assert len(line["per_rank"]) == 8
+    for r in line["per_rank"]:
+        assert {"rank", "device", "numa_node", "frames_K", "fps_K", "fps_E", "h2d_GBps", "d2h_GBps", "first_frame_ms"} <= set(r)
+    assert sum(r["frames_K"] for r in line["per_rank"]) == 64
+    assert set(line["per_rank_summary"]) >= {"fps_K", "h2d_GBps", "d2h_GBps", "first_frame_ms", "frames_K"}
+
+
+def test_file_counter_is_exact_under_contention(tmp_path):
+    import threading
+    sys.path.insert(0, ROOT)
+    import bench
+    path = str(tmp_path / "c")
+    bench.FileCounter(path, create=True).close()
+    got = []
+
+    def worker():
+        c = bench.FileCounter(path)
+        for _ in range(200):
+            got.append(c.take(3))
+        c.close()
+    ts = [threading.Thread(target=worker) for _ in range(6)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert sorted(got) == list(range(0, 3 * 1200, 3))
+    c = bench.FileCounter(path)
+    c.reset()
+    assert c.take() == 0 and c.take() == 1
+
+
+def test_harness_prints_per_worker_rates():
+    """test_gpus.py -g 0,..,7: the calls' seconds grouped per worker (slot, GPU), slowest and fastest named"""
+    sys.path.insert(0, ROOT)
+    import test_gpus
+    times = {(k, str(k % 4)): [0.1 + 0.01 * k] * (3 if k else 2) for k in range(8)}
+    lines = test_gpus.per_worker_table(times, elapsed=0.5)
+    assert len(lines) == 1 + 8 + 1
+    assert "worker 0 on GPU 0: 2 calls, 0.1000 s per call, 10.00 frames/s" in lines[1]
+    assert "worker 7 on GPU 3: 3 calls" in lines[8]
+    assert "slowest / fastest worker: 5.88 / 10.00 frames/s" in lines[-1] and "the pool's 46.00" in lines[-1]

@@ -81,3 +81,68 @@ def test_too_large_frame_is_refused():
     need, stride = ctypes.c_size_t(0), ctypes.c_int(0)
     assert L.uva_debug_sub10_rows(20000, 20000, 256, None, 0, need, None, stride) != 0
     assert b"too large" in L.uva_last_error()
+
+
+# ---- several frames of one geometry in one launch (uva_net_process_u8_device_batch, round 6) -------------------------------
+def rows_for_batch(h, w, frames, grid=256):
+    L = _lib.load()
+    need, stride = ctypes.c_size_t(0), ctypes.c_int(0)
+    L.uva_debug_sub10_rows_batch(h, w, frames, grid, None, 0, need, None, stride)
+    words = np.zeros(need.value, np.uint32)
+    nrows = np.zeros(grid, np.int32)
+    rc = L.uva_debug_sub10_rows_batch(h, w, frames, grid, words.ctypes.data, words.size, need, nrows.ctypes.data, stride)
+    assert rc == 0, L.uva_last_error()
+    return words.view(np.int32).reshape(grid, stride.value, 4), nrows, stride.value
+
+
+@pytest.mark.parametrize("h,w,frames", [(1080, 1920, 2), (1080, 1920, 3), (1080, 1920, 4), (480, 640, 8), (7, 5, 5), (1, 1, 8), (720, 1280, 8)])
+def test_batch_rows_cover_every_frame_once(h, w, frames):
+    """the sequence runs over (frame, strip, row): every pixel of every frame written exactly once, a segment never
+    straddles two frames, warm-up / tail rows and the distance word as for one frame"""
+    rows, nrows, stride = rows_for_batch(h, w, frames)
+    assert stride <= 640                     # S10_MAX_ROWS: the kernel's LDS copy
+    cover = np.zeros((frames, h, w), np.int32)
+    for b in range(rows.shape[0]):
+        r = rows[b, :nrows[b]]
+        i = 0
+        while i < len(r):
+            j = i
+            while j + 1 < len(r) and r[j + 1, 0] == r[j, 0] + 1 and r[j + 1, 1] == r[i, 1] and (r[j + 1, 2] >> 8) == (r[i, 2] >> 8):
+                j += 1
+            seg = r[i:j + 1]
+            f = int(seg[0, 2]) >> 8
+            assert 0 <= f < frames and ((seg[:, 2] >> 8) == f).all()
+            emit = np.flatnonzero(seg[:, 2] & 1)
+            assert len(emit) >= 1 and emit[0] == NL and len(seg) - 1 - emit[-1] == NL and (np.diff(emit) == 1).all()
+            k = np.arange(len(seg))
+            assert (seg[:, 3] == np.where(k < emit[0], emit[0] - k, np.where(k > emit[-1], k - emit[-1], 0))).all()
+            x0 = int(seg[0, 1])
+            y0, y1 = int(seg[emit[0], 0]), int(seg[emit[-1], 0]) + 1
+            assert (x0 + NL) % VALID == 0 and 0 <= y0 and y1 <= h
+            cover[f, y0:y1, max(x0 + NL, 0):min(x0 + NL + VALID, w)] += 1
+            i = j + 1
+    assert (cover == 1).all()
+
+
+def test_batch_of_one_is_the_single_frame_list():
+    a, na, sa = rows_for(1080, 1920)
+    b, nb, sb = rows_for_batch(1080, 1920, 1)
+    assert sa == sb and (na == nb).all() and (a == b).all()
+
+
+def test_batches_pay_the_warm_up_rows_once_per_launch():
+    """what the batch is for: a workgroup's steps per frame (its rows + the pipeline's 20 steps of fill and drain) fall with
+    the number of frames in the launch -- 175 for one 1080p frame, ~155 at two, ~145 at four"""
+    per_frame = {}
+    for k in (1, 2, 4):
+        _, nrows, _ = rows_for_batch(1080, 1920, k)
+        per_frame[k] = (nrows.max() + 20) / k
+    assert per_frame[1] > 170 and per_frame[2] < 160 and per_frame[4] < 150, per_frame
+
+
+def test_a_batch_that_does_not_fit_is_refused():
+    L = _lib.load()
+    need, stride = ctypes.c_size_t(0), ctypes.c_int(0)
+    assert L.uva_debug_sub10_rows_batch(1080, 1920, 8, 256, None, 0, need, None, stride) != 0      # 8 x 135 rows > 640
+    assert L.uva_debug_sub10_rows_batch(1080, 1920, 9, 256, None, 0, need, None, stride) != 0      # > S10_MAXB
+    assert L.uva_debug_sub10_rows_batch(1080, 1920, 0, 256, None, 0, need, None, stride) != 0

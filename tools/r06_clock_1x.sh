@@ -1,0 +1,46 @@
+#!/bin/bash
+# Run ON THE MI355X BOX (gpurun).  VERDICT r5 weak 6: one sub10_kernel binary read 3 075-3 600 frames/s on different boxes
+# (17 %) while the 2x net's spread is 3-4 %.  Is it the clock?  The 1x net's launch is 0.28 ms of light work (the package
+# does not reach its power cap), so its rate should follow whatever shader clock the box's firmware grants -- measured here:
+# the shader clock and package power sampled WHILE a long run is in flight, free-running and then with the clock capped by
+# `rocm-smi --setperfdeterminism` at three values; frames/s divided by the sampled clock should be one number.
+O=gpurun_out/${1:-r06_clock}; mkdir -p $O
+P='import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print("frames/s", d["value"], "frac", d["roofline"]["frac"], "launch_ms", d["roofline"]["avg_launch_ms"], "frames_per_launch", d["roofline"].get("frames_per_launch"))'
+sample() {  # $1 = label, rest = bench args; the clock and the power are sampled for the whole run, the busy samples count
+  local label=$1; shift
+  python bench.py "$@" --no-cpu-baseline --no-parity > $O/run_$label.json 2> $O/run_$label.err &
+  local pid=$!
+  : > $O/smi_$label.txt
+  while kill -0 $pid 2>/dev/null; do
+    rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|Power" | tr '\n' ' ' >> $O/smi_$label.txt; echo >> $O/smi_$label.txt; sleep 0.4
+  done
+  wait $pid
+  echo -n "$label: "; python -c "$P" < $O/run_$label.json
+  python - $O/smi_$label.txt <<'PY'
+import re, sys
+rows = []
+for line in open(sys.argv[1]):
+    clk = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", line)
+    pw = re.search(r"Power \(W\): ([0-9.]+)", line)
+    if clk and pw:
+        rows.append((float(pw.group(1)), int(clk.group(1))))
+if rows:
+    top = max(p for p, _ in rows)
+    busy = [(p, c) for p, c in rows if p >= 0.8 * top]
+    print("   busy samples %d of %d: sclk mean %.0f MHz (min %d, max %d), package power mean %.0f W" % (
+        len(busy), len(rows), sum(c for _, c in busy) / len(busy), min(c for _, c in busy), max(c for _, c in busy), sum(p for p, _ in busy) / len(busy)))
+PY
+}
+python -c "import torch" 2>/dev/null     # (a fresh box pages the image in for a minute or two: not inside a sample)
+rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|Power" | head -4
+echo "== free-running"
+sample free_1x_b1 --workload 1x_hurrdeblur_1080p --batch 1 --steps 40000 --warmup 200 --repeats 1
+sample free_1x_b4 --workload 1x_hurrdeblur_1080p --batch 4 --steps 40000 --warmup 200 --repeats 1
+sample free_2x --workload 2x_compact_1080p --steps 6000 --warmup 50 --repeats 1
+for mhz in 2100 1900 1700; do
+  echo "== rocm-smi --setperfdeterminism $mhz"
+  rocm-smi --setperfdeterminism $mhz 2>&1 | grep -v "^$" | tail -2
+  sample cap${mhz}_1x_b1 --workload 1x_hurrdeblur_1080p --batch 1 --steps 40000 --warmup 200 --repeats 1
+  sample cap${mhz}_2x --workload 2x_compact_1080p --steps 6000 --warmup 50 --repeats 1
+done
+rocm-smi --resetperfdeterminism 2>&1 | tail -1

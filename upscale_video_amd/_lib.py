@@ -6,15 +6,15 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UVA_LIB_PATH") or os.path.join(_HERE, "libuva.so")   # override: A/B builds
 
 # every symbol include/uva.h declares
-ABI_VERSION = 14  # include/uva.h UVA_ABI_VERSION
+ABI_VERSION = 15  # include/uva.h UVA_ABI_VERSION
 
 SYMBOLS = [
     "uva_get_gpu_count", "uva_get_default_gpu_index", "uva_get_gpu_info", "uva_get_gpu_pci_bus_id",
-    "uva_debug_trunk2_schedule", "uva_debug_trunkw_schedule", "uva_debug_sub10_rows", "uva_debug_sub5_rows", "uva_net_submit_u8_png", "uva_png_workspace_bytes",
+    "uva_debug_trunk2_schedule", "uva_debug_trunkw_schedule", "uva_debug_sub10_rows", "uva_debug_sub10_rows_batch", "uva_debug_sub5_rows", "uva_net_submit_u8_png", "uva_png_workspace_bytes",
     "uva_png_assemble", "uva_png_deflate_u8", "uva_debug_png_deflate_host", "uva_png_decode_bgr", "uva_debug_zlib_decompress", "uva_net_debug_generic_plan", "uva_debug_generic_segments", "uva_debug_generic_segments_planes", "uva_debug_generic_batches", "uva_denoise_u8", "uva_denoise_u8_device", "uva_denoise_synchronize", "uva_debug_denoise_stage", "uva_destroy_gpu_instance",
     "uva_net_create", "uva_net_set_device", "uva_net_device", "uva_net_load_param", "uva_net_load_model",
     "uva_net_destroy", "uva_net_scale", "uva_net_num_features", "uva_net_num_convs",
-    "uva_net_extract_f32", "uva_net_process_u8", "uva_net_process_u8_device", "uva_net_synchronize",
+    "uva_net_extract_f32", "uva_net_process_u8", "uva_net_process_u8_device", "uva_net_process_u8_device_batch", "uva_net_synchronize",
     "uva_net_wait_for", "uva_net_submit_u8", "uva_net_collect_u8", "uva_host_alloc", "uva_host_free",
     "uva_net_debug_read_activation", "uva_net_set_profiling", "uva_net_kernel_stats",
     "uva_net_debug_packed_weights", "uva_last_error", "uva_abi_version",
@@ -85,6 +85,7 @@ def load():
     decl("uva_png_decode_bgr", [c_p, c_sz, c_p, c_sz, pi, pi])
     decl("uva_debug_zlib_decompress", [c_p, c_sz, c_p, c_sz])
     decl("uva_debug_sub10_rows", [c_i, c_i, c_i, c_p, c_sz, psz, c_p, pi])
+    decl("uva_debug_sub10_rows_batch", [c_i, c_i, c_i, c_i, c_p, c_sz, psz, c_p, pi])
     decl("uva_debug_sub5_rows", [c_i, c_i, c_i, c_p, c_sz, psz, c_p, pi])
     decl("uva_debug_trunk2_schedule", [c_i, c_i, c_i, c_i, c_i, c_p, c_sz, psz, c_p, pi, c_p, c_i, pi, pll])
     decl("uva_debug_trunkw_schedule", [c_i, c_i, c_i, c_i, c_i, c_p, c_sz, psz, c_p, pi, c_p, c_i, pi, pll])
@@ -105,6 +106,7 @@ def load():
     decl("uva_net_collect_u8", [c_p, ctypes.c_longlong])
     decl("uva_host_free", [c_p], "void")
     decl("uva_net_process_u8_device", [c_p, c_p, c_i, c_i, c_sz, c_p, c_sz, c_i, c_i])
+    decl("uva_net_process_u8_device_batch", [c_p, c_p, c_p, c_i, c_i, c_i, c_sz, c_sz, c_i, c_i])
     decl("uva_net_debug_read_activation", [c_p, c_i, c_p, c_i, c_i])
     decl("uva_net_set_profiling", [c_p, c_i])
     decl("uva_net_kernel_stats", [c_p, c_i, pll, ctypes.POINTER(ctypes.c_double)])

@@ -13,6 +13,7 @@
 #include "uva_png.hip.h"
 #include "uva_wino.h"
 #include "uva_sub5.h"
+#include "uva_sub10.h"
 
 namespace uva {   // uva_pngread.cpp
 int png_read_bgr(const uint8_t* file, size_t len, uint8_t* out, size_t cap, int* h_out, int* w_out, std::string& err);
@@ -69,10 +70,12 @@ struct Workspace {
     char* act_base[2] = {nullptr, nullptr};
     _Float16* act[2] = {nullptr, nullptr};
     // sub10_kernel (the whole 24-feature 1x net in one launch): per-workgroup row descriptors
-    uint4* d_rows10 = nullptr;
-    int* d_nrows10 = nullptr;
-    int max_rows10 = 0, grid10 = 0;
-    bool sub10_unfit = false;
+    // (one set per number of frames in a launch, built on first use: [k - 1] = k frames; uva_net_process_u8_device_batch)
+    uint4* d_rows10[S10_MAXB] = {};
+    int* d_nrows10[S10_MAXB] = {};
+    int max_rows10[S10_MAXB] = {}, grid10 = 0;
+    bool sub10_unfit = false;             // one frame does not fit the kernel's row table: the per-pair path
+    int sub10_max_batch = S10_MAXB;       // the largest number of frames whose row table fits (found on demand)
     // sub5_kernel (the 1x net as two launches of five layers, two pipelines per workgroup): row descriptors and the 24-channel
     // image between the launches
     uint4* d_rows5 = nullptr;
@@ -98,10 +101,8 @@ struct Workspace {
         if (d_nstepsw) (void)hipFree(d_nstepsw);
         d_stepsw = nullptr;
         d_nstepsw = nullptr;
-        if (d_rows10) (void)hipFree(d_rows10);
-        if (d_nrows10) (void)hipFree(d_nrows10);
-        d_rows10 = nullptr;
-        d_nrows10 = nullptr;
+        for (auto& q : d_rows10) { if (q) (void)hipFree(q); q = nullptr; }
+        for (auto& q : d_nrows10) { if (q) (void)hipFree(q); q = nullptr; }
         if (d_rows5) (void)hipFree(d_rows5);
         if (d_nrows5) (void)hipFree(d_nrows5);
         if (d_mid5) (void)hipFree(d_mid5);
@@ -704,9 +705,12 @@ int launch_trunkw(uva_net* n, const Workspace* ws, TrunkwArgs& a, int i, bool in
 // Row descriptors of sub10_kernel for an h x w frame: 60-column strips, the sequence (strip, row) dealt out to the
 // workgroups in contiguous ranges; every range (segment) starts 10 rows early and ends 9 rows late (the rows the
 // layers in between need), only its own rows are written out.
-int build_sub10_rows(int h, int w, int grid, std::vector<uint4>& rows, std::vector<int>& nrows, int* max_rows)
+// `frames` frames of the one geometry in one launch: the sequence runs over (frame, strip, row); a row's frame sits in z >> 8.
+int build_sub10_rows(int h, int w, int frames, int grid, std::vector<uint4>& rows, std::vector<int>& nrows, int* max_rows)
 {
-    const int ns = (w + S10_VALID - 1) / S10_VALID;
+    if (frames < 1 || frames > S10_MAXB || h > S10_MAX_H) return 2;
+    const int ns1 = (w + S10_VALID - 1) / S10_VALID;
+    const int ns = ns1 * frames;             // k = frame * ns1 + strip
     const long long total = (long long)ns * h;
     struct Seg { int k, y0, n; };
     std::vector<std::vector<Seg>> per_wg;
@@ -740,7 +744,8 @@ int build_sub10_rows(int h, int w, int grid, std::vector<uint4>& rows, std::vect
                 // w = how many rows y lies outside the segment's own rows (0 inside, 1..10): layer s (0 = the first) is needed on rows
                 // with w <= 9 - s only, and the kernel's wave of that layer skips the others
                 const int dist = y < sg.y0 ? sg.y0 - y : y >= sg.y0 + sg.n ? y - (sg.y0 + sg.n - 1) : 0;
-                out[g] = make_uint4((unsigned)y, (unsigned)(sg.k * S10_VALID - S10_NL), dist == 0 ? 1u : 0u, (unsigned)dist);
+                out[g] = make_uint4((unsigned)y, (unsigned)((sg.k % ns1) * S10_VALID - S10_NL), (dist == 0 ? 1u : 0u) | ((unsigned)(sg.k / ns1) << 8),
+                                    (unsigned)dist);
             }
         nrows[b] = g;
     }
@@ -803,12 +808,23 @@ int launch_sub5(uva_net* n, Workspace* ws, const void* src, size_t src_stride, v
             ws->sub5_unfit = true;
             return 2;
         }
-        HIP_TRY(hipMalloc((void**)&ws->d_mid5, (size_t)ws->h * ws->w * S5_MIDB));
-        HIP_TRY(hipMalloc((void**)&ws->d_rows5, rows.size() * sizeof(uint4)));
-        HIP_TRY(hipMalloc((void**)&ws->d_nrows5, nrows.size() * sizeof(int)));
-        HIP_TRY(hipMemcpyAsync(ws->d_rows5, rows.data(), rows.size() * sizeof(uint4), hipMemcpyHostToDevice, n->stream));
-        HIP_TRY(hipMemcpyAsync(ws->d_nrows5, nrows.data(), nrows.size() * sizeof(int), hipMemcpyHostToDevice, n->stream));
-        HIP_TRY(hipStreamSynchronize(n->stream));
+        // into locals first: a failure half way leaves nothing in the workspace (the next call starts over instead of leaking)
+        char* d_mid = nullptr;
+        uint4* d_rows = nullptr;
+        int* d_nrows = nullptr;
+        hipError_t e = hipMalloc((void**)&d_mid, (size_t)ws->h * ws->w * S5_MIDB);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_rows, rows.size() * sizeof(uint4));
+        if (e == hipSuccess) e = hipMalloc((void**)&d_nrows, nrows.size() * sizeof(int));
+        if (e == hipSuccess) e = hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(uint4), hipMemcpyHostToDevice, n->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_nrows, nrows.data(), nrows.size() * sizeof(int), hipMemcpyHostToDevice, n->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(n->stream);
+        if (e != hipSuccess) {
+            if (d_mid) (void)hipFree(d_mid);
+            if (d_rows) (void)hipFree(d_rows);
+            if (d_nrows) (void)hipFree(d_nrows);
+            return fail(std::string("sub5 workspace: ") + hipGetErrorString(e));
+        }
+        ws->d_mid5 = d_mid; ws->d_rows5 = d_rows; ws->d_nrows5 = d_nrows;
     }
     for (int part = 0; part < 2; ++part) {
         Sub5Args a;
@@ -829,45 +845,59 @@ int launch_sub5(uva_net* n, Workspace* ws, const void* src, size_t src_stride, v
     return 0;
 }
 
-// the whole 24-feature 1x net in one launch (u8 route, one plane); returns 2 when the frame is too large for it
-int launch_sub10(uva_net* n, Workspace* ws, const void* src, size_t src_stride, void* dst, size_t dst_stride,
+// the whole 24-feature 1x net in one launch (u8 route, one plane per frame), `frames` frames of the workspace's geometry at once;
+// returns 2 when that many frames do not fit the kernel's row table (the caller takes fewer, or for one frame another path)
+int launch_sub10(uva_net* n, Workspace* ws, const void* const* srcs, size_t src_stride, void* const* dsts, size_t dst_stride, int frames,
                  unsigned long long* dbg = nullptr)
 {
-    if (ws->sub10_unfit) return 2;
-    if (!ws->d_rows10) {
+    if (ws->sub10_unfit || frames < 1 || frames > ws->sub10_max_batch) return 2;
+    const int bi = frames - 1;
+    if (!ws->d_rows10[bi]) {
         std::vector<uint4> rows;
         std::vector<int> nrows;
         ws->grid10 = std::max(8, (n->ncu / 8) * 8);
-        if (build_sub10_rows(ws->h, ws->w, ws->grid10, rows, nrows, &ws->max_rows10)) {
-            ws->sub10_unfit = true;
+        if (build_sub10_rows(ws->h, ws->w, frames, ws->grid10, rows, nrows, &ws->max_rows10[bi])) {
+            if (frames == 1) ws->sub10_unfit = true;
+            ws->sub10_max_batch = frames - 1;
             return 2;
         }
-        HIP_TRY(hipMalloc((void**)&ws->d_rows10, rows.size() * sizeof(uint4)));
-        HIP_TRY(hipMalloc((void**)&ws->d_nrows10, nrows.size() * sizeof(int)));
-        HIP_TRY(hipMemcpyAsync(ws->d_rows10, rows.data(), rows.size() * sizeof(uint4), hipMemcpyHostToDevice, n->stream));
-        HIP_TRY(hipMemcpyAsync(ws->d_nrows10, nrows.data(), nrows.size() * sizeof(int), hipMemcpyHostToDevice, n->stream));
-        HIP_TRY(hipStreamSynchronize(n->stream));
+        uint4* d_rows = nullptr;
+        int* d_nrows = nullptr;
+        hipError_t e = hipMalloc((void**)&d_rows, rows.size() * sizeof(uint4));
+        if (e == hipSuccess) e = hipMalloc((void**)&d_nrows, nrows.size() * sizeof(int));
+        if (e == hipSuccess) e = hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(uint4), hipMemcpyHostToDevice, n->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_nrows, nrows.data(), nrows.size() * sizeof(int), hipMemcpyHostToDevice, n->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(n->stream);
+        if (e != hipSuccess) {                 // nothing half-made stays in the workspace
+            if (d_rows) (void)hipFree(d_rows);
+            if (d_nrows) (void)hipFree(d_nrows);
+            return fail(std::string("sub10 row table: ") + hipGetErrorString(e));
+        }
+        ws->d_rows10[bi] = d_rows;
+        ws->d_nrows10[bi] = d_nrows;
     }
     Sub10Args a;
     std::memset(&a, 0, sizeof a);
-    a.src = (const uint8_t*)src; a.src_stride = src_stride;
-    a.dst = (uint8_t*)dst; a.dst_stride = dst_stride;
+    for (int f = 0; f < S10_MAXB; ++f) {       // (unused slots repeat the last frame: never addressed, never null)
+        a.src[f] = (const uint8_t*)srcs[std::min(f, frames - 1)];
+        a.dst[f] = (uint8_t*)dsts[std::min(f, frames - 1)];
+    }
+    a.src_stride = src_stride;
+    a.dst_stride = dst_stride;
     a.h = ws->h; a.w = ws->w;
-    a.rows = ws->d_rows10; a.nrows = ws->d_nrows10; a.max_rows = ws->max_rows10;
+    a.rows = ws->d_rows10[bi]; a.nrows = ws->d_nrows10[bi]; a.max_rows = ws->max_rows10[bi];
     a.dbg = dbg;
     for (int i = 0; i < S10_NL; ++i) {
         a.wpk[i] = n->layers[i].wpk_s10;
         a.bias[i] = n->layers[i].bias_s10;
         a.slope[i] = n->layers[i].slope;
     }
-    const size_t lds = sub10_lds_bytes();
-    if (!n->attr_set[10]) {
-        HIP_TRY(hipFuncSetAttribute((const void*)sub10_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        n->attr_set[10] = true;
-    }
-    hipLaunchKernelGGL(sub10_kernel, dim3(ws->grid10), dim3(64 * S10_NW), lds, n->stream, a);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_sub10_kernel(n->stream, ws->grid10, a));
     return 0;
+}
+int launch_sub10(uva_net* n, Workspace* ws, const void* src, size_t src_stride, void* dst, size_t dst_stride, unsigned long long* dbg = nullptr)
+{
+    return launch_sub10(n, ws, &src, src_stride, &dst, dst_stride, 1, dbg);
 }
 
 // two trunk layers of the 24-feature net per launch (pair24_kernel), two persistent workgroups per CU
@@ -1321,37 +1351,54 @@ void resolve_events(uva_net* n)
 }
 
 // The whole graph for one frame.  stop_after >= 0: run only convolutions 0..stop_after (debug).
+// does this call go through sub10_kernel / sub5_kernel (the 24-feature 1x net on a whole-frame plane, u8 in / u8 out)?
+bool sub10_route(const uva_net* n, const Workspace* ws, bool f32, int stop_after)
+{
+    const Graph& g = n->g;
+    return n->fuse_all && !f32 && stop_after < 0 && g.nf == 24 && g.scale == 1 && (int)g.convs.size() == S10_NL && ws->planes.size() == 1 &&
+           n->layers[0].wpk_s10 && !ws->sub10_unfit;
+}
+
+// `frames` frames (1 .. S10_MAXB) of the workspace's geometry through the 1x net in ONE launch, with the profiling events of one
+// launch around it; 0 = done, 1 = error, 2 = does not fit (fewer frames, or for one frame the layer-pair path)
+int run_sub10(uva_net* n, Workspace* ws, const void* const* srcs, size_t src_stride, void* const* dsts, size_t dst_stride, int frames)
+{
+    uva_net::EvSet ev1;
+    const bool prof1 = n->prof;
+    if (prof1) {
+        for (auto& e : ev1.e) e = nullptr;
+        for (auto& e : ev1.e) {
+            e = take_event(n);
+            if (!e) return 1;
+        }
+        HIP_TRY(hipEventRecord(ev1.e[0], n->stream));
+        HIP_TRY(hipEventRecord(ev1.e[1], n->stream));
+    }
+    int rc = 2, launches = 2;
+    if (frames == 1 && n->split5 && !ws->sub5_unfit) rc = launch_sub5(n, ws, srcs[0], src_stride, dsts[0], dst_stride);
+    if (rc == 2) { rc = launch_sub10(n, ws, srcs, src_stride, dsts, dst_stride, frames); launches = 1; }
+    if (prof1) {
+        if (rc == 0) {
+            HIP_TRY(hipEventRecord(ev1.e[2], n->stream));
+            HIP_TRY(hipEventRecord(ev1.e[3], n->stream));
+            ev1.ntrunk = launches;
+            n->ev_pending.push_back(ev1);
+        } else {
+            for (auto e : ev1.e) n->ev_free.push_back(e);
+        }
+    }
+    return rc;
+}
+
 int run_graph(uva_net* n, Workspace* ws, bool f32, const void* src, size_t src_stride, void* dst,
               size_t dst_stride, int stop_after)
 {
     const Graph& g = n->g;
     const int nconv = (int)g.convs.size();
     // the 24-feature 1x net on a whole-frame plane, u8 in / u8 out: one launch for all ten convolutions
-    if (n->fuse_all && !f32 && stop_after < 0 && g.nf == 24 && g.scale == 1 && nconv == S10_NL && ws->planes.size() == 1 &&
-        n->layers[0].wpk_s10 && !ws->sub10_unfit) {
-        uva_net::EvSet ev1;
-        const bool prof1 = n->prof;
-        if (prof1) {
-            for (auto& e : ev1.e) e = nullptr;
-            for (auto& e : ev1.e) {
-                e = take_event(n);
-                if (!e) return 1;
-            }
-            HIP_TRY(hipEventRecord(ev1.e[0], n->stream));
-            HIP_TRY(hipEventRecord(ev1.e[1], n->stream));
-        }
-        int rc = 2, launches = 2;
-        if (n->split5 && !ws->sub5_unfit) rc = launch_sub5(n, ws, src, src_stride, dst, dst_stride);
-        if (rc == 2) { rc = launch_sub10(n, ws, src, src_stride, dst, dst_stride); launches = 1; }
-        if (rc == 1) return 1;
-        if (prof1) {
-            HIP_TRY(hipEventRecord(ev1.e[2], n->stream));
-            HIP_TRY(hipEventRecord(ev1.e[3], n->stream));
-            ev1.ntrunk = launches;
-            if (rc == 0) n->ev_pending.push_back(ev1);
-            else for (auto e : ev1.e) n->ev_free.push_back(e);
-        }
-        if (rc == 0) return 0;
+    if (sub10_route(n, ws, f32, stop_after)) {
+        const int rc = run_sub10(n, ws, &src, src_stride, &dst, dst_stride, 1);
+        if (rc != 2) return rc;
     }
     const bool prof = n->prof && stop_after < 0;
     uva_net::EvSet ev;
@@ -2611,6 +2658,45 @@ int uva_net_process_u8_device(uva_net* n, const void* d_in, int h, int w, size_t
     return run_graph(n, ws, false, d_in, in_stride, d_out, out_stride, -1);
 }
 
+// `count` frames of ONE geometry, all resident on the net's device.  The 1x net takes up to S10_MAXB of them per launch
+// (sub10_kernel: the segments' warm-up rows and the pipeline's fill and drain are paid once per launch, not once per frame);
+// every other net -- and whatever does not fit the kernel's row table -- runs frame by frame, exactly as `count` calls of
+// uva_net_process_u8_device would.  The bytes are those of the single-frame calls either way (tests).
+int uva_net_process_u8_device_batch(uva_net* n, const void* const* d_in, void* const* d_out, int count, int h, int w,
+                                    size_t in_stride, size_t out_stride, int tile_size, int border)
+{
+    if (check_dims(n, h, w)) return 1;
+    if (count < 0 || (count > 0 && (!d_in || !d_out))) return fail("bad frame list");
+    for (int i = 0; i < count; ++i)
+        if (!d_in[i] || !d_out[i]) return fail("null frame pointer");
+    if (count == 0) return 0;
+    if (ensure_device(n)) return 1;
+    if (in_stride < (size_t)w * 3 || out_stride < (size_t)w * uva_net_scale(n) * 3) return fail("row stride too small");
+    Workspace* ws = nullptr;
+    if (!n->generic && get_workspace(n, h, w, tile_size, border, &ws)) return 1;
+    int i = 0;
+    if (ws && sub10_route(n, ws, false, -1) && !n->split5) {
+        if ((unsigned long long)in_stride * (unsigned long long)h >= (1ull << 32) - 64 ||
+            (unsigned long long)out_stride * (unsigned long long)h >= (1ull << 32) - 64)
+            return fail("frame of 4 GB or more");
+        while (i < count) {
+            const int k = std::min(count - i, std::max(1, ws->sub10_max_batch));
+            const int rc = run_sub10(n, ws, d_in + i, in_stride, d_out + i, out_stride, k);
+            if (rc == 1) return 1;
+            if (rc == 2) {
+                if (k == 1) break;              // not even one frame fits: the rest goes frame by frame below
+                continue;                       // (launch_sub10 lowered sub10_max_batch)
+            }
+            i += k;
+            n->last.valid = true; n->last.ws = ws; n->last.f32 = false; n->last.src = d_in[i - 1]; n->last.src_stride = in_stride;
+            n->last.dst = d_out[i - 1]; n->last.dst_stride = out_stride;
+        }
+    }
+    for (; i < count; ++i)
+        if (uva_net_process_u8_device(n, d_in[i], h, w, in_stride, d_out[i], out_stride, tile_size, border)) return 1;
+    return 0;
+}
+
 // ---- pipelined host route -----------------------------------------------------------------------
 namespace {
 bool is_pinned_host(const void* p)
@@ -3011,7 +3097,7 @@ int uva_net_debug_trunk_stamps(uva_net* n, unsigned long long* out, int max_tile
         // workgroup 0 (max_tiles*8 words must hold 40 per step); *tiles = steps
         if (n->last.f32 || !n->last.dst || ws->planes.size() != 1) { (void)hipFree(d); return fail("sub10 stamps need a previous whole-frame uva_net_process_u8 call"); }
         int rc7 = launch_sub10(n, ws, n->last.src, n->last.src_stride, n->last.dst, n->last.dst_stride);
-        if (rc7 == 0 && (size_t)(ws->max_rows10 + S10_DRAIN + 2) * 4 * S10_NW > (size_t)max_tiles * 8) { (void)hipFree(d); return fail("max_tiles too small"); }
+        if (rc7 == 0 && (size_t)(ws->max_rows10[0] + S10_DRAIN + 2) * 4 * S10_NW > (size_t)max_tiles * 8) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d); return fail("max_tiles too small"); }
         HIP_TRY(hipEventRecord(e0, n->stream));
         for (int r = 0; r < 50 && !rc7; ++r) rc7 = launch_sub10(n, ws, n->last.src, n->last.src_stride, n->last.dst, n->last.dst_stride);
         HIP_TRY(hipEventRecord(e1, n->stream));
@@ -3026,7 +3112,7 @@ int uva_net_debug_trunk_stamps(uva_net* n, unsigned long long* out, int max_tile
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
         (void)hipFree(d);
-        if (tiles) *tiles = ws->max_rows10 + S10_DRAIN;
+        if (tiles) *tiles = ws->max_rows10[0] + S10_DRAIN;
         return rc7 ? (rc7 == 2 ? fail("frame too large for sub10_kernel") : 1) : 0;
     }
     if (ablate == 9 || ablate == 10) {
@@ -3034,7 +3120,7 @@ int uva_net_debug_trunk_stamps(uva_net* n, unsigned long long* out, int max_tile
         // done (front wave), 2 at the barrier}] of workgroup 0; *tiles = steps; kernel_ms = both launches
         if (n->last.f32 || !n->last.dst || ws->planes.size() != 1) { (void)hipFree(d); return fail("sub5 stamps need a previous whole-frame uva_net_process_u8 call"); }
         int rc9 = launch_sub5(n, ws, n->last.src, n->last.src_stride, n->last.dst, n->last.dst_stride);
-        if (rc9 == 0 && (size_t)(ws->max_rows5 + 16) * 4 * 12 > (size_t)max_tiles * 8) { (void)hipFree(d); return fail("max_tiles too small"); }
+        if (rc9 == 0 && (size_t)(ws->max_rows5 + 16) * 4 * 12 > (size_t)max_tiles * 8) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d); return fail("max_tiles too small"); }
         HIP_TRY(hipEventRecord(e0, n->stream));
         for (int r = 0; r < 50 && !rc9; ++r) rc9 = launch_sub5(n, ws, n->last.src, n->last.src_stride, n->last.dst, n->last.dst_stride);
         HIP_TRY(hipEventRecord(e1, n->stream));
@@ -3261,11 +3347,17 @@ int uva_debug_trunkw_schedule(int h, int w, int tile_size, int border, int grid,
 int uva_debug_sub10_rows(int h, int w, int grid, uint32_t* rows_words, size_t capacity_words, size_t* needed_words,
                          int* nrows, int* stride)
 {
-    if (h <= 0 || w <= 0 || grid < 8 || grid % 8) return fail("bad argument");
+    return uva_debug_sub10_rows_batch(h, w, 1, grid, rows_words, capacity_words, needed_words, nrows, stride);
+}
+
+int uva_debug_sub10_rows_batch(int h, int w, int frames, int grid, uint32_t* rows_words, size_t capacity_words, size_t* needed_words,
+                               int* nrows, int* stride)
+{
+    if (h <= 0 || w <= 0 || grid < 8 || grid % 8 || frames < 1 || frames > S10_MAXB) return fail("bad argument");
     std::vector<uint4> rows;
     std::vector<int> nr;
     int max_rows = 0;
-    const int rc = build_sub10_rows(h, w, grid, rows, nr, &max_rows);
+    const int rc = build_sub10_rows(h, w, frames, grid, rows, nr, &max_rows);
     if (rc == 2) return fail("frame too large for the fused 1x kernel's row table");
     if (rc) return 1;
     if (needed_words) *needed_words = rows.size() * 4;

@@ -339,6 +339,18 @@ class Net:
             self._h, ctypes.c_void_p(d_in), h, w, in_stride or w * 3, ctypes.c_void_p(d_out),
             out_stride or w * s * 3, int(tile_size), int(border)))
 
+    def process_u8_device_batch(self, d_ins, h, w, d_outs, tile_size=0, border=0, in_stride=None, out_stride=None):
+        """Asynchronous: several dense u8 HWC frames of ONE geometry in this GPU's HBM (lists of raw device pointers) in one
+        call (include/uva.h uva_net_process_u8_device_batch).  The 1x net runs up to eight of them per kernel launch; the bytes
+        are those of one process_u8_device call per frame."""
+        n = len(d_ins)
+        assert n == len(d_outs)
+        s = self.scale
+        ins = (ctypes.c_void_p * n)(*[int(p) for p in d_ins])
+        outs = (ctypes.c_void_p * n)(*[int(p) for p in d_outs])
+        _lib.check(self._L.uva_net_process_u8_device_batch(
+            self._h, ins, outs, n, h, w, in_stride or w * 3, out_stride or w * s * 3, int(tile_size), int(border)))
+
     def denoise_u8_device(self, d_in, h, w, d_out, strength, after=None, in_stride=None, out_stride=None):
         """`-m n=K` on a frame in HBM, queued IN FRONT of this net (include/uva.h uva_denoise_u8_device): everything `after`
         (a net, or None) has been asked so far comes first, and whatever this net is asked from now on waits for the frame."""
