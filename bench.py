@@ -685,7 +685,7 @@ def run(args, comm, device):
             step_group(i0, min(batch, n_frames - i0))
 
     counter = None
-    if args.dynamic and world > 1:
+    if args.dynamic:
         cpath = os.path.join(job_scratch_dir(), "frame_counter")
         if rank == 0:
             FileCounter(cpath, create=True).close()
@@ -853,6 +853,8 @@ def run(args, comm, device):
         if pre is not None:
             frame_flops += conv_flops_per_px(pre.num_features, pre.num_convs, 1) * h * w
         traffic, traffic_source = pmc_traffic(args, nf, "sub10_kernel" if whole_net else kernel)
+        if whole_net and traffic is not None:
+            traffic = int(traffic * frames_per_launch)      # (the committed figure is one frame's launch: a batch moves as many frames' bytes)
         result = {
             "metric": "frames/sec 1080p->2x Compact (SRVGGNetCompact per-frame SR hot path)" if args.workload == "2x_compact_1080p"
                       else "frames/sec " + args.workload,

@@ -304,20 +304,48 @@ sys.exit(pytest.main(["-x", "-q", "-m", "gpu", os.path.join(sys.argv[1], "tests"
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sk", ["0", "1"])
+@pytest.mark.parametrize("sk", ["0", "1", "direct"])
 def test_long_segments_against_the_restatement(sk):
     """The persistent kernels' loops over the blocks / rows of a segment, and several segments per workgroup: with one
     workgroup per CU a frame small enough for the numpy restatement gives every workgroup at most one block, so the two
     parity tests are run again on EIGHT workgroups (UVA_GENERIC_GRID=8: 6-7 four-row blocks and 17 rows per workgroup),
-    with g_conv3_sw<6, 1> and with the k-split 32x32x16 kernel (UVA_GENERIC_SK=1) for the 192 -> 64 convolutions."""
+    with g_conv3_sww (the default since round 6: Winograd F(2,3)), with g_conv3_sw<6, 1> (UVA_GENERIC_WINO=0, "direct") and with the
+    k-split 32x32x16 kernel (UVA_GENERIC_SK=1) for the 192 -> 64 convolutions."""
     import subprocess
     import sys
     if os.environ.get("UVA_GENERIC_GRID"):
         pytest.skip("already the child")
-    r = subprocess.run([sys.executable, "-c", _GRID_CHILD, ROOT], env=dict(os.environ, UVA_GENERIC_GRID="8", UVA_GENERIC_SK=sk),
-                       capture_output=True, text=True)
+    env = dict(os.environ, UVA_GENERIC_GRID="8", UVA_GENERIC_SK="1" if sk == "1" else "0", UVA_GENERIC_WINO="0" if sk == "direct" else "1")
+    r = subprocess.run([sys.executable, "-c", _GRID_CHILD, ROOT], env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "2 passed" in r.stdout, r.stdout[-500:]
+
+
+@pytest.mark.gpu
+def test_winograd_conv5_against_the_direct_kernel(tmp_path):
+    """Round 6: a dense block's last convolution (192 -> 64) runs as 1-D Winograd F(2,3) (g_conv3_sww, csrc/uva_sww.hip.h);
+    UVA_GENERIC_WINO=0 keeps g_conv3_sw<6, 1>.  In exact arithmetic the same convolution; what moves is where fp16 rounds (the
+    transformed inputs and weights are the MFMA operands) -- 69 such layers deep the two must stay within ONE u8 level of each
+    other and well above 50 dB, whole frames and the reference tiling with ragged tiles (the planes narrower than a strip take
+    the layer-by-layer kernel either way: identical there)."""
+    import subprocess
+    import sys
+    from oracle import generic_oracle as go
+    b = str(tmp_path / "4x_Valar_v1.bin")
+    go.write_synthetic_bin(VALAR, b, seed=7, gain=0.5)
+    res = []
+    for v in ("1", "0"):
+        f = str(tmp_path / ("o%s.npz" % v))
+        subprocess.check_call([sys.executable, "-c", _FUSE_CHILD, ROOT, VALAR, b, f], env=dict(os.environ, UVA_GENERIC_WINO=v))
+        res.append(np.load(f))
+    some_differ = False
+    for k in res[0].files:
+        a, d = res[0][k], res[1][k]
+        diff = np.abs(a.astype(int) - d.astype(int))
+        assert diff.max() <= 1 and psnr_u8(a, d) >= 55, (k, int(diff.max()), psnr_u8(a, d))
+        some_differ |= bool(diff.max() > 0)
+        assert a.std() > 0
+    assert some_differ, "UVA_GENERIC_WINO changed nothing: is g_conv3_sww the kernel that ran?"
 
 
 @pytest.mark.gpu

@@ -363,3 +363,47 @@ def test_positional_writers_give_the_bytes_of_the_single_writer(tmp_path, thread
     rawvideo.stream_segments(str(src), a, h, w, mk(), 2, alloc=alloc, write_threads=threads)
     rawvideo.stream_segments(str(src), b, h, w, mk(), 2, alloc=alloc, write_threads=1)
     assert open(a, "rb").read() == open(b, "rb").read() == ref.getvalue()
+
+
+@pytest.mark.parametrize("splice", ["1", "0"])
+def test_results_into_a_pipe_by_vmsplice_are_the_bytes_of_write(splice, monkeypatch):
+    """stdout into ffmpeg is a pipe: result frames larger than the pipe's capacity are handed over with vmsplice (the pipe
+    refers to the result buffer's pages, no copy on our side) -- a SLOW reader must still see every frame intact and in order
+    although the eight result buffers are rewritten while it reads, and UVA_RAW_VMSPLICE=0 (plain write) gives the same bytes"""
+    import threading
+    import time
+    monkeypatch.setenv("UVA_RAW_VMSPLICE", splice)
+    h, w, nframes = 120, 160, 30                    # results 240 x 320 x 3 = 230 KB > the pipe's 64 KB
+    frames = _frames(nframes, h, w)
+    r, wfd = os.pipe()
+    got = []
+
+    def reader():
+        with os.fdopen(r, "rb") as f:
+            while True:
+                b = f.read(2 * h * 2 * w * 3)
+                if not b:
+                    return
+                got.append(b)
+                time.sleep(0.003)                   # slower than the producer: buffers come round while frames wait in the pipe
+    t = threading.Thread(target=reader)
+    t.start()
+    with os.fdopen(wfd, "wb") as fout:
+        sink_probe = rawvideo.PipeSink(fout)
+        assert (sink_probe._fd is not None) == (splice == "1")
+        n = rawvideo.stream(io.BytesIO(b"".join(f.tobytes() for f in frames)), fout, h, w, [(FakeNet(2), 0)],
+                            alloc=lambda s: np.empty(s, np.uint8))
+    t.join()
+    assert n == nframes and len(got) == nframes
+    for i, f in enumerate(frames):
+        assert got[i] == (np.repeat(np.repeat(f, 2, 0), 2, 1) + 1).tobytes(), i
+
+
+def test_frames_smaller_than_the_pipe_are_written_not_spliced():
+    r, wfd = os.pipe()
+    with os.fdopen(wfd, "wb") as fout, os.fdopen(r, "rb") as fin:
+        sink = rawvideo.PipeSink(fout)
+        a = np.arange(300, dtype=np.uint8)
+        sink.write(a)
+        sink.flush()
+        assert sink.spliced == 0 and fin.read(300) == a.tobytes()

@@ -12,7 +12,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_IFETCH SQ_LDS_BANK_CONFLICT" \
            "SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_SMEM"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $grp -d $OUT/p$i -o pmc --output-format csv -- python $R/bench.py --workload 1x_hurrdeblur_1080p --tile 0 --no-cpu-baseline --steps 10 --warmup 2 > $OUT.log 2>&1 || { echo "group failed: $grp"; tail -3 $OUT.log; }
+  rocprofv3 --kernel-trace --pmc $grp -d $OUT/p$i -o pmc --output-format csv -- python $R/bench.py --workload 1x_hurrdeblur_1080p --batch 1 --tile 0 --no-cpu-baseline --steps 10 --warmup 2 > $OUT.log 2>&1 || { echo "group failed: $grp"; tail -3 $OUT.log; }
 done
 python - "$OUT" <<'PY'
 import csv, glob, sys, statistics, collections

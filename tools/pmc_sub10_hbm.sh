@@ -3,7 +3,7 @@
 # Run on the GPU box:  bash tools/pmc_sub10_hbm.sh
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-B="python $R/bench.py --workload 1x_hurrdeblur_1080p --no-cpu-baseline --steps 6 --warmup 2"
+B="python $R/bench.py --workload 1x_hurrdeblur_1080p --batch 1 --no-cpu-baseline --steps 6 --warmup 2"
 rm -rf /tmp/s10hbm
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/s10hbm/pmc_fetch -o p -- $B > /tmp/s10hbm_f.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/s10hbm/pmc_write -o p -- $B > /tmp/s10hbm_w.log 2>&1

@@ -6,6 +6,8 @@ TAG=${1:-r02_x}
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
+exec < /dev/null                        # nothing here may wait for a terminal (a rocm-smi prompt once cost a call its whole limit)
+export UVA_DEBUG_SWITCHES=1             # the A/B lines below use the library's debug switches (ignored without the opt-in)
 bash "$REPO/tools/collect_profiles.sh" "$TAG" > "$OUT/collect.log" 2>&1
 cd "$REPO"
 # same-box A/B against earlier kernels shipped beside the library: upscale_video_amd/libuva_prev.so = round 4's trunk kernel
@@ -39,8 +41,15 @@ UVA_SUB5=1 python bench.py --workload 1x_hurrdeblur_1080p --steps 100 --warmup 1
 UVA_TW_FOLD=0 python bench.py --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_no_folded_strips.json" 2>> "$OUT/bench.err"
 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/${TAG}_bench_driver_form.json" 2>> "$OUT/bench.err"
 python bench.py --gpus 8 --devices 0,0,0,0,0,0,0,0 --workload 2x_compact_2160p --steps 8 --warmup 2 --no-cpu-baseline --no-parity > "$OUT/${TAG}_bench_config5_eight_ranks_one_gpu.json" 2>> "$OUT/bench.err"
+# round 6: the 1x net one, two and four frames per launch (uva_net_process_u8_device_batch; the workload's default is four), two
+# ranks on the one GPU with the static and the dynamic frame queue (per-rank records), the driver's N > 1 form with one rank
+for b in 1 2 4; do python bench.py --workload 1x_hurrdeblur_1080p --batch $b --steps 200 --warmup 20 --no-cpu-baseline > "$OUT/${TAG}_bench_1x_batch$b.json" 2>> "$OUT/bench.err"; done
+python bench.py --gpus 2 --devices 0,0 --dynamic --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_two_ranks_one_gpu_dynamic.json" 2>> "$OUT/bench.err"
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --dynamic --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/${TAG}_bench_torchrun_one_rank_dynamic.json" 2>> "$OUT/bench.err"
+python tools/png_decode_split.py 9 > "$OUT/${TAG}_png_decode_split.txt" 2>&1
+python tools/pipe_bench.py 200 > "$OUT/${TAG}_pipe_bench.txt" 2>&1
 python bench.py --workload 1x_hurrdeblur_1080p --tile 960 --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_1x_tiled_960.json" 2>> "$OUT/bench.err"
-(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d /tmp/prof1x_$TAG -o p --output-format csv -- python $REPO/bench.py --workload 1x_hurrdeblur_1080p --tile 0 --steps 120 --warmup 10 --no-cpu-baseline --no-parity > /dev/null 2>&1; cp $(find /tmp/prof1x_$TAG -name "*kernel_stats.csv" | head -1) "$OUT/${TAG}_kernel_stats_1x_rocprofv3.csv")
+(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d /tmp/prof1x_$TAG -o p --output-format csv -- python $REPO/bench.py --workload 1x_hurrdeblur_1080p --batch 1 --tile 0 --steps 120 --warmup 10 --no-cpu-baseline --no-parity > /dev/null 2>&1; cp $(find /tmp/prof1x_$TAG -name "*kernel_stats.csv" | head -1) "$OUT/${TAG}_kernel_stats_1x_rocprofv3.csv")
 bash tools/pmc_sub10.sh /tmp/pmc_sub10_$TAG > "$OUT/${TAG}_sub10_pmc.txt" 2>&1
 python tools/png_route_bench.py 384 > "$OUT/${TAG}_png_route_bench.txt" 2>&1
 python tools/png_gpu_route_bench.py 240 > "$OUT/${TAG}_png_gpu_route_bench.txt" 2>&1

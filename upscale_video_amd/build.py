@@ -14,11 +14,12 @@ LIB = os.path.join(_HERE, "libuva.so")
 _UVA_H = os.path.join("..", "..", "include", "uva.h")
 # source -> the headers it includes (directly or not)
 SOURCES = {
-    "uva_api.hip": ["uva_kernels.hip.h", "uva_devutil.hip.h", "uva_wino.h", "uva_sub5.h", "uva_sub10.h", "uva_rdb.hip.h", "uva_generic.hip.h", "uva_generic.h",
+    "uva_api.hip": ["uva_kernels.hip.h", "uva_devutil.hip.h", "uva_wino.h", "uva_sub5.h", "uva_sub10.h", "uva_sw.h", "uva_rdb.hip.h", "uva_generic.hip.h", "uva_generic.h",
                     "uva_model.h", "uva_png.hip.h", "uva_denoise.hip.h", _UVA_H],
     "uva_wino.hip": ["uva_wino.hip.h", "uva_wino.h", "uva_devutil.hip.h"],
     "uva_sub5.hip": ["uva_sub5.hip.h", "uva_sub5.h", "uva_devutil.hip.h", "uva_model.h"],
     "uva_sub10.hip": ["uva_sub10.hip.h", "uva_sub10.h", "uva_devutil.hip.h", "uva_model.h"],
+    "uva_sww.hip": ["uva_sww.hip.h", "uva_sw.h", "uva_devutil.hip.h"],
     "uva_model.cpp": ["uva_model.h"],
     "uva_generic.cpp": ["uva_generic.h", "uva_model.h"],
     "uva_pngread.cpp": [_UVA_H],

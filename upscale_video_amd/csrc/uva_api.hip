@@ -1000,6 +1000,12 @@ int ensure_device(uva_net* n)
                 if (upload(&cd.wpk_lds, pkl.data(), pkl.size() * 2, n->stream)) return 1;
                 HIP_TRY(hipStreamSynchronize(n->stream));
             }
+            if (gl.ksize == 3 && cd.cin_pad == 192 && cd.cout_pad == 64) {           // a dense block's last convolution: g_conv3_sww
+                std::vector<uint16_t> pkw;
+                pack_generic_wino(c, cd.cin_pad, cd.cout_pad, pkw);
+                if (upload(&cd.wpk_w, pkw.data(), pkw.size() * 2, n->stream)) return 1;
+                HIP_TRY(hipStreamSynchronize(n->stream));
+            }
             std::vector<float> b((size_t)cd.cout_pad, 0.f);
             std::copy(c.bias.begin(), c.bias.end(), b.begin());
             if (upload(&cd.bias, b.data(), b.size() * 4, n->stream)) return 1;
@@ -1914,7 +1920,17 @@ int generic_run_planes(uva_net* n, bool f32, const std::vector<PlaneJob>& jobs)
                 // g_conv3_sw<6, 1>.  Measured equal within 1 % (profiles/r03_ab_results.txt, block 10: both sit at the package's
                 // power limit), so the simpler kernel stays the default; the other is kept runnable for the next round's work.
                 static const bool sk_on = [] { const char* e = uva::debug_env("UVA_GENERIC_SK"); return e && std::atoi(e) != 0; }();
-                if (variant == 0 && sk_on) { if (launch_sw(g_conv3_sk<2, 0>, 32, sk_lds_bytes())) return 1; }
+                // 192 inputs, round 6: g_conv3_sww -- the same convolution as 1-D Winograd F(2,3), two thirds of the MFMAs
+                // (csrc/uva_sww.hip.h).  UVA_GENERIC_WINO=0: the direct kernels below, the A/B switch.
+                static const bool wino_on = [] { const char* e = uva::debug_env("UVA_GENERIC_WINO"); return !e || std::atoi(e) != 0; }();
+                if ((variant == 0 || variant == 1 || variant == 4) && wino_on && !sk_on && cd.wpk_w) {
+                    sa.wpk = cd.wpk_w;
+                    EvPairScope evp(n, 2, n->prof);
+                    HIP_TRY(evp.begin());
+                    HIP_TRY(launch_conv3_sww(n->stream, plan.grid, sa, variant == 4 ? 0 : 2, variant == 1 ? 2 : 0));
+                    HIP_TRY(evp.end());
+                }
+                else if (variant == 0 && sk_on) { if (launch_sw(g_conv3_sk<2, 0>, 32, sk_lds_bytes())) return 1; }
                 else if (variant == 1 && sk_on) { if (launch_sw(g_conv3_sk<2, 2>, 33, sk_lds_bytes())) return 1; }
                 else if (variant == 4 && sk_on) { if (launch_sw(g_conv3_sk<0, 0>, 34, sk_lds_bytes())) return 1; }
                 else if (variant == 0) { if (launch_sw(g_conv3_sw<6, 1, false, 2, 0>, 24, sw_lds_bytes<6, 1>())) return 1; }

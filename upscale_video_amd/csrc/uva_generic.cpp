@@ -437,6 +437,31 @@ bool load_bin_generic(const std::string& path, GenericGraph& g, std::string& err
     return true;
 }
 
+// 3x3 weights as 1-D Winograd F(2,3) along x for g_conv3_sww (csrc/uva_sww.hip.h): per filter row dy the three taps g0, g1, g2
+// become U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2 (fp32 arithmetic on the stored weights, ONE rounding
+// to fp16 each); image [dy*4 + j][cin_pad/32][cout_pad/16][64 lanes][8], natural octet order like pack_generic's.
+void pack_generic_wino(const ConvWeights& c, int cin_pad, int cout_pad, std::vector<uint16_t>& out)
+{
+    const int c32n = cin_pad / 32, mbn = cout_pad / 16;
+    out.assign((size_t)12 * c32n * mbn * 64 * 8, 0);
+    for (int dy = 0; dy < 3; ++dy)
+        for (int c32 = 0; c32 < c32n; ++c32)
+            for (int mb = 0; mb < mbn; ++mb)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int co = 16 * mb + (lane & 15);
+                    if (co >= c.cout) continue;
+                    for (int e = 0; e < 8; ++e) {
+                        const int ci = 32 * c32 + 8 * (lane >> 4) + e;
+                        if (ci >= c.cin) continue;
+                        const float* g = &c.w[((size_t)co * c.cin + ci) * 9 + dy * 3];
+                        // (the stored weights are fp16 values or fp32 ones: either way the transform is taken in fp32)
+                        const float u[4] = {g[0], (g[0] + g[1] + g[2]) * 0.5f, (g[0] - g[1] + g[2]) * 0.5f, g[2]};
+                        for (int j = 0; j < 4; ++j)
+                            out[((((size_t)(dy * 4 + j) * c32n + c32) * mbn + mb) * 64 + lane) * 8 + e] = f32_to_f16_bits(u[j]);
+                    }
+                }
+}
+
 void pack_generic(const ConvWeights& c, int ksize, int cin_pad, int cout_pad, std::vector<uint16_t>& out, bool lds_order)
 {
     const int taps = ksize * ksize, c32n = cin_pad / 32, mbn = cout_pad / 16;

@@ -90,5 +90,6 @@ bool load_bin_generic(const std::string& path, GenericGraph& g, std::string& err
 // 16*mb + i and input channels 32*c32 + 8*octet .. +7 of that tap; out-of-range -> 0.
 // lds_order: the image g_conv3_lds reads -- the lane groups (lane >> 4) = 0..3 hold the octets {0, 2, 1, 3} of the 32.
 void pack_generic(const ConvWeights& c, int ksize, int cin_pad, int cout_pad, std::vector<uint16_t>& out, bool lds_order = false);
+void pack_generic_wino(const ConvWeights& c, int cin_pad, int cout_pad, std::vector<uint16_t>& out);     // 3x3 only: g_conv3_sww's image
 
 }  // namespace uva

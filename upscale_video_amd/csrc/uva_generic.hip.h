@@ -670,6 +670,7 @@ struct GenericDevice {
     struct ConvDev {
         half8* wpk = nullptr;
         half8* wpk_lds = nullptr;     // g_conv3_lds's image (3x3 convolutions with <= 64 output channels)
+        half8* wpk_w = nullptr;       // g_conv3_sww's image (192 -> 64, 3x3: pack_generic_wino)
         float* bias = nullptr;
         int cin_pad = 0, cout_pad = 0;
     };
@@ -692,6 +693,7 @@ struct GenericDevice {
         for (auto& c : convs) {
             if (c.wpk) (void)hipFree(c.wpk);
             if (c.wpk_lds) (void)hipFree(c.wpk_lds);
+            if (c.wpk_w) (void)hipFree(c.wpk_w);
             if (c.bias) (void)hipFree(c.bias);
         }
         convs.clear();

@@ -25,6 +25,7 @@
 #include <stdint.h>
 
 #include "uva_kernels.hip.h"
+#include "uva_sw.h"
 
 #define UVA_SW_D 3
 #define UVA_RA_D 2       // rdb4_kernel: k-steps (of 3 fragment reads) the reads run ahead of the MFMAs
@@ -37,33 +38,6 @@
 
 namespace uva {
 
-struct GSwSeg { int c0, y0, y1, plane; };     // output columns [c0, c0 + SW_C) x rows [y0, y1) of plane `plane`, y1 - y0 a multiple
-                                              // of 4 except at the plane's bottom
-constexpr int GEN_MAX_PLANES = 16;            // planes (reference tiles) of a frame that one launch of the kernels below takes
-
-struct GSwArgs {
-    // per plane (all planes of a launch: same layer, same strides): zero-bordered arrays [(h+3)][(w+2)][stride], pixel (y, x)
-    // at row y+1, column x+1
-    const _Float16* in[GEN_MAX_PLANES];     // channels read: [0, 32*KC)
-    _Float16* out[GEN_MAX_PLANES];
-    const _Float16* res[GEN_MAX_PLANES];    // the element-wise sum behind the convolution (GConvArgs::res: same expression, same rounding)
-    const _Float16* res2[GEN_MAX_PLANES];   // ... and a second sum behind the first: out = x2*ca2 + y2*cb2, one of them the first sum's result
-    int ph[GEN_MAX_PLANES], pw[GEN_MAX_PLANES];
-    int in_stride;                // elements per pixel
-    const half8* wpk;             // pack_generic image (natural octet order): [tap][KC][4][64 lanes][8]
-    const float* bias;            // [64]
-    int out_stride, out_coff;
-    float slope;                  // LeakyReLU (template ACT)
-    int res_stride;
-    float ca, cb;
-    int res2_stride;
-    float ca2, cb2;
-    const GSwSeg* segs;           // this launch's segments; workgroup g owns segs[seg_begin[g] .. seg_begin[g+1])
-    const int* seg_begin;
-    _Float16* sink;               // >= 64 * 8 bytes: where lanes outside the plane store to
-};
-
-constexpr int SW_R = 4;                       // output rows per block
 constexpr int SW_SLOTS = 10;                  // ring rows: 6 of the current block + the 4 new ones of the next
 template <int MBW> constexpr int sw_cols() { return 32 * (MBW == 1 ? 1 : 2); }       // output columns per strip
 template <int KC, int MBW> constexpr int sw_np() { return (KC * (sw_cols<MBW>() + 2) * 4 + 63) / 64; }   // 1-KiB LDS-DMA pieces per ring row
@@ -72,20 +46,6 @@ template <int KC, int MBW> constexpr int sw_lds_bytes() { return SW_SLOTS * sw_r
 static_assert(sw_lds_bytes<6, 1>() <= 160 * 1024 && sw_lds_bytes<2, 2>() <= 160 * 1024, "g_conv3_sw LDS budget");
 
 __device__ __forceinline__ void sw_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// out = x*ca + y*cb of an element-wise sum (BinaryOp ADD, Eltwise SUM with coefficients), rounded to fp16: ONE spelling
-// for every kernel that computes it (g_axpby, g_axpby_strided and the convolution epilogues that absorb a sum), so that a
-// sum gives the same bytes whichever kernel does it -- left to the compiler, `x*ca + y*cb` contracts into an fma around
-// either product
-__device__ __forceinline__ _Float16 g_axpby1(float x, float ca, float y, float cb)
-{
-    // The fp32 result is made opaque before it is rounded to fp16: where the compiler sees both steps it may pick
-    // v_fma_mixlo_f16, which rounds the exact fma ONCE -- other call sites round twice (fp32, then fp16), and the two
-    // differ in rare ties.
-    float t = __builtin_fmaf(x, ca, y * cb);
-    asm volatile("" : "+v"(t));
-    return (_Float16)t;
-}
 
 // RES / RES2: the first / second fused sum -- 0 none, 1 the other operand is the sum's x (out = res*ca + conv*cb), 2 the
 // convolution's side is (out = conv*ca + res*cb); g_axpby1 is not symmetric in x and y, so the order is part of the bytes

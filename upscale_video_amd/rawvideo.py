@@ -218,6 +218,8 @@ def stream(fin, fout, h, w, nets_tiles, alloc=None, max_frames=None, write_threa
             k = os.pwrite(fd, view, pos)
             view, pos = view[k:], pos + k
 
+    sink = PipeSink(fout)
+
     def writer():
         pos = pos0 if fd is not None else 0
         try:
@@ -227,10 +229,10 @@ def stream(fin, fout, h, w, nets_tiles, alloc=None, max_frames=None, write_threa
                     if fd is not None:
                         fout.seek(pos)
                     return
-                view = memoryview(item).cast("B")
                 if fd is None:
-                    fout.write(view)
+                    sink.write(item)
                     continue
+                view = memoryview(item).cast("B")
                 n = len(view)
                 per = -(-n // write_threads)
                 piece = -(-per // (1 << 20)) * (1 << 20)              # whole MiB per writer
@@ -454,6 +456,68 @@ def grow_pipe(f):
         pass
 
 
+class PipeSink:
+    """The writer's end of a PIPE (stdout into ffmpeg): result frames go in with vmsplice(2) -- the pipe then refers to the pages
+    of our page-locked result buffer and the only copy left is the reader's -- instead of write(2), which allocates a pipe page
+    and copies into it for every 4 KiB (one thread manages ~6 GB/s of that: 250 4K frames a second, half of what one GPU
+    delivers; profiles/r05_final_rawvideo_bench.txt).  No SPLICE_F_GIFT: the pages stay ours, so a buffer must not be rewritten
+    while the pipe still refers to it -- vmsplice returns once the LAST piece of a frame is in the pipe, whose capacity is far
+    below one frame, so when frame k + 1 has been handed over frame k has been read completely; the result rings hold eight
+    buffers (Stage.outs).  Falls back to write() for good the first time the kernel refuses (memory it cannot take
+    references on, a pipe that went away is an error as before)."""
+
+    class _IoVec(__import__("ctypes").Structure):
+        _fields_ = [("base", __import__("ctypes").c_void_p), ("len", __import__("ctypes").c_size_t)]
+
+    def __init__(self, f):
+        import ctypes
+        import stat
+        self._f = f
+        self._fd = None
+        self._cap = None            # the pipe's capacity, asked for at the first frame (grow_pipe may come after the constructor)
+        self.spliced = 0            # frames that went through vmsplice (tests, the bench's log line)
+        try:
+            fd = f.fileno()
+            if stat.S_ISFIFO(os.fstat(fd).st_mode) and os.environ.get("UVA_RAW_VMSPLICE", "1") != "0":
+                self._libc = ctypes.CDLL(None, use_errno=True)
+                self._libc.vmsplice.restype = ctypes.c_ssize_t
+                self._fd = fd
+        except (AttributeError, OSError, ValueError):
+            self._fd = None
+
+    def write(self, arr):
+        """arr: a C-contiguous numpy array (a result buffer of a Stage)"""
+        import ctypes
+        if self._fd is not None and self._cap is None:
+            import fcntl
+            try:
+                self._cap = fcntl.fcntl(self._fd, getattr(fcntl, "F_GETPIPE_SZ", 1032))
+            except OSError:
+                self._cap = 1 << 30
+        if self._fd is None or arr.nbytes < self._cap:        # (frames smaller than the pipe: several could sit in it, still referred to)
+            self._f.write(memoryview(arr).cast("B"))
+            return
+        self._f.flush()             # (nothing of ours is buffered in front of the spliced bytes)
+        addr, n, off = arr.ctypes.data, arr.nbytes, 0
+        while off < n:
+            iov = self._IoVec(addr + off, n - off)
+            k = self._libc.vmsplice(self._fd, ctypes.byref(iov), 1, 0)
+            if k < 0:
+                err = ctypes.get_errno()
+                if err == 4:        # EINTR
+                    continue
+                if off == 0 and err in (14, 22, 38):      # EFAULT / EINVAL / ENOSYS: this memory or this kernel cannot
+                    self._fd = None
+                    self._f.write(memoryview(arr).cast("B"))
+                    return
+                raise OSError(err, os.strerror(err))
+            off += k
+        self.spliced += 1
+
+    def flush(self):
+        self._f.flush()
+
+
 def copy_through(fin, fout, h, w, max_frames=None):
     """`-s 1` without `-m a`: the reference renames the frames, nothing is computed (:924-929)."""
     buf = bytearray(h * w * 3)
@@ -550,7 +614,16 @@ def main(argv=None):
                 ap.error("%s is input and output at once" % o)
     wthreads = max(1, a.write_threads)
     regular = all(os.path.isfile(f) for f in ins) and all(not os.path.exists(f) or os.path.isfile(f) for f in outs)
-    if nets and (len(ins) > 1 or len(outs) > 1 or (len(nets) > 1 and not a.round_robin and a.input != "-" and a.output != "-" and regular)):
+    # ONE output file on tmpfs: every write into it allocates its pages under the inode's lock, so several workers writing their
+    # segments into it are SLOWER than one (246.7 -> 208.3 -> 162.4 frames/s at 1 / 4 / 8 workers, profiles/r05_final_rawvideo_bench.txt;
+    # a disk-backed file system scales: 201 -> 431 -> 614).  There the workers feed ONE writer thread instead (the pipe route's
+    # shape: one reader, frames dealt round-robin, results written in order) -- never slower than one worker.  `-o a,b,..` (a file
+    # per worker) is the way past the lock and keeps its segments.
+    one_file_on_tmpfs = (len(nets) > 1 and len(outs) == 1 and a.output != "-" and
+                         filesystem_type(os.path.dirname(os.path.abspath(a.output)) or ".") in ("tmpfs", "ramfs") and
+                         os.environ.get("UVA_RAW_TMPFS_SEGMENTS") != "1")
+    if nets and (len(ins) > 1 or len(outs) > 1 or (len(nets) > 1 and not a.round_robin and not one_file_on_tmpfs and
+                                                   a.input != "-" and a.output != "-" and regular)):
         if not regular:
             ap.error("-i / -o lists take regular files")
         scale_total = 1
