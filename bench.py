@@ -812,7 +812,7 @@ def run(args, comm, device):
                 "frames_per_rank": args.steps, "tile_size": args.tile, "parallelism": f"frame-sharded x{world}, no collective",
                 "timed_regions_s": [round(x, 5) for x in regions], "reported": "median region (value and kernel event statistics)",
                 "frame_tflop": round(frame_flops / 1e12, 4), "whole_path_tflops": round(frame_flops * fps / world / 1e12, 1),
-                "kernel_ms_per_frame": {"rdb4_kernel": round(trunk_ms / steps_timed, 3), "conv5 (g_conv3_sw<6,1>)": round(tail_ms / steps_timed, 3)},
+                "kernel_ms_per_frame": {"rdb4_kernel": round(trunk_ms / steps_timed, 3), "conv5 (g_conv3_sww: 192 -> 64 as Winograd F(2,3))": round(tail_ms / steps_timed, 3)},
                 "numa_cpus_rank0": (len(numa_cpus) if numa_cpus else None),
                 "pinned_host_bytes_all_ranks": pinned_need, "host_memory_available_bytes": pinned_avail,
                 "frame_queue": "dynamic (one shared counter)" if counter is not None else "static (frames r, r + N, ...)",

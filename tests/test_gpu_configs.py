@@ -321,7 +321,7 @@ def test_bench_valar_workload(tmp_path):
     assert 5.0 < d["value"] < 30.0 and d["config"]["frame_tflop"] == pytest.approx(74.93, abs=0.01)
     assert d["roofline"]["bound"] == "mfma" and 0.1 < d["roofline"]["frac"] < 1.0 and d["roofline"]["launches"] == 3 * 69 and d["roofline"]["launches_per_frame"] == 69
     k = d["config"]["kernel_ms_per_frame"]
-    assert 0 < k["rdb4_kernel"] + k["conv5 (g_conv3_sw<6,1>)"] < d["ms_per_step"]
+    assert 0 < sum(k.values()) < d["ms_per_step"]
     assert d["config"]["host_route_fps_pcie_inclusive"] > 0 and "random-init" in d["data"]
     # a complete line: the CPU restatement timed on a crop beside it, and the kernel's HBM bytes per launch from the PMC summary
     assert d["cpu_baseline"]["kind"] == "port" and 0 < d["cpu_baseline"]["value"] < 0.05

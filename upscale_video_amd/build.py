@@ -123,11 +123,17 @@ def rebuild_trunkw(out, defines=(), verbose=False):
         for src in SOURCES:
             obj = _obj(objdir, src)
             if src == "uva_wino.hip" or _stale(obj, src):
-                dst = os.path.join(tmp, os.path.basename(obj)) if src == "uva_wino.hip" else obj
-                cmd = [hipcc()] + FLAGS + list(defines) + ["-c", os.path.join(CSRC, src), "-o", dst]
+                # (the kernel's object stays in the scratch directory; a stale object of another file is rebuilt for good, through
+                # a temporary name like _build's, so that a concurrent build never links half a file)
+                dst = os.path.join(tmp, os.path.basename(obj))
+                cmd = [hipcc()] + FLAGS + list(defines if src == "uva_wino.hip" else []) + ["-c", os.path.join(CSRC, src), "-o", dst]
                 if verbose:
                     print(" ".join(cmd))
                 subprocess.check_call(cmd)
+                if src != "uva_wino.hip":
+                    keep = "%s.tmp.%d" % (obj, os.getpid())
+                    shutil.copyfile(dst, keep)
+                    os.replace(keep, obj)
                 obj = dst
             objs.append(obj)
         subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out])

@@ -655,6 +655,8 @@ int build_trunkw_schedule(const std::vector<PlaneDesc>& planes, int grid, size_t
                 for (int r = 0; r < 4; ++r)
                     if (yA + r >= 0 && yA + r < p.h) rmask |= 1u << r;
                 const unsigned c_lo = sg.x0 == 0 ? 1 : 0, c_hi = (unsigned)std::min(32, p.w - sg.x0 + 1);
+                // (a folded step carries its first plane's index in .z's top byte: the debug view's, the kernel masks it off)
+                if (sg.fold >= 0 && sg.plane > 255) return fail("trunkw schedule: more than 256 planes with folded strips");
                 // a folded step: the second plane's pixels lie fold_add + 2048 bytes behind the first's
                 const unsigned fold_add = sg.fold >= 0 ? (unsigned)(((long long)planes[sg.fold].act_off - (long long)p.act_off) * PIXB - 2048) : 0u;
                 out[g].a = make_uint4((unsigned)ao, (unsigned)(ao >> 32) | (rmask << 8) | (c_lo << 12) | (c_hi << 18) | (1u << 24) |

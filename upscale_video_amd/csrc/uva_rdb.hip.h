@@ -226,15 +226,19 @@ __global__ __launch_bounds__(256, 1) void g_conv3_sw(GSwArgs a)
             constexpr int cd = idx / NIR, ir = idx - cd * NIR, c = cd / 3, dx = cd - 3 * c;
             if constexpr (idx + D < NSTEP) rd(idx + D, bq[(idx + D) % (D + 1)]);
             constexpr int ndy = (ir < 3 ? ir + 1 : 3) - (ir >= SW_R ? ir - SW_R + 1 : 0);     // tap rows with an output row in the block
+            // fragment-major: a B fragment feeds its tap rows and channel blocks back to back (neighbours that share the B operand
+            // draw less at the power cap than neighbours that share the weights: tools/mfma_operand_order_bench.hip; every
+            // accumulator still sees its own additions in the same order: the same bytes)
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                const int r = ir - dy;
-                if (r < 0 || r >= SW_R) continue;
+            for (int f = 0; f < NF; ++f) {
 #pragma unroll
-                for (int f = 0; f < NF; ++f)
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int r = ir - dy;
+                    if (r < 0 || r >= SW_R) continue;
 #pragma unroll
                     for (int m = 0; m < MBW; ++m)
                         acc[r][f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wgt[dy * 3 + dx][c][m], bq[idx % (D + 1)][f], acc[r][f][m], 0, 0, 0);
+                }
             }
             if constexpr (idx + D < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, UVA_SW_HALFREAD ? 1 : NF, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, ndy * NF * MBW, 0);

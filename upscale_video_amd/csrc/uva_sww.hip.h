@@ -240,12 +240,15 @@ __global__ __launch_bounds__(256, 1) void g_conv3_sww(GSwArgs a)
             constexpr int g = decltype(G)::value, ir = g / KC, c = g - ir * KC;
             if constexpr (g + 2 < NG) rd(g + 2, d[g & 1]);
             if constexpr (g + 1 < NG) transform(d[(g + 1) & 1], v[(g + 1) & 1]);
+            // B-operand-major: a transformed fragment Vj feeds its (up to three) tap rows back to back.  At the power cap the order
+            // matters: neighbours that share the B operand run 10 % faster than neighbours that share nothing, neighbours that share
+            // the weights only 3 % (tools/mfma_operand_order_bench.hip, profiles/r06h/) -- trunkw_kernel's order, and now this one's.
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                const int r = ir - dy;
-                if (r < 0 || r >= SW_R) continue;
+            for (int j = 0; j < 4; ++j) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int r = ir - dy;
+                    if (r < 0 || r >= SW_R) continue;
                     const bool first = dy == 0 && c == 0;
                     acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wgt[dy * 4 + j][c], v[g & 1][j], first ? (j == 1 ? bias4 : zero4) : acc[r][j], 0, 0, 0);
                 }

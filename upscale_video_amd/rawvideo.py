@@ -311,7 +311,11 @@ class MappedSegment:
         gran = mmap.ALLOCATIONGRANULARITY
         base = offset - offset % gran
         self._pos = offset - base
-        self._mm = mmap.mmap(f.fileno(), self._pos + nbytes, access=mmap.ACCESS_WRITE, offset=base)
+        try:
+            self._mm = mmap.mmap(f.fileno(), self._pos + nbytes, access=mmap.ACCESS_WRITE, offset=base)
+        except Exception:
+            f.close()                            # (the handle was handed over: nobody else closes it)
+            raise
         self._arr = np.frombuffer(self._mm, np.uint8)
         self._populate = hasattr(self._mm, "madvise")
 
@@ -545,7 +549,7 @@ def main(argv=None):
                     help="HIP ordinals, one worker per entry, e.g. 0,1,2,3 or 0,0,1 (upscale_video.py -g; default 0)")
     ap.add_argument("--tile", type=int, default=TILE_SIZE, help="reference tile size of the final pass (960); 0 = whole frame")
     ap.add_argument("--frames", type=int, default=None, help="stop after this many frames")
-    ap.add_argument("--write-threads", type=int, default=0,
+    ap.add_argument("--write-threads", type=int, default=1,
                     help="positional writers per worker for a regular output file (default 1: more gained 10 %% on a disk-backed file "
                          "system and lost 40 %% on tmpfs)")
     ap.add_argument("--round-robin", action="store_true",
