@@ -407,3 +407,35 @@ def test_frames_smaller_than_the_pipe_are_written_not_spliced():
         sink.write(a)
         sink.flush()
         assert sink.spliced == 0 and fin.read(300) == a.tobytes()
+
+
+def test_the_pipe_is_drained_before_the_buffers_go(monkeypatch):
+    """stream() returns only when the reader has taken the last spliced bytes (the pipe refers to the result buffers' pages)"""
+    import threading
+    import time
+    monkeypatch.setenv("UVA_RAW_VMSPLICE", "1")
+    h, w, nframes = 120, 160, 4
+    frames = _frames(nframes, h, w)
+    r, wfd = os.pipe()
+    state = {"returned_at": None, "read_done_at": None}
+    got = []
+
+    def reader():
+        time.sleep(0.3)                                     # the reader starts late: the last frame's tail sits in the pipe
+        with os.fdopen(r, "rb") as f:
+            while True:
+                b = f.read(2 * h * 2 * w * 3)
+                if not b:
+                    break
+                got.append(b)
+                if len(got) == nframes:
+                    state["read_done_at"] = time.monotonic()
+    t = threading.Thread(target=reader)
+    t.start()
+    with os.fdopen(wfd, "wb") as fout:
+        n = rawvideo.stream(io.BytesIO(b"".join(f.tobytes() for f in frames)), fout, h, w, [(FakeNet(2), 0)],
+                            alloc=lambda s: np.empty(s, np.uint8))
+        state["returned_at"] = time.monotonic()
+    t.join()
+    assert n == nframes and len(got) == nframes
+    assert state["returned_at"] >= state["read_done_at"] - 0.05, state      # not before the reader had everything

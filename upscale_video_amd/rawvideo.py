@@ -279,6 +279,7 @@ def stream(fin, fout, h, w, nets_tiles, alloc=None, max_frames=None, write_threa
     if werr:
         raise werr[0]
     fout.flush()
+    sink.drain()
     return written
 
 
@@ -520,6 +521,27 @@ class PipeSink:
 
     def flush(self):
         self._f.flush()
+
+    def drain(self, timeout=60.0):
+        """After the LAST frame: wait until the reader has taken every spliced byte out of the pipe (FIONREAD = 0).  The pipe
+        refers to our buffers' pages; the caller is about to free them (page-locked memory goes back to the driver's pool), and
+        what the reader then found in the pipe's last megabyte would be whatever the pool did with those pages."""
+        if self._fd is None or not self.spliced:
+            return
+        import array
+        import fcntl
+        import termios
+        import time
+        t0 = time.monotonic()
+        n = array.array("i", [0])
+        while time.monotonic() - t0 < timeout:
+            try:
+                fcntl.ioctl(self._fd, termios.FIONREAD, n, True)
+            except OSError:
+                return                      # (the reader went away: nothing to protect)
+            if n[0] == 0:
+                return
+            time.sleep(0.001)
 
 
 def copy_through(fin, fout, h, w, max_frames=None):
