@@ -122,16 +122,27 @@ def job_scratch_dir():
     """where the ranks of THIS job meet on the node's file system (per-rank records, --dynamic's counter): launch_ranks makes it
     for self-launched ranks; under torch.distributed.run it is named after the rendezvous port"""
     d = os.environ.get("UVA_BENCH_JOB_DIR")
-    if not d:
-        base = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
-        d = os.path.join(base, "uva_bench_%s_%s" % (os.environ.get("MASTER_PORT", "solo"), os.environ.get("TORCHELASTIC_RUN_ID", os.getppid())))
-    os.makedirs(d, exist_ok=True)
-    return d
+    if d:
+        os.makedirs(d, exist_ok=True)
+        return d
+    import tempfile
+    name = "uva_bench_%s_%s" % (os.environ.get("MASTER_PORT", "solo"), os.environ.get("TORCHELASTIC_RUN_ID", os.getppid()))
+    for base in ("/dev/shm", tempfile.gettempdir(), ROOT):          # (the first one this user may write to)
+        try:
+            d = os.path.join(base, name)
+            os.makedirs(d, exist_ok=True)
+            if os.access(d, os.W_OK):
+                return d
+        except OSError:
+            continue
+    raise SystemExit("bench.py: no writable directory for the ranks' records (/dev/shm, %s, %s)" % (tempfile.gettempdir(), ROOT))
 
 
 def gather_records(comm, record):
     """every rank's dict -> the list of all of them, in rank order, on every rank (through the job's scratch directory and two
     fences: no collective, any launcher)"""
+    if comm.world == 1:
+        return [record]                 # (one rank: nothing to exchange, no file system involved)
     d = job_scratch_dir()
     tmp = os.path.join(d, "rank%d.json.tmp" % comm.rank)
     with open(tmp, "w") as f:
