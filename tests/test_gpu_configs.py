@@ -241,6 +241,47 @@ def test_bench_starts_its_own_ranks():
 
 
 @pytest.mark.gpu
+def test_bench_dynamic_queue_and_per_rank_records_on_the_box():
+    """Round 6: `--dynamic` -- the ranks take frame indices off ONE shared counter -- and the per-rank records
+    of the one JSON line, with two self-launched ranks on the box's one GPU: every frame done exactly once between them, every
+    rank's own device, NUMA node, K / E rates, PCIe rates and first-frame time in the line, the summary beside them."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("UVA_BENCH_JOB_DIR", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--devices", "0,0", "--dynamic", "--steps", "24",
+                        "--warmup", "4", "--no-cpu-baseline", "--no-parity"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and "dynamic" in d["config"]["frame_queue"]
+    pr = d["per_rank"]
+    assert [x["rank"] for x in pr] == [0, 1] and sum(x["frames_K"] for x in pr) == 2 * 24
+    for x in pr:
+        assert x["device"] == 0 and x["fps_K"] > 0 and x["fps_E"] > 0 and x["h2d_GBps"] > 1 and x["d2h_GBps"] > 1 and x["first_frame_ms"] > 0
+    assert {"fps_K", "fps_E", "h2d_GBps", "d2h_GBps", "first_frame_ms", "frames_K"} <= set(d["per_rank_summary"])
+
+
+@pytest.mark.gpu
+def test_bench_batches_the_1x_net():
+    """`--workload 1x_hurrdeblur_1080p` hands four frames per call to uva_net_process_u8_device_batch by default: one sub10_kernel
+    launch per four frames in the kernel statistics, the roofline's FLOPs and the replayed traffic per LAUNCH, the one-frame-per-call
+    rate of the same run beside it -- and the batch is the faster of the two"""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "1x_hurrdeblur_1080p", "--steps", "80", "--warmup", "8",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=dict(os.environ))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    rf = d["roofline"]
+    assert d["config"]["frames_per_call"] == 4 and rf["frames_per_launch"] == pytest.approx(4.0) and rf["launches"] == 20
+    assert rf["flops_per_launch"] == pytest.approx(4 * 85536 * 1080 * 1920)
+    assert d["value"] > d["config"]["one_frame_per_call_fps"] > 0.5 * d["value"]
+    assert d["parity"]["max_abs_lsb"] <= 1
+
+
+@pytest.mark.gpu
 def test_config5_line_eight_ranks_on_the_one_gpu():
     """BASELINE config 5's bench line -- `python bench.py --gpus 8 --workload 2x_compact_2160p` -- with all
     eight ranks on the box's one GPU (`--devices 0,0,0,0,0,0,0,0`): eight spawned processes, eight sets of page-locked rings
