@@ -2,7 +2,7 @@
 (UVA_RAW_TMPFS_SEGMENTS=1).  The output file is removed before every run (a file that exists keeps its pages: rewriting it is not
 what a job does)."""
 import os, subprocess, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from upscale_video_amd.synth import synthetic_frame
 N = 400
 src, dst = "/dev/shm/uva_in.bgr24", "/dev/shm/uva_out.bgr24"
