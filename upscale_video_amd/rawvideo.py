@@ -29,6 +29,7 @@ UVA_RAW_MMAP=1: slower than write() on tmpfs, equal on overlay) and `--write-thr
 written with os.pwrite by a pool: +10 % for one worker on overlay, -40 % on tmpfs; default 1).
 """
 import argparse
+import ctypes
 import mmap
 import os
 import sys
@@ -471,11 +472,10 @@ class PipeSink:
     buffers (Stage.outs).  Falls back to write() for good the first time the kernel refuses (memory it cannot take
     references on, a pipe that went away is an error as before)."""
 
-    class _IoVec(__import__("ctypes").Structure):
-        _fields_ = [("base", __import__("ctypes").c_void_p), ("len", __import__("ctypes").c_size_t)]
+    class _IoVec(ctypes.Structure):
+        _fields_ = [("base", ctypes.c_void_p), ("len", ctypes.c_size_t)]
 
     def __init__(self, f):
-        import ctypes
         import stat
         self._f = f
         self._fd = None
@@ -492,7 +492,6 @@ class PipeSink:
 
     def write(self, arr):
         """arr: a C-contiguous numpy array (a result buffer of a Stage)"""
-        import ctypes
         if self._fd is not None and self._cap is None:
             import fcntl
             try:
