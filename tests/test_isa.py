@@ -32,8 +32,8 @@ def test_winograd_conv5_kernel_keeps_what_round_6_fixed(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     text = open(asm).read()
-    kernels = re.findall(r"^(_ZN3uva11g_conv3_swwILi\dELi\dEEEvNS_7GSwArgsE):[^\n]*\n(.*?)s_endpgm", text, flags=re.S | re.M)
-    assert len(kernels) == 3, [k for k, _ in kernels]
+    kernels = re.findall(r"^(_ZN3uva11g_conv3_swwILi\dELi\dELb[01]EEEvNS_7GSwArgsE):[^\n]*\n(.*?)s_endpgm", text, flags=re.S | re.M)
+    assert len(kernels) == 5, [k for k, _ in kernels]       # (no sum; one / two sums with the first operand from HBM or from the LDS ring)
     for name, body in kernels:
         mfma = re.findall(r"v_mfma_f32_16x16x32_f16 [^\n]*", body)
         assert len(mfma) == 288, (name, len(mfma))

@@ -5,10 +5,10 @@
 
 namespace uva {
 
-template <int RES, int RES2>
+template <int RES, int RES2, bool RL>
 static hipError_t launch_one(hipStream_t stream, int grid, const GSwArgs& a)
 {
-    auto kfn = g_conv3_sww<RES, RES2>;
+    auto kfn = g_conv3_sww<RES, RES2, RL>;
     static std::atomic<bool> attr_done[64];       // per device: the kernel's 133 KB of dynamic LDS must be allowed once
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -24,9 +24,13 @@ static hipError_t launch_one(hipStream_t stream, int grid, const GSwArgs& a)
 
 hipError_t launch_conv3_sww(hipStream_t stream, int grid, const GSwArgs& a, int res, int res2)
 {
-    if (res == 0 && res2 == 0) return launch_one<0, 0>(stream, grid, a);
-    if (res == 2 && res2 == 0) return launch_one<2, 0>(stream, grid, a);
-    if (res == 2 && res2 == 2) return launch_one<2, 2>(stream, grid, a);
+    // the first sum's other operand is the convolution's own input (every plane: the same array, the same pixel stride)?
+    bool in_ring = res != 0 && a.res_stride == a.in_stride;
+    for (int pl = 0; pl < GEN_MAX_PLANES && in_ring; ++pl)
+        if (a.in[pl] && a.res[pl] != a.in[pl]) in_ring = false;
+    if (res == 0 && res2 == 0) return launch_one<0, 0, false>(stream, grid, a);
+    if (res == 2 && res2 == 0) return in_ring ? launch_one<2, 0, true>(stream, grid, a) : launch_one<2, 0, false>(stream, grid, a);
+    if (res == 2 && res2 == 2) return in_ring ? launch_one<2, 2, true>(stream, grid, a) : launch_one<2, 2, false>(stream, grid, a);
     return hipErrorInvalidValue;
 }
 

@@ -46,9 +46,14 @@ constexpr int SWW_SLOTS = 10;
 constexpr int sww_lds_bytes() { return SWW_SLOTS * SWW_ROWB + 256; }
 static_assert(sww_lds_bytes() <= 160 * 1024, "g_conv3_sww LDS budget");
 
-template <int RES, int RES2>
+// RL: the FIRST sum's other operand is the convolution's own input, channels 0..63 of the same array (a dense block's
+// `x*1.0 + conv5(cat(x, x1..x4))*0.2`: models/4x_Valar_v1.param:16-21) -- then it is already in the LDS ring (the centre tap's
+// pixel) and is read from there, 8 bytes per lane and pixel, instead of being loaded from HBM a second time: a fifth of the
+// kernel's memory traffic and every wait that came with it.  The same fp16 bytes either way.
+template <int RES, int RES2, bool RL>
 __global__ __launch_bounds__(256, 1) void g_conv3_sww(GSwArgs a)
 {
+    static_assert(!RL || RES != 0, "RL needs a first sum");
     constexpr int KC = SWW_KC, RC = SWW_RC, NREC = SWW_NREC, NP = SWW_NP, ROWB = SWW_ROWB;
     constexpr int NIR = SW_R + 2;              // input rows of a block
     constexpr int NPW = (NP + 3) / 4;          // DMA pieces per wave and ring row
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(256, 1) void g_conv3_sww(GSwArgs a)
             if (t * KC + c < SWW_WA) asm volatile("" : "+a"(wgt[t][c]));
 
     const int ch0 = 16 * wave + 4 * o;         // this lane's four output channels
-    constexpr int NL = 2 * ((RES != 0) + (RES2 != 0));      // loads of the sums' other operands per output row
+    constexpr int NL = 2 * ((RES != 0 && !RL) + (RES2 != 0));      // HBM loads of the sums' other operands per output row
     f32x4 acc[SW_R][4];                        // [output row][j]
 #pragma unroll
     for (int r = 0; r < SW_R; ++r)
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(256, 1) void g_conv3_sww(GSwArgs a)
                 // asm loads: invisible to hipcc's s_waitcnt bookkeeping ON PURPOSE.  Its own wait in front of a use would be
                 // vmcnt(k), k = the loads IT knows of behind this one -- and would drain the next block's row DMA (asm too, issued
                 // in between) half a block early.  The uses wait with the exact count instead (res_wait below).
-                if constexpr (RES != 0) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rs[r][q]) : "v"(pres + pos * a.res_stride + ch0) : "memory");
+                if constexpr (RES != 0 && !RL) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rs[r][q]) : "v"(pres + pos * a.res_stride + ch0) : "memory");
                 if constexpr (RES2 != 0) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rw[r][q]) : "v"(pres2 + pos * a.res2_stride + ch0) : "memory");
             }
         }
@@ -171,14 +176,25 @@ __global__ __launch_bounds__(256, 1) void g_conv3_sww(GSwArgs a)
         } else if constexpr (sl == 1) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) cv[q] = half4{(_Float16)ev[q][0], (_Float16)ev[q][1], (_Float16)ev[q][2], (_Float16)ev[q][3]};
+            if constexpr (RL) {
+                // output pixel (row r of block b, column 2p + q) = ring row 4b + r + 1, ring column 2p + q + 1: q = 0 the odd record p,
+                // q = 1 the even record p + 1; this lane's four channels: chunk wave >> 1, unit 2 (wave & 1) + (o >> 1), half o & 1
+                const unsigned rrow = (unsigned)((SW_R * b + r + 1) % SWW_SLOTS) * ROWB + (unsigned)(wave >> 1) * SWW_CHB + (o & 1) * 8;
+                const int u = 2 * (wave & 1) + (o >> 1);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int e = p + q, par = 1 - q;
+                    rs[r][q] = *(const half4*)(ring + rrow + par * (NREC * 64) + e * 64 + ((u ^ (((e >> 2) & 1) << 1)) * 16));
+                }
+            }
         } else if constexpr (sl == 2 || sl == 3) {
             if constexpr (RES != 0) {
                 constexpr int q = sl - 2;
                 // The row's operands were requested in slice 5 of the same row of the previous block.  Behind them, in issue order:
                 // the slice-5 operations (2 stores + NL loads) of the three other rows and the >= 12 DMA pieces of this block --
                 // "all but the newest 3 (2 + NL) + 12 have completed" is exactly "they are here", and waits for nothing younger.
-                if constexpr (sl == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (2 + NL) + 12) : "memory");
-                asm volatile("" : "+v"(rs[r][0]), "+v"(rs[r][1]));
+                if constexpr (sl == 2 && NL > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (2 + NL) + 12) : "memory");
+                if constexpr (!RL) asm volatile("" : "+v"(rs[r][0]), "+v"(rs[r][1]));
                 if constexpr (RES2 != 0) asm volatile("" : "+v"(rw[r][0]), "+v"(rw[r][1]));
                 const half4 rv = rs[r][q];
 #pragma unroll
